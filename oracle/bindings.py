@@ -1,0 +1,373 @@
+"""ctypes bindings for the parity oracle and (when built) the compiled reference.
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never by the product package.
+
+``Oracle``    -> oracle/liboracle.so        (this repo's plain-C restatement)
+``Reference`` -> oracle/_ref/libworld_ref.so (the real reference, compiled by
+                 ``make -C oracle ref`` from /root/reference where it lies)
+
+Both expose the same numpy-level methods so tests can swap one for the other.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def _c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so (always) and _ref (when the reference tree is present)."""
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if ref and os.path.isdir("/root/reference/externs/WORLD_v2/src"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+class Oracle:
+    kind = "port"
+
+    def __init__(self, path: str | None = None):
+        path = path or os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = L = C.CDLL(path)
+        L.orc_dio_samples.restype = C.c_int
+        L.orc_dio_samples.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.orc_harvest_samples.restype = C.c_int
+        L.orc_harvest_samples.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.orc_dio.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_int, C.c_double, _dp, _dp]
+        L.orc_harvest.argtypes = [_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_stonemask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.orc_cheaptrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
+        L.orc_cheaptrick_fft_size.restype = C.c_int
+        L.orc_cheaptrick_fft_size.argtypes = [C.c_int, C.c_double]
+        L.orc_d4c.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp]
+        L.orc_synthesis.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp]
+        L.orc_randn_table.argtypes = [_dp, C.c_int]
+        L.orc_randn_table_u32.argtypes = [C.POINTER(C.c_uint32), C.c_int]
+        L.orc_interp1.argtypes = [_dp, _dp, C.c_int, _dp, C.c_int, _dp]
+        L.orc_interp1q.argtypes = [C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int, _dp]
+        L.orc_decimate.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.orc_nuttall.argtypes = [C.c_int, _dp]
+        L.orc_dc_correction.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.orc_linear_smoothing.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.orc_fft_r2c.argtypes = [_dp, C.c_int, _dp, _dp]
+        L.orc_fft_c2r.argtypes = [_dp, _dp, C.c_int, _dp]
+        L.orc_min_phase.argtypes = [_dp, C.c_int, _dp, _dp]
+        L.orc_matlab_round.restype = C.c_int
+        L.orc_matlab_round.argtypes = [C.c_double]
+        L.orc_suitable_fft_size.restype = C.c_int
+        L.orc_suitable_fft_size.argtypes = [C.c_int]
+
+    # -- public API mirror -------------------------------------------------
+    def dio(self, x, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+            channels_in_octave=2.0, speed=1, allowed_range=0.1):
+        x = _c(x)
+        nf = self.lib.orc_dio_samples(fs, len(x), frame_period)
+        t, f0 = np.zeros(nf), np.zeros(nf)
+        self.lib.orc_dio(_p(x), len(x), fs, f0_floor, f0_ceil, channels_in_octave,
+                         frame_period, speed, allowed_range, _p(t), _p(f0))
+        return t, f0
+
+    def harvest(self, x, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0):
+        x = _c(x)
+        nf = self.lib.orc_harvest_samples(fs, len(x), frame_period)
+        t, f0 = np.zeros(nf), np.zeros(nf)
+        self.lib.orc_harvest(_p(x), len(x), fs, f0_floor, f0_ceil, frame_period, _p(t), _p(f0))
+        return t, f0
+
+    def stonemask(self, x, fs, t, f0):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        out = np.zeros(len(f0))
+        self.lib.orc_stonemask(_p(x), len(x), fs, _p(t), _p(f0), len(f0), _p(out))
+        return out
+
+    def cheaptrick_fft_size(self, fs, f0_floor=71.0):
+        return self.lib.orc_cheaptrick_fft_size(fs, f0_floor)
+
+    def cheaptrick(self, x, fs, t, f0, q1=-0.15, fft_size=None):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        fft_size = fft_size or self.cheaptrick_fft_size(fs)
+        sp = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.orc_cheaptrick(_p(x), len(x), fs, _p(t), _p(f0), len(f0), q1, fft_size, _p(sp))
+        return sp
+
+    def d4c(self, x, fs, t, f0, fft_size, threshold=0.85):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        ap = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.orc_d4c(_p(x), len(x), fs, _p(t), _p(f0), len(f0), fft_size, threshold, _p(ap))
+        return ap
+
+    def synthesis(self, f0, sp, ap, fft_size, frame_period, fs, y_length=None):
+        f0, sp, ap = _c(f0), _c(sp), _c(ap)
+        if y_length is None:
+            y_length = int((len(f0) - 1) * frame_period / 1000.0 * fs) + 1   # synth.cpp:259
+        y = np.zeros(y_length)
+        self.lib.orc_synthesis(_p(f0), len(f0), _p(sp), _p(ap), fft_size, frame_period, fs,
+                               y_length, _p(y))
+        return y
+
+    # -- primitives ----------------------------------------------------------
+    def randn_table(self, n):
+        out = np.zeros(n)
+        self.lib.orc_randn_table(_p(out), n)
+        return out
+
+    def randn_table_u32(self, n):
+        out = np.zeros(n, dtype=np.uint32)
+        self.lib.orc_randn_table_u32(out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out
+
+    def interp1(self, x, y, xi):
+        x, y, xi = _c(x), _c(y), _c(xi)
+        yi = np.zeros(len(xi))
+        self.lib.orc_interp1(_p(x), _p(y), len(x), _p(xi), len(xi), _p(yi))
+        return yi
+
+    def interp1q(self, x0, dx, y, xi):
+        y, xi = _c(y), _c(xi)
+        yi = np.zeros(len(xi))
+        self.lib.orc_interp1q(x0, dx, _p(y), len(y), _p(xi), len(xi), _p(yi))
+        return yi
+
+    def decimate(self, x, r):
+        x = _c(x)
+        y = np.zeros((len(x) - 1) // r + 1 + 2)
+        self.lib.orc_decimate(_p(x), len(x), r, _p(y))
+        return y[: (len(x) - 1) // r + 1]
+
+    def nuttall(self, n):
+        w = np.zeros(n)
+        self.lib.orc_nuttall(n, _p(w))
+        return w
+
+    def dc_correction(self, spec, f0, fs, fft_size):
+        spec = _c(spec)
+        out = spec.copy()
+        self.lib.orc_dc_correction(_p(spec), f0, fs, fft_size, _p(out))
+        return out
+
+    def linear_smoothing(self, spec, width, fs, fft_size):
+        spec = _c(spec)
+        out = np.zeros(fft_size // 2 + 1)
+        self.lib.orc_linear_smoothing(_p(spec), width, fs, fft_size, _p(out))
+        return out
+
+    def fft_r2c(self, x):
+        x = _c(x)
+        n = len(x)
+        re, im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+        self.lib.orc_fft_r2c(_p(x), n, _p(re), _p(im))
+        return re + 1j * im
+
+    def fft_c2r(self, spec, n):
+        re, im = _c(spec.real), _c(spec.imag)
+        x = np.zeros(n)
+        self.lib.orc_fft_c2r(_p(re), _p(im), n, _p(x))
+        return x
+
+    def min_phase(self, log_spec, fft_size):
+        ls = _c(log_spec)
+        re, im = np.zeros(fft_size // 2 + 1), np.zeros(fft_size // 2 + 1)
+        self.lib.orc_min_phase(_p(ls), fft_size, _p(re), _p(im))
+        return re + 1j * im
+
+
+# ---- the real reference ------------------------------------------------------
+class _DioOption(C.Structure):          # world/dio.h:16-23
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double),
+                ("channels_in_octave", C.c_double), ("frame_period", C.c_double),
+                ("speed", C.c_int), ("allowed_range", C.c_double)]
+
+
+class _HarvestOption(C.Structure):      # world/harvest.h:16-20
+    _fields_ = [("f0_floor", C.c_double), ("f0_ceil", C.c_double), ("frame_period", C.c_double)]
+
+
+class _CheapTrickOption(C.Structure):   # world/cheaptrick.h:16-20
+    _fields_ = [("q1", C.c_double), ("f0_floor", C.c_double), ("fft_size", C.c_int)]
+
+
+class _D4COption(C.Structure):          # world/d4c.h:16-18
+    _fields_ = [("threshold", C.c_double)]
+
+
+def _rows(a: np.ndarray):
+    """double** over the rows of a C-contiguous 2-D array."""
+    n = a.shape[0]
+    arr = (_dp * n)()
+    base, stride = a.ctypes.data, a.strides[0]
+    for i in range(n):
+        arr[i] = C.cast(base + i * stride, _dp)
+    return arr
+
+
+class WorldCApi:
+    """Caller of WORLD's public C ABI; works on any .so exporting it (the
+    compiled reference, or this repo's libworld_mi355.so drop-in)."""
+    kind = "reference"
+
+    def __init__(self, path: str):
+        self.lib = L = C.CDLL(path)
+        L.GetSamplesForDIO.restype = C.c_int
+        L.GetSamplesForDIO.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.Dio.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_DioOption), _dp, _dp]
+        L.InitializeDioOption.argtypes = [C.POINTER(_DioOption)]
+        L.StoneMask.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.CheapTrick.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int,
+                                 C.POINTER(_CheapTrickOption), C.POINTER(_dp)]
+        L.InitializeCheapTrickOption.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
+        L.GetFFTSizeForCheapTrick.restype = C.c_int
+        L.GetFFTSizeForCheapTrick.argtypes = [C.c_int, C.POINTER(_CheapTrickOption)]
+        L.GetF0FloorForCheapTrick.restype = C.c_double
+        L.GetF0FloorForCheapTrick.argtypes = [C.c_int, C.c_int]
+        L.D4C.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int,
+                          C.POINTER(_D4COption), C.POINTER(_dp)]
+        L.InitializeD4COption.argtypes = [C.POINTER(_D4COption)]
+        L.Synthesis.argtypes = [_dp, C.c_int, C.POINTER(_dp), C.POINTER(_dp), C.c_int,
+                                C.c_double, C.c_int, C.c_int, _dp]
+        self.has_harvest = hasattr(L, "Harvest")
+        if self.has_harvest:
+            L.GetSamplesForHarvest.restype = C.c_int
+            L.GetSamplesForHarvest.argtypes = [C.c_int, C.c_int, C.c_double]
+            L.Harvest.argtypes = [_dp, C.c_int, C.c_int, C.POINTER(_HarvestOption), _dp, _dp]
+            L.InitializeHarvestOption.argtypes = [C.POINTER(_HarvestOption)]
+
+    def dio(self, x, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0,
+            channels_in_octave=2.0, speed=1, allowed_range=0.1):
+        x = _c(x)
+        opt = _DioOption()
+        self.lib.InitializeDioOption(C.byref(opt))
+        opt.frame_period, opt.f0_floor, opt.f0_ceil = frame_period, f0_floor, f0_ceil
+        opt.channels_in_octave, opt.speed, opt.allowed_range = channels_in_octave, speed, allowed_range
+        nf = self.lib.GetSamplesForDIO(fs, len(x), frame_period)
+        t, f0 = np.zeros(nf), np.zeros(nf)
+        self.lib.Dio(_p(x), len(x), fs, C.byref(opt), _p(t), _p(f0))
+        return t, f0
+
+    def harvest(self, x, fs, frame_period=5.0, f0_floor=71.0, f0_ceil=800.0):
+        x = _c(x)
+        opt = _HarvestOption()
+        self.lib.InitializeHarvestOption(C.byref(opt))
+        opt.frame_period, opt.f0_floor, opt.f0_ceil = frame_period, f0_floor, f0_ceil
+        nf = self.lib.GetSamplesForHarvest(fs, len(x), frame_period)
+        t, f0 = np.zeros(nf), np.zeros(nf)
+        self.lib.Harvest(_p(x), len(x), fs, C.byref(opt), _p(t), _p(f0))
+        return t, f0
+
+    def stonemask(self, x, fs, t, f0):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        out = np.zeros(len(f0))
+        self.lib.StoneMask(_p(x), len(x), fs, _p(t), _p(f0), len(f0), _p(out))
+        return out
+
+    def cheaptrick_fft_size(self, fs, f0_floor=71.0):
+        opt = _CheapTrickOption()
+        opt.f0_floor = f0_floor
+        return self.lib.GetFFTSizeForCheapTrick(fs, C.byref(opt))
+
+    def cheaptrick(self, x, fs, t, f0, q1=-0.15, fft_size=None):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        opt = _CheapTrickOption()
+        self.lib.InitializeCheapTrickOption(fs, C.byref(opt))
+        opt.q1 = q1
+        if fft_size:
+            opt.fft_size = fft_size
+        sp = np.zeros((len(f0), opt.fft_size // 2 + 1))
+        self.lib.CheapTrick(_p(x), len(x), fs, _p(t), _p(f0), len(f0), C.byref(opt), _rows(sp))
+        return sp
+
+    def d4c(self, x, fs, t, f0, fft_size, threshold=0.85):
+        x, t, f0 = _c(x), _c(t), _c(f0)
+        opt = _D4COption()
+        opt.threshold = threshold
+        ap = np.zeros((len(f0), fft_size // 2 + 1))
+        self.lib.D4C(_p(x), len(x), fs, _p(t), _p(f0), len(f0), fft_size, C.byref(opt), _rows(ap))
+        return ap
+
+    def synthesis(self, f0, sp, ap, fft_size, frame_period, fs, y_length=None):
+        f0, sp, ap = _c(f0), _c(sp), _c(ap)
+        if y_length is None:
+            y_length = int((len(f0) - 1) * frame_period / 1000.0 * fs) + 1
+        y = np.zeros(y_length)
+        self.lib.Synthesis(_p(f0), len(f0), _rows(sp), _rows(ap), fft_size, frame_period, fs,
+                           y_length, _p(y))
+        return y
+
+
+class Reference(WorldCApi):
+    """The compiled reference plus the primitives it happens to export."""
+
+    PATH = os.path.join(HERE, "_ref", "libworld_ref.so")
+
+    @classmethod
+    def available(cls) -> bool:
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        super().__init__(self.PATH)
+        L = self.lib
+        L.randn.restype = C.c_double
+        L.interp1.argtypes = [_dp, _dp, C.c_int, _dp, C.c_int, _dp]
+        L.interp1Q.argtypes = [C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_int, _dp]
+        L.decimate.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.NuttallWindow.argtypes = [C.c_int, _dp]
+        L.DCCorrection.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.LinearSmoothing.argtypes = [_dp, C.c_double, C.c_int, C.c_int, _dp]
+        L.matlab_round.restype = C.c_int
+        L.matlab_round.argtypes = [C.c_double]
+        L.GetSuitableFFTSize.restype = C.c_int
+        L.GetSuitableFFTSize.argtypes = [C.c_int]
+
+    def randn_table(self, n):
+        self.lib.randn_reseed()
+        return np.array([self.lib.randn() for _ in range(n)])
+
+    def interp1(self, x, y, xi):
+        x, y, xi = _c(x), _c(y), _c(xi)
+        yi = np.zeros(len(xi))
+        self.lib.interp1(_p(x), _p(y), len(x), _p(xi), len(xi), _p(yi))
+        return yi
+
+    def interp1q(self, x0, dx, y, xi):
+        y, xi = _c(y), _c(xi)
+        yi = np.zeros(len(xi))
+        self.lib.interp1Q(x0, dx, _p(y), len(y), _p(xi), len(xi), _p(yi))
+        return yi
+
+    def decimate(self, x, r):
+        x = _c(x)
+        y = np.zeros((len(x) - 1) // r + 1 + 2)
+        self.lib.decimate(_p(x), len(x), r, _p(y))
+        return y[: (len(x) - 1) // r + 1]
+
+    def nuttall(self, n):
+        w = np.zeros(n)
+        self.lib.NuttallWindow(n, _p(w))
+        return w
+
+    def dc_correction(self, spec, f0, fs, fft_size):
+        spec = _c(spec)
+        out = spec.copy()
+        self.lib.DCCorrection(_p(spec), f0, fs, fft_size, _p(out))
+        return out
+
+    def linear_smoothing(self, spec, width, fs, fft_size):
+        spec = _c(spec)
+        out = np.zeros(fft_size // 2 + 1)
+        self.lib.LinearSmoothing(_p(spec), width, fs, fft_size, _p(out))
+        return out
