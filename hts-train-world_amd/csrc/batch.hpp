@@ -1,0 +1,94 @@
+// batch.hpp -- host-side state shared by the kernel launchers and the C ABI.
+//
+// Context : one per (process, device): HIP stream, the universal randn table
+//           (matlabfunctions.cpp:247-277 as data), launch geometry.
+// Batch   : one per set of utterances: lengths/offsets on host and device, the
+//           frame->utterance map and every scratch buffer the kernels need, all
+//           allocated at creation so the analysis path never calls hipMalloc.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/world_mi355.h"
+
+namespace wm {
+
+int wm_check(hipError_t e);   // maps to WM_ERR_HIP and records the message
+
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cu = 256;
+  int frame_grid = 256 * 8;          // workgroups for grid-stride per-frame kernels
+  uint32_t* d_rng = nullptr;         // universal randn table, uint32 sums
+  int64_t rng_cap = 0;
+  double* d_scratch = nullptr;       // growable scratch (synthesis responses)
+  int64_t scratch_cap = 0;           // in doubles
+  int ensure_rng(int64_t count);     // grow + (re)generate, returns error code
+  int ensure_scratch(int64_t doubles);
+};
+
+struct Batch {
+  Context* ctx = nullptr;
+  WorldMi355Params p{};
+  int n_utt = 0;
+  std::vector<int> x_len, f0_len, y_len;
+  std::vector<int64_t> x_off, f_off, y_off;
+  int64_t total_x = 0, total_f = 0, total_y = 0;
+  int max_x_len = 0, max_f0_len = 0, max_y_len = 0;
+  // device descriptors
+  int64_t *d_x_off = nullptr, *d_f_off = nullptr, *d_y_off = nullptr;
+  int *d_x_len = nullptr, *d_f0_len = nullptr, *d_y_len = nullptr;
+  int* d_frame_utt = nullptr;        // [total_f]
+  int* d_rng_off = nullptr;          // [total_f] per-frame randn offsets (CheapTrick / D4C phase 2)
+  int* d_rng_off2 = nullptr;         // [total_f] D4C LoveTrain offsets
+  double* d_ap0 = nullptr;           // [total_f] D4C LoveTrain result
+  double* d_f0_tmp = nullptr;        // [total_f] raw DIO f0 before StoneMask
+  // D4C tables
+  double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
+  int* d_utt_total = nullptr;        // [n_utt] LoveTrain randn totals
+  // DIO workspace
+  bool dio_ready = false;
+  void* dio_host = nullptr;          // DioHost (dio.hip)
+  double* d_dio_lowcut = nullptr;    // low-cut FIR taps by lag
+  double* d_dio_win = nullptr;       // Nuttall low-pass windows, all bands
+  int* d_dio_fft = nullptr;          // [n_utt] the reference's fft_size (circular indexing)
+  double* d_dio_ws = nullptr;        // [3][total_f] contour work arrays
+  int dio_bands = 0;
+  double* d_dio_mean = nullptr;      // [n_utt]
+  double* d_dio_z = nullptr;         // low-cut output, per utterance y_len + 2*pad
+  int64_t* d_dio_z_off = nullptr;
+  std::vector<int64_t> dio_z_off;
+  int dio_pad = 0;
+  double* d_dio_events = nullptr;    // fine edges, [utt][band][4][cap]
+  int64_t* d_dio_ev_off = nullptr;   // per utterance base into events (in doubles)
+  std::vector<int64_t> dio_ev_off;
+  int* d_dio_ev_cnt = nullptr;       // [utt][band][4]
+  double* d_dio_cand = nullptr;      // [band][total_f]
+  double* d_dio_score = nullptr;     // [band][total_f]
+  // Synthesis workspace
+  int* d_pulse_idx = nullptr;        // [total_y]
+  double* d_pulse_shift = nullptr;   // [total_y]
+  double* d_vuv = nullptr;           // [total_y] interpolated vuv
+  double* d_phase = nullptr;         // [total_y] scratch (increments / wrapped phase)
+  int* d_pulse_cnt = nullptr;        // [n_utt]
+  int64_t* d_pulse_off = nullptr;    // [n_utt+1]
+  int* h_pulse_cnt = nullptr;        // pinned
+  double* d_dc_remover = nullptr;    // [fft_size]
+
+  int64_t rng_bound_cheaptrick() const;
+  int64_t rng_bound_d4c() const;
+  int64_t rng_bound_synthesis() const;
+};
+
+// kernel launchers (one translation unit each)
+int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0);
+int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_out);
+int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp);
+int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
+int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
+
+}  // namespace wm

@@ -1,0 +1,425 @@
+// capi.cpp -- the C-ABI of libworld_mi355.so.
+//
+// (1) WORLD's public API (include/world/*.h), one utterance per call, host
+//     pointers in and out, exactly the reference's signatures
+//     (externs/WORLD_v2/src/world/{dio,stonemask,cheaptrick,d4c,synthesis,harvest}.h).
+//     Each call stages the utterance into HBM, runs the batch kernels with B = 1
+//     and copies the result back.  There is NO CPU fallback: without a HIP device
+//     the call aborts with a message, like the reference aborts on bad_alloc.
+// (2) The batched device-pointer extension (include/world_mi355.h).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "batch.hpp"
+#include "common.hpp"
+#include "world/cheaptrick.h"
+#include "world/d4c.h"
+#include "world/dio.h"
+#include "world/harvest.h"
+#include "world/stonemask.h"
+#include "world/synthesis.h"
+
+namespace wm {
+const char* last_error();
+void set_error(const char* msg);
+int launch_test_rfft(Context* ctx, int n, int count, const double* x, double* re, double* im, double* xb);
+int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0);
+void free_batch_buffers(Batch& b);
+}  // namespace wm
+
+using namespace wm;
+
+struct WorldMi355Context { Context c; };
+struct WorldMi355Batch { Batch b; };
+
+template <typename T> static int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  return wm_check(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+}
+template <typename T> static int upload(T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (v.empty()) return WM_OK;
+  return wm_check(hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+}
+
+extern "C" {
+
+const char* WorldMi355LastError(void) { return wm::last_error(); }
+
+void WorldMi355DefaultParams(int fs, double frame_period, WorldMi355Params* p) {
+  memset(p, 0, sizeof(*p));
+  p->fs = fs;
+  p->frame_period = frame_period;
+  p->f0_floor = 71.0;            // analysis.cpp:111
+  p->f0_ceil = 800.0;            // dio.cpp:652 (kCeilF0)
+  p->channels_in_octave = 2.0;   // dio.cpp:651
+  p->speed = 1;                  // analysis.cpp:106
+  p->allowed_range = 0.1;        // analysis.cpp:116
+  p->q1 = -0.15;                 // analysis.cpp:151
+  p->fft_size = 0;
+  p->d4c_threshold = 0.0;        // analysis.cpp:190
+}
+
+int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** out) {
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    wm::set_error("no HIP device visible: libworld_mi355 has no CPU path");
+    return WM_ERR_NO_DEVICE;
+  }
+  if (device >= 0) {
+    int rc = wm_check(hipSetDevice(device));
+    if (rc) return rc;
+  }
+  WorldMi355Context* h = new WorldMi355Context();
+  Context& c = h->c;
+  hipGetDevice(&c.device);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) c.num_cu = prop.multiProcessorCount;
+  c.frame_grid = c.num_cu * 16;
+  if (hip_stream) {
+    c.stream = (hipStream_t)hip_stream;
+    c.own_stream = false;
+  } else {
+    int rc = wm_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (rc) { delete h; return rc; }
+    c.own_stream = true;
+  }
+  *out = h;
+  return WM_OK;
+}
+
+void WorldMi355DestroyContext(WorldMi355Context* h) {
+  if (!h) return;
+  Context& c = h->c;
+  hipStreamSynchronize(c.stream);
+  if (c.d_rng) hipFree(c.d_rng);
+  if (c.d_scratch) hipFree(c.d_scratch);
+  if (c.own_stream) hipStreamDestroy(c.stream);
+  delete h;
+}
+
+int WorldMi355SetStream(WorldMi355Context* h, void* hip_stream) {
+  Context& c = h->c;
+  int rc = wm_check(hipStreamSynchronize(c.stream));
+  if (rc) return rc;
+  if (c.own_stream) hipStreamDestroy(c.stream);
+  c.own_stream = false;
+  c.stream = (hipStream_t)hip_stream;
+  return WM_OK;
+}
+
+int WorldMi355Synchronize(WorldMi355Context* h) { return wm_check(hipStreamSynchronize(h->c.stream)); }
+
+int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, int n_utt,
+                          const int* x_lengths, const int* f0_lengths, const int* y_lengths,
+                          WorldMi355Batch** out) {
+  *out = nullptr;
+  if (!h || !params || n_utt <= 0 || (!x_lengths && !f0_lengths)) {
+    wm::set_error("CreateBatch: bad argument");
+    return WM_ERR_BAD_ARG;
+  }
+  WorldMi355Batch* hb = new WorldMi355Batch();
+  Batch& b = hb->b;
+  b.ctx = &h->c;
+  b.p = *params;
+  if (b.p.fft_size == 0)   // GetFFTSizeForCheapTrick, cheaptrick.cpp:191-194
+    b.p.fft_size = (int)pow(2.0, 1.0 + (int)(log(3.0 * b.p.fs / b.p.f0_floor + 1) / kLog2));
+  b.n_utt = n_utt;
+  b.x_len.assign(n_utt, 0); b.f0_len.assign(n_utt, 0); b.y_len.assign(n_utt, 0);
+  b.x_off.assign(n_utt + 1, 0); b.f_off.assign(n_utt + 1, 0); b.y_off.assign(n_utt + 1, 0);
+  for (int u = 0; u < n_utt; ++u) {
+    b.x_len[u] = x_lengths ? x_lengths[u] : 0;
+    b.f0_len[u] = f0_lengths ? f0_lengths[u]
+                             : (int)(1000.0 * b.x_len[u] / b.p.fs / b.p.frame_period) + 1;   // dio.cpp:638-640
+    b.y_len[u] = y_lengths ? y_lengths[u]
+                           : (int)((b.f0_len[u] - 1) * b.p.frame_period / 1000.0 * b.p.fs) + 1;   // synth.cpp:259
+    if (b.x_len[u] < 0 || b.f0_len[u] <= 0 || b.y_len[u] < 0) {
+      delete hb;
+      wm::set_error("CreateBatch: negative length");
+      return WM_ERR_BAD_ARG;
+    }
+    b.x_off[u + 1] = b.x_off[u] + b.x_len[u];
+    b.f_off[u + 1] = b.f_off[u] + b.f0_len[u];
+    b.y_off[u + 1] = b.y_off[u] + b.y_len[u];
+    b.max_x_len = imax(b.max_x_len, b.x_len[u]);
+    b.max_f0_len = imax(b.max_f0_len, b.f0_len[u]);
+    b.max_y_len = imax(b.max_y_len, b.y_len[u]);
+  }
+  b.total_x = b.x_off[n_utt]; b.total_f = b.f_off[n_utt]; b.total_y = b.y_off[n_utt];
+  int rc = WM_OK;
+  rc = rc ? rc : upload(&b.d_x_off, b.x_off);
+  rc = rc ? rc : upload(&b.d_f_off, b.f_off);
+  rc = rc ? rc : upload(&b.d_y_off, b.y_off);
+  rc = rc ? rc : upload(&b.d_x_len, b.x_len);
+  rc = rc ? rc : upload(&b.d_f0_len, b.f0_len);
+  rc = rc ? rc : upload(&b.d_y_len, b.y_len);
+  std::vector<int> fu((size_t)b.total_f);
+  for (int u = 0; u < n_utt; ++u)
+    for (int64_t i = b.f_off[u]; i < b.f_off[u + 1]; ++i) fu[(size_t)i] = u;
+  rc = rc ? rc : upload(&b.d_frame_utt, fu);
+  rc = rc ? rc : dev_alloc(&b.d_rng_off, (size_t)b.total_f);
+  rc = rc ? rc : dev_alloc(&b.d_rng_off2, (size_t)b.total_f);
+  rc = rc ? rc : dev_alloc(&b.d_ap0, (size_t)b.total_f);
+  rc = rc ? rc : dev_alloc(&b.d_f0_tmp, (size_t)b.total_f);
+  if (rc) { WorldMi355DestroyBatch(hb); return rc; }
+  *out = hb;
+  return WM_OK;
+}
+
+void WorldMi355DestroyBatch(WorldMi355Batch* hb) {
+  if (!hb) return;
+  Batch& b = hb->b;
+  hipStreamSynchronize(b.ctx->stream);
+  wm::free_batch_buffers(b);
+  delete hb;
+}
+
+int64_t WorldMi355BatchTotalSamples(const WorldMi355Batch* b) { return b->b.total_x; }
+int64_t WorldMi355BatchTotalFrames(const WorldMi355Batch* b) { return b->b.total_f; }
+int64_t WorldMi355BatchTotalOutputSamples(const WorldMi355Batch* b) { return b->b.total_y; }
+int WorldMi355BatchFftSize(const WorldMi355Batch* b) { return b->b.p.fft_size; }
+const int64_t* WorldMi355BatchSampleOffsets(const WorldMi355Batch* b) { return b->b.x_off.data(); }
+const int64_t* WorldMi355BatchFrameOffsets(const WorldMi355Batch* b) { return b->b.f_off.data(); }
+const int64_t* WorldMi355BatchOutputOffsets(const WorldMi355Batch* b) { return b->b.y_off.data(); }
+
+int WorldMi355Dio(WorldMi355Batch* b, const double* x, double* t, double* f0) {
+  return launch_dio(b->b, x, t, f0);
+}
+int WorldMi355StoneMask(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
+                        double* refined_f0) {
+  return launch_stonemask(b->b, x, t, f0, refined_f0);
+}
+int WorldMi355CheapTrick(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
+                         double* sp) {
+  return launch_cheaptrick(b->b, x, t, f0, sp);
+}
+int WorldMi355D4C(WorldMi355Batch* b, const double* x, const double* t, const double* f0, double* ap) {
+  return launch_d4c(b->b, x, t, f0, ap);
+}
+int WorldMi355Synthesis(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
+                        double* y) {
+  return launch_synthesis(b->b, f0, sp, ap, y);
+}
+int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0) {
+  return wm::launch_harvest(b->b, x, t, f0);
+}
+int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
+                      double* ap) {
+  Batch& b = hb->b;
+  int rc = launch_dio(b, x, t, b.d_f0_tmp);
+  rc = rc ? rc : launch_stonemask(b, x, t, b.d_f0_tmp, f0);
+  rc = rc ? rc : launch_cheaptrick(b, x, t, f0, sp);
+  rc = rc ? rc : launch_d4c(b, x, t, f0, ap);
+  return rc;
+}
+int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
+                       double* im, double* x_back) {
+  return wm::launch_test_rfft(&ctx->c, n, count, x, re, im, x_back);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// WORLD's own API: host pointers, one utterance, B = 1 batch.
+// ---------------------------------------------------------------------------
+namespace {
+
+std::mutex g_mu;
+WorldMi355Context* g_ctx = nullptr;
+
+[[noreturn]] void die(const char* where, int rc) {
+  fprintf(stderr, "libworld_mi355: %s failed (code %d): %s\n", where, rc, WorldMi355LastError());
+  abort();
+}
+
+WorldMi355Context* default_context() {
+  if (!g_ctx) {
+    int rc = WorldMi355CreateContext(-1, nullptr, &g_ctx);
+    if (rc) die("CreateContext", rc);
+  }
+  return g_ctx;
+}
+
+struct DevBuf {
+  double* p = nullptr;
+  explicit DevBuf(size_t n) {
+    if (hipMalloc((void**)&p, sizeof(double) * (n ? n : 1)) != hipSuccess) die("hipMalloc", WM_ERR_HIP);
+  }
+  ~DevBuf() { if (p) hipFree(p); }
+  void put(const double* h, size_t n) {
+    if (n && hipMemcpy(p, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) die("H2D", WM_ERR_HIP);
+  }
+  void get(double* h, size_t n) {
+    if (n && hipMemcpy(h, p, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) die("D2H", WM_ERR_HIP);
+  }
+};
+
+struct OneBatch {
+  WorldMi355Batch* b = nullptr;
+  OneBatch(const WorldMi355Params& p, const int* xl, const int* fl, const int* yl) {
+    int rc = WorldMi355CreateBatch(default_context(), &p, 1, xl, fl, yl, &b);
+    if (rc) die("CreateBatch", rc);
+  }
+  ~OneBatch() { WorldMi355DestroyBatch(b); }
+};
+
+void sync_or_die(const char* where, int rc) {
+  if (rc) die(where, rc);
+  rc = WorldMi355Synchronize(default_context());
+  if (rc) die(where, rc);
+}
+
+void put_rows(DevBuf& d, const double* const* rows, int n_rows, int width) {
+  std::vector<double> h((size_t)n_rows * width);
+  for (int i = 0; i < n_rows; ++i) memcpy(&h[(size_t)i * width], rows[i], sizeof(double) * width);
+  d.put(h.data(), h.size());
+}
+void get_rows(DevBuf& d, double** rows, int n_rows, int width) {
+  std::vector<double> h((size_t)n_rows * width);
+  d.get(h.data(), h.size());
+  for (int i = 0; i < n_rows; ++i) memcpy(rows[i], &h[(size_t)i * width], sizeof(double) * width);
+}
+
+}  // namespace
+
+extern "C" {
+
+int GetSamplesForDIO(int fs, int x_length, double frame_period) {      // dio.cpp:638-640
+  return (int)(1000.0 * x_length / fs / frame_period) + 1;
+}
+void InitializeDioOption(DioOption* option) {                           // dio.cpp:649-665
+  option->channels_in_octave = 2.0;
+  option->f0_ceil = 800.0;
+  option->f0_floor = 71.0;
+  option->frame_period = 5;
+  option->speed = 1;
+  option->allowed_range = 0.1;
+}
+void Dio(const double* x, int x_length, int fs, const DioOption* option, double* temporal_positions,
+         double* f0) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, option->frame_period, &p);
+  p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
+  p.channels_in_octave = option->channels_in_octave; p.speed = option->speed;
+  p.allowed_range = option->allowed_range;
+  p.fft_size = 1024;   // unused by DIO
+  OneBatch ob(p, &x_length, nullptr, nullptr);
+  const int nf = (int)WorldMi355BatchTotalFrames(ob.b);
+  DevBuf dx((size_t)x_length), dt((size_t)nf), df((size_t)nf);
+  dx.put(x, (size_t)x_length);
+  sync_or_die("Dio", WorldMi355Dio(ob.b, dx.p, dt.p, df.p));
+  dt.get(temporal_positions, (size_t)nf);
+  df.get(f0, (size_t)nf);
+}
+
+int GetSamplesForHarvest(int fs, int x_length, double frame_period) {  // harvest.cpp:1219-1221
+  return (int)(1000.0 * x_length / fs / frame_period) + 1;
+}
+void InitializeHarvestOption(HarvestOption* option) {                   // harvest.cpp:1257-1262
+  option->f0_ceil = 800.0;
+  option->f0_floor = 71.0;
+  option->frame_period = 5;
+}
+void Harvest(const double* x, int x_length, int fs, const HarvestOption* option,
+             double* temporal_positions, double* f0) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, option->frame_period, &p);
+  p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
+  p.fft_size = 1024;   // unused by Harvest
+  OneBatch ob(p, &x_length, nullptr, nullptr);
+  const int nf = (int)WorldMi355BatchTotalFrames(ob.b);
+  DevBuf dx((size_t)x_length), dt((size_t)nf), df((size_t)nf);
+  dx.put(x, (size_t)x_length);
+  sync_or_die("Harvest", WorldMi355Harvest(ob.b, dx.p, dt.p, df.p));
+  dt.get(temporal_positions, (size_t)nf);
+  df.get(f0, (size_t)nf);
+}
+
+void StoneMask(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
+               int f0_length, double* refined_f0) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, 5.0, &p);
+  p.fft_size = 1024;   // unused by StoneMask
+  OneBatch ob(p, &x_length, &f0_length, nullptr);
+  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), dr((size_t)f0_length);
+  dx.put(x, (size_t)x_length);
+  dt.put(temporal_positions, (size_t)f0_length);
+  df.put(f0, (size_t)f0_length);
+  sync_or_die("StoneMask", WorldMi355StoneMask(ob.b, dx.p, dt.p, df.p, dr.p));
+  dr.get(refined_f0, (size_t)f0_length);
+}
+
+int GetFFTSizeForCheapTrick(int fs, const CheapTrickOption* option) {   // cheaptrick.cpp:191-194
+  return (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / option->f0_floor + 1) / kLog2));
+}
+double GetF0FloorForCheapTrick(int fs, int fft_size) {                   // cheaptrick.cpp:196-198
+  return 3.0 * fs / (fft_size - 3.0);
+}
+void InitializeCheapTrickOption(int fs, CheapTrickOption* option) {      // cheaptrick.cpp:230-239
+  option->q1 = -0.15;
+  option->f0_floor = 71.0;
+  option->fft_size = GetFFTSizeForCheapTrick(fs, option);
+}
+void CheapTrick(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
+                int f0_length, const CheapTrickOption* option, double** spectrogram) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, 5.0, &p);
+  p.q1 = option->q1;
+  p.fft_size = option->fft_size;
+  const int w = option->fft_size / 2 + 1;
+  OneBatch ob(p, &x_length, &f0_length, nullptr);
+  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), ds((size_t)f0_length * w);
+  dx.put(x, (size_t)x_length);
+  dt.put(temporal_positions, (size_t)f0_length);
+  df.put(f0, (size_t)f0_length);
+  sync_or_die("CheapTrick", WorldMi355CheapTrick(ob.b, dx.p, dt.p, df.p, ds.p));
+  get_rows(ds, spectrogram, f0_length, w);
+}
+
+void InitializeD4COption(D4COption* option) { option->threshold = 0.85; }   // d4c.cpp:399-401
+void D4C(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
+         int f0_length, int fft_size, const D4COption* option, double** aperiodicity) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, 5.0, &p);
+  p.fft_size = fft_size;
+  p.d4c_threshold = option->threshold;
+  const int w = fft_size / 2 + 1;
+  OneBatch ob(p, &x_length, &f0_length, nullptr);
+  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), da((size_t)f0_length * w);
+  dx.put(x, (size_t)x_length);
+  dt.put(temporal_positions, (size_t)f0_length);
+  df.put(f0, (size_t)f0_length);
+  sync_or_die("D4C", WorldMi355D4C(ob.b, dx.p, dt.p, df.p, da.p));
+  get_rows(da, aperiodicity, f0_length, w);
+}
+
+void Synthesis(const double* f0, int f0_length, const double* const* spectrogram,
+               const double* const* aperiodicity, int fft_size, double frame_period, int fs, int y_length,
+               double* y) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  WorldMi355Params p;
+  WorldMi355DefaultParams(fs, frame_period, &p);
+  p.fft_size = fft_size;
+  const int w = fft_size / 2 + 1;
+  OneBatch ob(p, nullptr, &f0_length, &y_length);
+  DevBuf df((size_t)f0_length), ds((size_t)f0_length * w), da((size_t)f0_length * w), dy((size_t)y_length);
+  df.put(f0, (size_t)f0_length);
+  put_rows(ds, spectrogram, f0_length, w);
+  put_rows(da, aperiodicity, f0_length, w);
+  sync_or_die("Synthesis", WorldMi355Synthesis(ob.b, df.p, ds.p, da.p, dy.p));
+  dy.get(y, (size_t)y_length);
+}
+
+}  // extern "C"

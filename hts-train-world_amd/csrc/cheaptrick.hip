@@ -1,0 +1,175 @@
+// cheaptrick.hip -- CheapTrick spectral-envelope estimation, one wavefront per frame.
+//
+// Replaces CheapTrick / CheapTrickGeneralBody and everything below it
+// (externs/WORLD_v2/src/cheaptrick.cpp:22-228) for a whole batch of utterances:
+// grid-stride over (utterance, frame) pairs, each frame handled by one 64-lane
+// workgroup that keeps the frame's window, spectra and cepstrum in registers and
+// LDS (3 real FFTs of fft_size, 1 blocked scan, log/lifter/exp fused).  The
+// reference's global xorshift generator (matlabfunctions.cpp:247-277) is a
+// table lookup at a per-frame offset computed by cheaptrick_offsets_kernel.
+#include "batch.hpp"
+#include "common.hpp"
+#include "fft.hpp"
+#include "window.hpp"
+
+namespace wm {
+
+// Per-utterance exclusive scan of each frame's randn consumption:
+// (2*round(1.5 fs/f0')+1) for the window (cheaptrick.cpp:126-128) then fft_size/2+1
+// for AddInfinitesimalNoise (:149-150).
+__global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* __restrict__ f0,
+                                                                 const int64_t* __restrict__ f_off,
+                                                                 int fs, int fft_size, int* __restrict__ rng_off) {
+  __shared__ int part[256];
+  __shared__ int carry_s;
+  const int u = blockIdx.x;
+  const int64_t base = f_off[u];
+  const int nf = (int)(f_off[u + 1] - base);
+  const double f0_floor = 3.0 * fs / (fft_size - 3.0);
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int start = 0; start < nf; start += 256) {
+    const int i = start + threadIdx.x;
+    int c = 0;
+    if (i < nf) {
+      double v = f0[base + i];
+      double cf0 = v <= f0_floor ? kDefaultF0 : v;
+      c = 2 * matlab_round(1.5 * fs / cf0) + 1 + fft_size / 2 + 1;
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int tv = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += tv;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (i < nf) rng_off[base + i] = carry + part[threadIdx.x] - c;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + part[255];
+    __syncthreads();
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(64) void cheaptrick_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, double q1,
+    int64_t total_frames, double* __restrict__ sp) {
+  constexpr int N = F / 2, M = N / 64, H = F / 2;
+  constexpr int kImg = 2 * FftLds<N>::kElems;                 // doubles
+  constexpr int kSeg = H + 2 * (F / 3 + 1) + 2;               // worst-case smoothing scratch
+  constexpr int kWork = kImg > kSeg ? kImg : kSeg;
+  __shared__ __attribute__((aligned(16))) double smem[(H + 2) + kWork];
+  double* pw = smem;                                           // [H+1] power / log spectrum
+  double* work = smem + (H + 2);                               // FFT image | spectrum | scan scratch
+  cpx* img = reinterpret_cast<cpx*>(work);
+
+  const int lane = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane);
+  const double f0_floor = 3.0 * fs / (F - 3.0);                // cheaptrick.cpp:196-198
+
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int u = frame_utt[frame];
+    const double* xu = x + x_off[u];
+    const int xl = x_len[u];
+    const double f0v = f0[frame];
+    const double cf0 = f0v <= f0_floor ? kDefaultF0 : f0v;     // cheaptrick.cpp:217
+    const double pos = tpos[frame];
+    const int roff = rng_off[frame];
+
+    // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) ----
+    cpx v[M];
+    const FrameWindow fw = windowed_waveform<M, kHann, true>(xu, xl, fs, cf0, pos, 3.0, rtab, roff, lane, v);
+    const int L = fw.L;
+
+    // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
+    rfft_forward<N>(v, img, img, tw, lane);
+    {
+      double p[M + 1];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        cpx s = img[lane + 64 * m];
+        p[m] = s.x * s.x + s.y * s.y;
+      }
+      cpx sn = img[N];
+      p[M] = sn.x * sn.x + sn.y * sn.y;
+#pragma unroll
+      for (int m = 0; m < M; ++m) pw[lane + 64 * m] = p[m];
+      if (lane == 0) pw[N] = p[M];
+    }
+    __syncthreads();
+    dc_correction_lds(pw, cf0, fs, F, work, lane);
+
+    // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
+    double sm[M + 1];
+    linear_smoothing_lds<M + 1>(pw, cf0 * 2.0 / 3.0, fs, F, work, sm, lane);
+#pragma unroll
+    for (int m = 0; m <= M; ++m) {
+      const int i = lane + 64 * m;
+      if (i <= H) pw[i] = log(sm[m] + fabs(randn_at(rtab, roff + L + i)) * kEps);
+    }
+    __syncthreads();
+
+    // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
+      v[m] = make_double2(pw[i0 <= H ? i0 : F - i0], pw[i1 <= H ? i1 : F - i1]);
+    }
+    rfft_forward<N>(v, img, img, tw, lane);
+#pragma unroll
+    for (int m = 0; m <= M; ++m) {
+      const int i = lane + 64 * m;
+      if (i <= H) {
+        double sl = 1.0, cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+        if (i > 0) {
+          double quef = (double)i / fs;
+          sl = sin(kPi * cf0 * quef) / (kPi * cf0 * quef);
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * quef * cf0);
+        }
+        img[i] = make_double2(img[i].x * sl * cl / F, 0.0);
+      }
+    }
+    rfft_backward<N>(img, v, img, tw, lane);
+    double* row = sp + frame * (int64_t)(H + 1);
+#pragma unroll
+    for (int m = 0; m < M / 2; ++m) {
+      const int n = lane + 64 * m;
+      row[2 * n] = exp(v[m].x);
+      row[2 * n + 1] = exp(v[m].y);
+    }
+    if (lane == 0) row[H] = exp(v[M / 2].x);
+    __syncthreads();
+  }
+}
+
+int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp) {
+  hipStream_t st = b.ctx->stream;
+  const int F = b.p.fft_size;
+  int rc = b.ctx->ensure_rng(b.rng_bound_cheaptrick());
+  if (rc) return rc;
+  hipLaunchKernelGGL(cheaptrick_offsets_kernel, dim3(b.n_utt), dim3(256), 0, st, d_f0, b.d_f_off, b.p.fs, F,
+                     b.d_rng_off);
+  const int64_t tf = b.total_f;
+  const int grid = (int)(tf < (int64_t)b.ctx->frame_grid ? tf : (int64_t)b.ctx->frame_grid);
+  if (grid <= 0) return 0;
+#define WM_CT_CASE(FF)                                                                                   \
+  case FF:                                                                                               \
+    hipLaunchKernelGGL(cheaptrick_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,    \
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng, b.p.fs, b.p.q1, tf, d_sp);  \
+    break;
+  switch (F) {
+    WM_CT_CASE(1024)
+    WM_CT_CASE(2048)
+    default:
+      return WM_ERR_UNSUPPORTED_FFT;
+  }
+#undef WM_CT_CASE
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm

@@ -1,0 +1,135 @@
+// common.hpp -- device helpers shared by the WORLD hot-path kernels (gfx950).
+//
+// Restates, for one 64-lane wavefront working on LDS-resident spectra, the
+// reference's small numeric helpers:
+//   matlab_round       externs/WORLD_v2/src/matlabfunctions.cpp:212-214
+//   randn (as table)   matlabfunctions.cpp:247-277
+//   interp1Q           matlabfunctions.cpp:220-241
+//   DCCorrection       common.cpp:56-75
+//   LinearSmoothing    common.cpp:27-46, 77-111
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wm {
+
+constexpr double kPi = 3.1415926535897932384;
+constexpr double kLog2 = 0.69314718055994529;
+constexpr double kSafe = 0.000000000001;                       // kMySafeGuardMinimum
+constexpr double kEps = 0.00000000000000022204460492503131;   // kEps
+constexpr double kDefaultF0 = 500.0;
+constexpr double kBig = 100000.0;                              // kMaximumValue
+
+__host__ __device__ __forceinline__ int matlab_round(double x) {
+  return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5);
+}
+__host__ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// k-th draw of the universal randn stream from its uint32 table.
+__device__ __forceinline__ double randn_at(const uint32_t* __restrict__ tab, int k) {
+  return (double)tab[k] / 268435456.0 - 6.0;
+}
+
+// ---- wavefront collectives (64 lanes) ----------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// inclusive prefix sum across lanes
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_scan_incl_i(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// interp1Q on an LDS array (matlabfunctions.cpp:220-241): y has n entries,
+// delta_y[n-1] := 0.
+__device__ __forceinline__ double interp1q_lds(double x0, double dx, const double* y, int n, double xi) {
+  double q = (xi - x0) / dx;
+  int b = (int)q;
+  double frac = q - b;
+  double y0 = y[b];
+  double dy = (b == n - 1) ? 0.0 : y[b + 1] - y0;
+  return y0 + dy * frac;
+}
+
+// DCCorrection (common.cpp:56-75) in place on pw[0..half] (LDS).  One wavefront.
+// `scratch` (LDS, >= upper doubles) holds the replica so that every read of pw
+// happens before any write, as in the reference.
+__device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs, int fft_size,
+                                                  double* scratch, int lane) {
+  const int upper = 2 + (int)(f0 * fft_size / fs);
+  const int nrep = upper - 1;
+  for (int i = lane; i < nrep; i += 64) {
+    double axis = (double)i * fs / fft_size;
+    scratch[i] = interp1q_lds(f0, -(double)fs / fft_size, pw, upper + 1, axis);
+  }
+  __syncthreads();
+  for (int i = lane; i < nrep; i += 64) pw[i] += scratch[i];
+  __syncthreads();
+}
+
+// LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[m] registers for
+// bins lane + 64 m, m < MB.  seg is an LDS scratch of >= half + 2*b + 1 doubles
+// (b = int(width*fft_size/fs)+1).  The cumulative sum is blocked per lane and
+// stitched by a wave scan (the reference's is sequential, common.cpp:38-41).
+template <int MB>
+__device__ __forceinline__ void linear_smoothing_lds(const double* in, double width, int fs, int fft_size,
+                                                     double* seg, double (&out)[MB], int lane) {
+  const int half = fft_size / 2;
+  const int b = (int)(width * fft_size / fs) + 1;
+  const int len = half + 2 * b + 1;
+  const int chunk = (len + 63) / 64;
+  const int beg = lane * chunk;
+  const int end = imin(len, beg + chunk);
+  double run = 0.0;
+  for (int i = beg; i < end; ++i) {
+    int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
+    run += in[src] * fs / fft_size;
+    seg[i] = run;
+  }
+  double incl = wave_scan_incl(run, lane);
+  double carry = incl - run;
+  __syncthreads();
+  for (int i = beg; i < end; ++i) seg[i] += carry;
+  __syncthreads();
+  const double origin = -(b - 0.5) * fs / fft_size;
+  const double step = (double)fs / fft_size;
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    int i = lane + 64 * m;
+    out[m] = 0.0;
+    if (i <= half) {
+      double lo_x = (double)i / fft_size * fs - width / 2.0;
+      double lo = interp1q_lds(origin, step, seg, len, lo_x);
+      double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
+      out[m] = (hi - lo) / width;
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace wm

@@ -1,0 +1,100 @@
+// context.cpp -- Context / Batch life cycle for libworld_mi355.so (host side, C++).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "batch.hpp"
+#include "common.hpp"
+
+namespace wm {
+
+static thread_local std::string g_last_error;
+
+int wm_check(hipError_t e) {
+  if (e == hipSuccess) return WM_OK;
+  g_last_error = std::string("HIP: ") + hipGetErrorString(e);
+  return WM_ERR_HIP;
+}
+const char* last_error() { return g_last_error.c_str(); }
+void set_error(const char* msg) { g_last_error = msg; }
+
+// xorshift128 stream of the reference's randn(), as uint32 sums of 12 draws
+// (matlabfunctions.cpp:247-277); index k = k-th sample after randn_reseed().
+static void fill_randn_u32(uint32_t* out, int64_t count) {
+  uint32_t x = 123456789u, y = 362436069u, z = 521288629u, w = 88675123u;
+  for (int64_t k = 0; k < count; ++k) {
+    uint32_t acc = 0;
+    for (int j = 0; j < 12; ++j) {
+      uint32_t t = x ^ (x << 11);
+      x = y; y = z; z = w;
+      w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+      acc += w >> 4;
+    }
+    out[k] = acc;
+  }
+}
+
+int Context::ensure_rng(int64_t count) {
+  if (count <= rng_cap) return WM_OK;
+  int64_t cap = count + count / 4 + 4096;
+  std::vector<uint32_t> host((size_t)cap);
+  fill_randn_u32(host.data(), cap);
+  // the old table may still be read by kernels in flight on the stream
+  int rc = wm_check(hipStreamSynchronize(stream));
+  if (rc) return rc;
+  if (d_rng) hipFree(d_rng);
+  d_rng = nullptr;
+  rc = wm_check(hipMalloc((void**)&d_rng, sizeof(uint32_t) * (size_t)cap));
+  if (rc) return rc;
+  rc = wm_check(hipMemcpy(d_rng, host.data(), sizeof(uint32_t) * (size_t)cap, hipMemcpyHostToDevice));
+  if (rc) return rc;
+  rng_cap = cap;
+  return WM_OK;
+}
+
+int Context::ensure_scratch(int64_t doubles) {
+  if (doubles <= scratch_cap) return WM_OK;
+  int rc = wm_check(hipStreamSynchronize(stream));
+  if (rc) return rc;
+  if (d_scratch) hipFree(d_scratch);
+  d_scratch = nullptr;
+  scratch_cap = 0;
+  rc = wm_check(hipMalloc((void**)&d_scratch, sizeof(double) * (size_t)doubles));
+  if (rc) return rc;
+  scratch_cap = doubles;
+  return WM_OK;
+}
+
+int64_t Batch::rng_bound_cheaptrick() const {
+  // per frame: window 2*hw+1 <= fft_size+1 (hw < (fft_size-3)/2 by the f0 floor) + fft_size/2+1
+  return (int64_t)max_f0_len * (p.fft_size + 1 + p.fft_size / 2 + 1) + 64;
+}
+int64_t Batch::rng_bound_d4c() const {
+  // LoveTrain: 2*round(1.5 fs/40)+1 per voiced frame; body: 3 windows of 2*round(2 fs/47)+1
+  int64_t lt = 2 * (int64_t)matlab_round(1.5 * p.fs / 40.0) + 1;
+  int64_t body = 3 * (2 * (int64_t)matlab_round(2.0 * p.fs / 47.0) + 1);
+  return (int64_t)max_f0_len * (lt + body) + 64;
+}
+int64_t Batch::rng_bound_synthesis() const { return (int64_t)max_y_len + 64; }
+
+}  // namespace wm
+
+namespace wm {
+void dio_free_host(void* h);
+
+void free_batch_buffers(Batch& b) {
+  void* ptrs[] = {b.d_x_off, b.d_f_off, b.d_y_off, b.d_x_len, b.d_f0_len, b.d_y_len, b.d_frame_utt,
+                  b.d_rng_off, b.d_rng_off2, b.d_ap0, b.d_f0_tmp, b.d_d4c_window, b.d_utt_total,
+                  b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_mean, b.d_dio_z,
+                  b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_cand,
+                  b.d_dio_score, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_phase, b.d_pulse_cnt,
+                  b.d_pulse_off, b.d_dc_remover};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (b.h_pulse_cnt) hipHostFree(b.h_pulse_cnt);
+  if (b.dio_host) dio_free_host(b.dio_host);
+  b.dio_host = nullptr;
+}
+}  // namespace wm

@@ -1,0 +1,425 @@
+// d4c.hip -- D4C band-aperiodicity estimation, one wavefront per voiced frame.
+//
+// Replaces D4C and everything below it (externs/WORLD_v2/src/d4c.cpp:21-397):
+//   d4c_offsets_kernel<0/1>  the two randn consumption scans (d4c.cpp:340 reseed;
+//                            LoveTrain first, then the frames that pass it)
+//   d4c_lovetrain_kernel     D4CLoveTrain(+Sub), d4c.cpp:225-282
+//   d4c_kernel               D4CGeneralBody d4c.cpp:290-316 + GetAperiodicity :325-333
+// The std::sort of d4c.cpp:215 only feeds "sum of all but the (boundary+1)
+// largest bins"; here the largest bins are peeled off by repeated wave-wide max
+// and the rest summed directly (no sort).
+#include "batch.hpp"
+#include "common.hpp"
+#include "fft.hpp"
+#include "window.hpp"
+
+namespace wm {
+
+constexpr double kFloorF0D4C = 47.0;     // constantnumbers.h
+constexpr double kFreqInterval = 3000.0;
+constexpr double kUpperLimit = 15000.0;
+
+__host__ __device__ inline int d4c_fft_size(int fs) {           // d4c.cpp:344-346
+  return (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / kFloorF0D4C + 1) / kLog2));
+}
+__host__ __device__ inline int lovetrain_fft_size(int fs) {     // d4c.cpp:261-263
+  return (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / kLog2));
+}
+
+// MODE 0: LoveTrain consumption 2*round(1.5 fs/max(f0,40))+1 for frames with f0 != 0
+//         (d4c.cpp:231-233, :272-278); writes per-utterance totals to utt_total.
+// MODE 1: body consumption 3*(2*round(2 fs/max(f0,47))+1) for frames with f0 != 0 and
+//         ap0 > threshold (d4c.cpp:380-383, :94-97, :152-153), offset by utt_total.
+template <int MODE>
+__global__ __launch_bounds__(256) void d4c_offsets_kernel(const double* __restrict__ f0,
+                                                          const double* __restrict__ ap0,
+                                                          const int64_t* __restrict__ f_off, int fs,
+                                                          double threshold, int* __restrict__ utt_total,
+                                                          int* __restrict__ rng_off) {
+  __shared__ int part[256];
+  __shared__ int carry_s;
+  const int u = blockIdx.x;
+  const int64_t base = f_off[u];
+  const int nf = (int)(f_off[u + 1] - base);
+  if (threadIdx.x == 0) carry_s = MODE == 0 ? 0 : utt_total[u];
+  __syncthreads();
+  for (int start = 0; start < nf; start += 256) {
+    const int i = start + threadIdx.x;
+    int c = 0;
+    if (i < nf) {
+      double v = f0[base + i];
+      if (MODE == 0) {
+        if (v != 0.0) c = 2 * matlab_round(1.5 * fs / (v > 40.0 ? v : 40.0)) + 1;
+      } else {
+        if (v != 0.0 && ap0[base + i] > threshold)
+          c = 3 * (2 * matlab_round(2.0 * fs / (v > kFloorF0D4C ? v : kFloorF0D4C)) + 1);
+      }
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int tv = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += tv;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (i < nf) rng_off[base + i] = carry + part[threadIdx.x] - c;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + part[255];
+    __syncthreads();
+  }
+  if (MODE == 0 && threadIdx.x == 0) utt_total[u] = carry_s;
+}
+
+// D4CLoveTrainSub (d4c.cpp:225-250): aperiodicity0 = cum[boundary1] / cum[boundary2]
+// over the power spectrum with bins <= boundary0 zeroed.
+template <int FL>
+__global__ __launch_bounds__(64) void d4c_lovetrain_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, int64_t total_frames,
+    double* __restrict__ ap0) {
+  constexpr int N = FL / 2, M = N / 64;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int lane = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane);
+  const int b0 = (int)ceil(100.0 * FL / fs), b1 = (int)ceil(4000.0 * FL / fs), b2 = (int)ceil(7900.0 * FL / fs);
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const double f0v = f0[frame];
+    if (f0v == 0.0) {
+      if (lane == 0) ap0[frame] = 0.0;
+      continue;
+    }
+    const int u = frame_utt[frame];
+    const double cf0 = f0v > 40.0 ? f0v : 40.0;
+    cpx v[M];
+    windowed_waveform<M, kBlackman, false>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0, rtab,
+                                            rng_off[frame], lane, v);
+    rfft_forward<N>(v, img, img, tw, lane);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int k = lane + 64 * m;
+      cpx s = img[k];
+      double p = s.x * s.x + s.y * s.y;
+      if (k > b0 && k <= b1) s1 += p;
+      if (k > b0 && k <= b2) s2 += p;
+    }
+    if (lane == 0) {        // bin N (Nyquist) only if a boundary reaches it
+      cpx s = img[N];
+      double p = s.x * s.x + s.y * s.y;
+      if (N <= b1) s1 += p;
+      if (N <= b2) s2 += p;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) ap0[frame] = s1 / s2;
+    __syncthreads();
+  }
+}
+
+struct D4CTables {
+  const double* nuttall;    // [window_length] NuttallWindow(window_length) (d4c.cpp:356-359)
+  int window_length;
+  int nap;                  // number_of_aperiodicities (d4c.cpp:351-353)
+};
+
+// FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
+template <int FD>
+__global__ __launch_bounds__(64) void d4c_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
+    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap) {
+  constexpr int N = FD / 2, M = N / 64, H = FD / 2, MB = M + 1;
+  constexpr int kA = H + 2;
+  constexpr int kBMax = FD / 16;
+  constexpr int kImg = 2 * FftLds<N>::kElems;
+  constexpr int kTot = kImg > (kA + H + 2 * kBMax + 2) ? kImg : (kA + H + 2 * kBMax + 2);
+  __shared__ __attribute__((aligned(16))) double smem[kTot];
+  double* arr = smem;                         // [H+1] spectrum-domain array
+  double* seg = smem + kA;                    // scan / DC scratch
+  cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image (aliases both)
+
+  const int lane = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane);
+  const int out_bins = out_fft / 2 + 1;
+
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    double* row = ap + frame * (int64_t)out_bins;
+    const double f0v = f0[frame];
+    bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
+    const double cf0 = f0v > kFloorF0D4C ? f0v : kFloorF0D4C;         // d4c.cpp:381
+    // LDS capacity guard for the smoothing scratch (width = f0 is the widest): f0 < fs/16
+    if (run && (int)(cf0 * FD / fs) + 1 > kBMax) run = false;
+    if (!run) {
+      for (int i = lane; i < out_bins; i += 64) row[i] = 1.0 - kSafe;  // d4c.cpp:318-323
+      continue;
+    }
+    const int u = frame_utt[frame];
+    const double* xu = x + x_off[u];
+    const int xl = x_len[u];
+    const double pos = tpos[frame];
+    const int roff = rng_off[frame];
+    const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
+
+    // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
+    double sc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) sc[m] = 0.0;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+      const int ro = roff + side * Lw;
+      cpx v[M];
+      const FrameWindow fw = windowed_waveform<M, kBlackman, false>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane, v);
+      double pwr = 0.0;                                   // d4c.cpp:96-100
+#pragma unroll
+      for (int m = 0; m < M; ++m) pwr += v[m].x * v[m].x + v[m].y * v[m].y;
+      const double nrm = sqrt(wave_sum(pwr));
+#pragma unroll
+      for (int m = 0; m < M; ++m) { v[m].x /= nrm; v[m].y /= nrm; }
+      rfft_forward<N>(v, img, img, tw, lane);
+      cpx s1[MB];
+#pragma unroll
+      for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
+      s1[M] = img[N];
+      // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
+      rebuild_waveform<M, kBlackman>(xu, xl, fw, rtab, ro, lane, v);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        v[m].x = v[m].x / nrm * (i0 + 1.0);
+        v[m].y = v[m].y / nrm * (i0 + 2.0);
+      }
+      rfft_forward<N>(v, img, img, tw, lane);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        cpx s2 = img[lane + 64 * m];
+        sc[m] += s2.x * s1[m].x + s1[m].y * s2.y;          // d4c.cpp:113-115
+      }
+      {
+        cpx s2 = img[N];
+        sc[M] += s2.x * s1[M].x + s1[M].y * s2.y;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m];
+    if (lane == 0) arr[N] = sc[M];
+    __syncthreads();
+    dc_correction_lds(arr, cf0, fs, FD, seg, lane);        // d4c.cpp:139
+#pragma unroll
+    for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
+    sc[M] = arr[N];
+    __syncthreads();
+
+    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
+    double gd[MB];
+    {
+      cpx v[M];
+      windowed_waveform<M, kHann, false>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, v);
+      rfft_forward<N>(v, img, img, tw, lane);
+      double p[MB];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        cpx s = img[lane + 64 * m];
+        p[m] = s.x * s.x + s.y * s.y;
+      }
+      {
+        cpx s = img[N];
+        p[M] = s.x * s.x + s.y * s.y;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
+      if (lane == 0) arr[N] = p[M];
+      __syncthreads();
+      dc_correction_lds(arr, cf0, fs, FD, seg, lane);
+      double sp[MB];
+      linear_smoothing_lds<MB>(arr, cf0, fs, FD, seg, sp, lane);
+      // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
+#pragma unroll
+      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / sp[m];
+      if (lane == 0) arr[N] = sc[M] / sp[M];
+      __syncthreads();
+    }
+    linear_smoothing_lds<MB>(arr, cf0 / 2.0, fs, FD, seg, gd, lane);
+#pragma unroll
+    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
+    if (lane == 0) arr[N] = gd[M];
+    __syncthreads();
+    {
+      double sg[MB];
+      linear_smoothing_lds<MB>(arr, cf0, fs, FD, seg, sg, lane);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) gd[m] -= sg[m];
+    }
+
+    // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
+    const int wl = tab.window_length;
+    const int bnd = matlab_round(FD * 8.0 / wl);
+    const int hwl = wl / 2;
+    double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int band = 0; band < tab.nap; ++band) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
+      if (lane == 0) arr[N] = gd[M];
+      __syncthreads();
+      const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
+      cpx v[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        double a0 = 0.0, a1 = 0.0;
+        if (i0 < wl) a0 = arr[center - hwl + i0] * tab.nuttall[i0];
+        if (i0 + 1 < wl) a1 = arr[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
+        v[m] = make_double2(a0, a1);
+      }
+      rfft_forward<N>(v, img, img, tw, lane);
+      double p[MB];
+      double tot = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        cpx s = img[lane + 64 * m];
+        p[m] = s.x * s.x + s.y * s.y;
+        tot += p[m];
+      }
+      p[M] = -1.0;
+      if (lane == 0) {
+        cpx s = img[N];
+        p[M] = s.x * s.x + s.y * s.y;
+        tot += p[M];
+      }
+      tot = wave_sum(tot);
+      // peel the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220)
+#pragma unroll 1
+      for (int it = 0; it <= bnd; ++it) {
+        double mx = p[0];
+#pragma unroll
+        for (int m = 1; m < MB; ++m) mx = fmax(mx, p[m]);
+        const double wmx = wave_max(mx);
+        const unsigned long long vote = __ballot(mx == wmx);
+        const int winner = __ffsll((long long)vote) - 1;
+        if (lane == winner) {
+          bool done = false;
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            if (!done && p[m] == wmx) { p[m] = -1.0; done = true; }
+          }
+        }
+      }
+      double low = 0.0;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) low += p[m] >= 0.0 ? p[m] : 0.0;
+      low = wave_sum(low);
+      double c = 10.0 * log10(low / tot);
+      c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
+      c = c < 0.0 ? c : 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
+      __syncthreads();
+    }
+
+    // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
+    const int nk = tab.nap + 2;
+    for (int i = lane; i < out_bins; i += 64) {
+      const double f = (double)i * fs / out_fft;
+      int k = 0;                                            // #{knots <= f}
+      for (int j = 0; j < nk; ++j) {
+        double xj = j <= tab.nap ? j * kFreqInterval : fs / 2.0;
+        k += xj <= f ? 1 : 0;
+      }
+      k = k < 1 ? 1 : (k > nk - 1 ? nk - 1 : k);
+      const double x0 = (k - 1) <= tab.nap ? (k - 1) * kFreqInterval : fs / 2.0;
+      const double x1 = k <= tab.nap ? k * kFreqInterval : fs / 2.0;
+      double y0 = -60.0, y1 = -kSafe;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < tab.nap) {
+          if (k - 1 == j + 1) y0 = coarse[j];
+          if (k == j + 1) y1 = coarse[j];
+        }
+      }
+      const double s = (f - x0) / (x1 - x0);
+      const double yi = y0 + s * (y1 - y0);
+      row[i] = pow(10.0, yi / 20.0);
+    }
+    __syncthreads();
+  }
+}
+
+int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int fs = b.p.fs;
+  const int FD = d4c_fft_size(fs), FL = lovetrain_fft_size(fs);
+  if (FD != FL || (FD != 1024 && FD != 2048 && FD != 4096)) {
+    return WM_ERR_UNSUPPORTED_FFT;
+  }
+  int rc = c.ensure_rng(b.rng_bound_d4c());
+  if (rc) return rc;
+  // Nuttall window table for GetCoarseAperiodicity (d4c.cpp:356-359, common.cpp:113-121)
+  const int wl = (int)(kFreqInterval * FD / fs) * 2 + 1;
+  if (!b.d_d4c_window) {
+    std::vector<double> w((size_t)wl);
+    for (int i = 0; i < wl; ++i) {
+      double tmp = i / (wl - 1.0);
+      w[(size_t)i] = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) + 0.144232 * cos(4.0 * kPi * tmp) -
+                     0.012604 * cos(6.0 * kPi * tmp);
+    }
+    rc = wm_check(hipMalloc((void**)&b.d_d4c_window, sizeof(double) * (size_t)wl));
+    if (rc) return rc;
+    rc = wm_check(hipMemcpyAsync(b.d_d4c_window, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
+    if (rc) return rc;
+    rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
+    if (rc) return rc;
+    rc = wm_check(hipMalloc((void**)&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
+    if (rc) return rc;
+  }
+  D4CTables tab;
+  tab.nuttall = b.d_d4c_window;
+  tab.window_length = wl;
+  double lim = fs / 2.0 - kFreqInterval;
+  tab.nap = (int)((kUpperLimit < lim ? kUpperLimit : lim) / kFreqInterval);
+  if (tab.nap < 1 || tab.nap > 6) return WM_ERR_UNSUPPORTED;
+
+  const int64_t tf = b.total_f;
+  const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
+  hipLaunchKernelGGL(d4c_offsets_kernel<0>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)nullptr,
+                     b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off2);
+#define WM_LT_CASE(FF)                                                                                     \
+  case FF:                                                                                                 \
+    hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,   \
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, b.d_ap0);                  \
+    break;
+  switch (FL) {
+    WM_LT_CASE(1024)
+    WM_LT_CASE(2048)
+    WM_LT_CASE(4096)
+  }
+#undef WM_LT_CASE
+  hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
+                     b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
+#define WM_D4C_CASE(FF)                                                                                   \
+  case FF:                                                                                                \
+    hipLaunchKernelGGL(d4c_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,            \
+                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs,        \
+                       b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap);                                   \
+    break;
+  switch (FD) {
+    WM_D4C_CASE(1024)
+    WM_D4C_CASE(2048)
+    WM_D4C_CASE(4096)
+  }
+#undef WM_D4C_CASE
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm

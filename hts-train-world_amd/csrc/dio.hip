@@ -1,0 +1,498 @@
+// dio.hip -- DIO F0 estimation for a batch of utterances.
+//
+// Replaces Dio / DioGeneralBody and everything below it
+// (externs/WORLD_v2/src/dio.cpp:40-647).  The reference filters by multiplying
+// whole-utterance spectra (16 FFTs of 2^16..2^18 points); because every filter is
+// a short FIR (641-tap low-cut, 40..320-tap Nuttall low-pass) and
+// fft_size >= y_length + filter length (dio.cpp:592-593), the same circular
+// convolution is evaluated here as tiled time-domain FIRs with explicit
+// wrap-around indexing (so even the aliasing corner case fft_size - y_length < 480
+// is reproduced):
+//
+//   dio_mean_kernel      mean over y_length = N+1 samples          dio.cpp:74-79
+//   dio_lowcut_kernel    y (*) low-cut filter, circular             dio.cpp:40-53, 85-101
+//   dio_band_kernel      per (utterance, band): Nuttall FIR, the four zero-crossing
+//                        event lists (ordered compaction)           dio.cpp:296-435
+//   dio_candidate_kernel interp1 of the four interval tracks, mean/std score  dio.cpp:441-508, 562-567
+//   dio_fix_kernel       best band + FixStep1..4                    dio.cpp:112-289
+#include <math.h>
+
+#include "batch.hpp"
+#include "common.hpp"
+
+namespace wm {
+
+constexpr int kMaxBands = 32;
+
+struct DioMeta {
+  int nb;                       // number_of_bands
+  int hal[kMaxBands];           // half_average_length per band (dio.cpp:532)
+  int win_off[kMaxBands];       // offset of the band's Nuttall window in d_win
+  double boundary[kMaxBands];   // boundary_f0_list
+  int cut;                      // cutoff_in_sample (dio.cpp:86)
+  int pad;                      // 2 * hal[0]: how far the low-cut output is needed outside [0, y_len)
+  int ratio;                    // decimation ratio (only 1 is implemented on device)
+  double afs;                   // actual_fs
+};
+
+__global__ __launch_bounds__(256) void dio_mean_kernel(const double* __restrict__ x,
+                                                       const int64_t* __restrict__ x_off,
+                                                       const int* __restrict__ x_len, double* __restrict__ mean) {
+  __shared__ double part[4];
+  const int u = blockIdx.x;
+  const double* xu = x + x_off[u];
+  const int n = x_len[u];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += xu[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) mean[u] = (part[0] + part[1] + part[2] + part[3]) / (n + 1);   // y_length = N + 1
+}
+
+// circular, zero-padded, mean-removed signal of the reference (dio.cpp:63-79)
+__device__ __forceinline__ double dio_y(const double* __restrict__ xu, int n, int ylen, int fftn, double mean,
+                                        int i) {
+  i = i < 0 ? i + fftn : (i >= fftn ? i - fftn : i);
+  if (i < n) return xu[i] - mean;
+  if (i < ylen) return 0.0 - mean;
+  return 0.0;
+}
+
+// z[m] = sum_lag h(lag) y[(m - lag) mod fft], m in [-pad, ylen + pad); stored at z[m + pad].
+constexpr int kLcTile = 1024;
+__global__ __launch_bounds__(256) void dio_lowcut_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const double* __restrict__ mean, const int* __restrict__ fft_sizes, const double* __restrict__ lowcut,
+    DioMeta meta, const int64_t* __restrict__ z_off, double* __restrict__ z) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int u = blockIdx.y;
+  const int n = x_len[u], ylen = n + 1, fftn = fft_sizes[u];
+  const int cut = meta.cut, ntap = 2 * cut + 1;
+  const int total = ylen + 2 * meta.pad;
+  const int m0 = blockIdx.x * kLcTile;              // tile start in z-storage coordinates
+  if (m0 >= total) return;
+  double* ytile = lds;                              // [kLcTile + 2 cut]
+  double* h = lds + (kLcTile + 2 * cut);            // [ntap], h[j] = filter at lag (j - cut)
+  const double* xu = x + x_off[u];
+  const double mu = mean[u];
+  for (int j = threadIdx.x; j < ntap; j += 256) h[j] = lowcut[j];
+  for (int j = threadIdx.x; j < kLcTile + 2 * cut; j += 256)
+    ytile[j] = dio_y(xu, n, ylen, fftn, mu, m0 - meta.pad - cut + j);
+  __syncthreads();
+  // each thread: 4 outputs, strided by 256 (conflict-free LDS reads)
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < ntap; ++j) {                  // lag = j - cut; y index = m - lag
+    const double hj = h[j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += hj * ytile[threadIdx.x + 256 * q + 2 * cut - j];
+  }
+  double* zu = z + z_off[u];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + threadIdx.x + 256 * q;
+    if (m < total) zu[m] = acc[q];
+  }
+}
+
+// One workgroup per (utterance, band): Nuttall FIR over the low-cut signal, then the four
+// ZeroCrossingEngine passes (dio.cpp:357-435) as an ordered stream compaction.
+// events layout per (utt, band): 4 lists of `cap` fine edges.
+constexpr int kBandK = 8;                       // outputs per thread
+constexpr int kBandTile = 256 * kBandK;         // samples per tile
+__global__ __launch_bounds__(256) void dio_band_kernel(
+    const int* __restrict__ x_len, const int64_t* __restrict__ z_off, const double* __restrict__ z,
+    const double* __restrict__ win, DioMeta meta, const int64_t* __restrict__ ev_off,
+    double* __restrict__ events, int* __restrict__ ev_cnt) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int u = blockIdx.y, band = blockIdx.x;
+  const int ylen = x_len[u] + 1;
+  const int hal = meta.hal[band], ntap = 4 * hal;
+  const int cap = ylen / 2 + 2;
+  // LDS: transposed z tile (element e at [(e % K) * stride + e / K]), window taps, filtered tile
+  const int zspan = kBandTile + ntap;                           // elements needed per tile
+  const int stride = (zspan + kBandK - 1) / kBandK + 1;
+  double* zt = lds;                                             // [K * stride]
+  double* w = zt + kBandK * stride;                             // [ntap]
+  double* s = w + ntap;                                         // [kBandTile] filtered samples
+  __shared__ int wave_cnt[4][4];                                // [type][wave]
+  __shared__ int run_cnt[4];
+  const double* zu = z + z_off[u] + meta.pad;                   // zu[m], m in [-pad, ylen+pad)
+  const double* wb = win + meta.win_off[band];
+  for (int j = threadIdx.x; j < ntap; j += 256) w[j] = wb[j];
+  if (threadIdx.x < 4) run_cnt[threadIdx.x] = 0;
+  double* ev = events + ev_off[u] + (int64_t)band * 4 * cap;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int step = kBandTile - 2;                               // tiles overlap by 2 (s[i+1], s[i+2] look-ahead)
+
+  for (int n0 = 0; n0 < ylen; n0 += step) {
+    __syncthreads();
+    // filtered[n] = sum_{k<ntap} w[k] z[n + 2 hal - k]  (dio.cpp:310-337); tile element e <-> z index
+    // zbase + e with zbase = n0 + 2 hal - (ntap - 1)
+    const int zbase = n0 + 2 * hal - (ntap - 1);
+    for (int e = threadIdx.x; e < zspan; e += 256) {
+      const int m = zbase + e;
+      const double val = (m >= -meta.pad && m < ylen + meta.pad) ? zu[m] : 0.0;
+      zt[(e % kBandK) * stride + e / kBandK] = val;
+    }
+    __syncthreads();
+    // thread t: outputs n0 + t*K + q, q < K; output q at tap k reads element e = t*K + q + (ntap-1) - k
+    {
+      double acc[kBandK];
+#pragma unroll
+      for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
+      const int t = threadIdx.x;
+      // sliding register window over elements t*K + c, c descending
+      double r[kBandK];                                          // r[q] = element for output q at current tap
+#pragma unroll
+      for (int q = 0; q < kBandK; ++q) {
+        const int e = t * kBandK + q + (ntap - 1);
+        r[q] = zt[(e % kBandK) * stride + e / kBandK];
+      }
+      for (int k = 0; k < ntap; ++k) {
+        const double wk = w[k];
+#pragma unroll
+        for (int q = 0; q < kBandK; ++q) acc[q] += wk * r[q];
+        // shift: next tap needs elements one lower; r[q] <- r[q-1], r[0] <- new element
+#pragma unroll
+        for (int q = kBandK - 1; q > 0; --q) r[q] = r[q - 1];
+        const int e = t * kBandK + (ntap - 1) - (k + 1);
+        r[0] = e >= 0 ? zt[(e % kBandK) * stride + e / kBandK] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
+    }
+    __syncthreads();
+    // ---- zero crossings over samples i in [n0, n0 + step) ----
+    for (int rowb = 0; rowb < step; rowb += 256) {
+      const int li = rowb + threadIdx.x;          // local index
+      const int i = n0 + li;
+      bool f[4] = {false, false, false, false};
+      double fine[4] = {0.0, 0.0, 0.0, 0.0};
+      if (li < step && i < ylen - 1) {
+        const double a = s[li], b = s[li + 1];
+        // type 0: positive -> non-positive (dio.cpp:361-363); type 1 on the negated signal (:419-422)
+        f[0] = 0.0 < a && b <= 0.0;
+        f[1] = 0.0 < -a && -b <= 0.0;
+        if (f[0] || f[1]) fine[f[0] ? 0 : 1] = (i + 1) - a / (b - a);          // :378-382
+        if (i < ylen - 2) {
+          const double c = s[li + 2];
+          const double p0 = b - a, p1 = c - b;     // (-s[i]) - (-s[i+1]) (:424-425)
+          f[2] = 0.0 < p0 && p1 <= 0.0;
+          f[3] = 0.0 < -p0 && -p1 <= 0.0;
+          if (f[2] || f[3]) fine[f[2] ? 2 : 3] = (i + 1) - p0 / (p1 - p0);
+        }
+      }
+      unsigned long long bal[4];
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) {
+        bal[ty] = __ballot(f[ty]);
+        if (lane == 0) wave_cnt[ty][wv] = __popcll(bal[ty]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) {
+        int base = run_cnt[ty];
+        for (int q = 0; q < wv; ++q) base += wave_cnt[ty][q];
+        if (f[ty]) {
+          const int rank = __popcll(bal[ty] & ((1ull << lane) - 1ull));
+          const int dst = base + rank;
+          if (dst < cap) ev[(int64_t)ty * cap + dst] = fine[ty];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 4) {
+        int tot = 0;
+        for (int q = 0; q < 4; ++q) tot += wave_cnt[threadIdx.x][q];
+        run_cnt[threadIdx.x] += tot;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) ev_cnt[((int64_t)u * meta.nb + band) * 4 + threadIdx.x] = imin(run_cnt[threadIdx.x], cap);
+}
+
+// interp1 (matlabfunctions.cpp:136-182) over a zero-crossing track given by its fine edges:
+// locations[j] = (e[j] + e[j+1]) / 2 / fs, intervals[j] = fs / (e[j+1] - e[j]), j < n (dio.cpp:384-387)
+__device__ __forceinline__ double dio_track(const double* __restrict__ e, int n, double fs, double t) {
+  int lo = 0, hi = n;                         // upper_bound on locations
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
+    if (loc <= t) lo = mid + 1; else hi = mid;
+  }
+  const int k = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+  const double x0 = (e[k - 1] + e[k]) / 2.0 / fs, x1 = (e[k] + e[k + 1]) / 2.0 / fs;
+  const double y0 = fs / (e[k] - e[k - 1]), y1 = fs / (e[k + 1] - e[k]);
+  const double h = x1 - x0;
+  const double sfrac = (t - x0) / h;
+  return y0 + sfrac * (y1 - y0);
+}
+
+__global__ __launch_bounds__(256) void dio_candidate_kernel(
+    const int* __restrict__ x_len, const int64_t* __restrict__ f_off, const int* __restrict__ frame_utt,
+    double frame_period, DioMeta meta, double f0_floor, double f0_ceil,
+    const int64_t* __restrict__ ev_off, const double* __restrict__ events, const int* __restrict__ ev_cnt,
+    int64_t total_frames, double* __restrict__ cand, double* __restrict__ score) {
+  const int band = blockIdx.y;
+  const int64_t frame = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (frame >= total_frames) return;
+  const int u = frame_utt[frame];
+  const int ylen = x_len[u] + 1;
+  const int cap = ylen / 2 + 2;
+  const int* cnt = ev_cnt + ((int64_t)u * meta.nb + band) * 4;
+  const double* ev = events + ev_off[u] + (int64_t)band * 4 * cap;
+  int nint[4];
+  bool ok = true;
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    nint[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;       // ZeroCrossingEngine returns count - 1 (dio.cpp:372-392)
+    ok = ok && nint[ty] > 2;                        // CheckEvent(n - 2) (dio.cpp:475-478)
+  }
+  double c = 0.0, sc = kBig;
+  if (ok) {
+    const double t = (int)(frame - f_off[u]) * frame_period / 1000.0;   // temporal_positions, dio.cpp:608-609
+    double v[4];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) v[ty] = dio_track(ev + (int64_t)ty * cap, nint[ty], meta.afs, t);
+    c = (v[0] + v[1] + v[2] + v[3]) / 4.0;          // dio.cpp:446-457
+    sc = sqrt(((v[0] - c) * (v[0] - c) + (v[1] - c) * (v[1] - c) + (v[2] - c) * (v[2] - c) +
+               (v[3] - c) * (v[3] - c)) / 3.0);
+    const double bf = meta.boundary[band];
+    if (c > bf || c < bf / 2.0 || c > f0_ceil || c < f0_floor) { c = 0.0; sc = kBig; }   // :459-463
+  }
+  cand[(int64_t)band * total_frames + frame] = c;
+  score[(int64_t)band * total_frames + frame] = sc / (c + kSafe);                        // :564-565
+}
+
+// SelectBestF0, dio.cpp:190-209
+__device__ __forceinline__ double dio_select(double cur, double past, const double* __restrict__ cand,
+                                             int64_t total_frames, int64_t gidx, int nb, double allowed) {
+  const double ref = (cur * 3.0 - past) / 2.0;
+  double best = cand[gidx];
+  double err = fabs(ref - best);
+  for (int b = 1; b < nb; ++b) {
+    const double cv = cand[(int64_t)b * total_frames + gidx];
+    const double e = fabs(ref - cv);
+    if (e < err) { err = e; best = cv; }
+  }
+  if (fabs(1.0 - best / ref) > allowed) return 0.0;
+  return best;
+}
+
+// GetBestF0Contour (dio.cpp:112-126) + FixF0Contour / FixStep1-4 (:132-289), one workgroup per
+// utterance.  Steps 1-2 are per-frame parallel; steps 3-4 are sequential along time and run on one
+// lane.  ws holds 3 work arrays of the utterance's frame count.
+__global__ __launch_bounds__(256) void dio_fix_kernel(const int64_t* __restrict__ f_off,
+                                                      const double* __restrict__ cand,
+                                                      const double* __restrict__ score, int nb,
+                                                      double frame_period, double f0_floor, double allowed,
+                                                      int64_t total_frames, double* __restrict__ ws,
+                                                      double* __restrict__ tpos, double* __restrict__ f0) {
+  const int u = blockIdx.x;
+  const int64_t base = f_off[u];
+  const int nf = (int)(f_off[u + 1] - base);
+  double* best = ws + base;
+  double* s1 = ws + total_frames + base;
+  double* s2 = ws + 2 * total_frames + base;
+  double* out = f0 + base;
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    tpos[base + i] = i * frame_period / 1000.0;                  // dio.cpp:608-609
+    double sv = score[base + i], bv = cand[base + i];
+    for (int b = 1; b < nb; ++b) {
+      const double s = score[(int64_t)b * total_frames + base + i];
+      if (sv > s) { sv = s; bv = cand[(int64_t)b * total_frames + base + i]; }
+    }
+    best[i] = bv;
+    out[i] = 0.0;
+  }
+  const int vrm = (int)(0.5 + 1000.0 / frame_period / f0_floor) * 2 + 1;   // dio.cpp:263-264
+  if (nf <= vrm) return;       // reference leaves f0 unwritten here (dio.cpp:266); we leave zeros
+  __syncthreads();
+  // step 1 (dio.cpp:132-150): f0_base is best with vrm frames zeroed at both ends
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    double r = 0.0;
+    if (i >= vrm) {
+      const double bi = (i < nf - vrm) ? best[i] : 0.0;
+      const double bp = (i - 1 >= vrm && i - 1 < nf - vrm) ? best[i - 1] : 0.0;
+      r = fabs((bi - bp) / (kSafe + bi)) < allowed ? bi : 0.0;
+    }
+    s1[i] = r;
+  }
+  __syncthreads();
+  // step 2 (dio.cpp:156-169)
+  const int c = (vrm - 1) / 2;
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    double r = s1[i];
+    if (i >= c && i < nf - c) {
+      for (int j = -c; j <= c; ++j)
+        if (s1[i + j] == 0) { r = 0.0; break; }
+    }
+    s2[i] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // step 3 (dio.cpp:215-231): forward from each falling edge of s2; result into s1
+  for (int i = 0; i < nf; ++i) s1[i] = s2[i];
+  {
+    int i = 1;
+    while (i < nf) {
+      if (s2[i] == 0 && s2[i - 1] != 0) {                       // negative_index = i - 1
+        const int start = i - 1;
+        int limit = nf - 1;                                     // next negative index, or f0_length - 1
+        for (int q = i + 1; q < nf; ++q)
+          if (s2[q] == 0 && s2[q - 1] != 0) { limit = q - 1; break; }
+        for (int j = start; j < limit; ++j) {
+          s1[j + 1] = dio_select(s1[j], s1[j - 1], cand, total_frames, base + j + 1, nb, allowed);
+          if (s1[j + 1] == 0) break;
+        }
+      }
+      ++i;
+    }
+  }
+  // step 4 (dio.cpp:237-253): backward from each rising edge of s2 (positive_index), last first
+  for (int i = 0; i < nf; ++i) out[i] = s1[i];
+  {
+    int i = nf - 1;
+    while (i >= 1) {
+      if (s2[i - 1] == 0 && s2[i] != 0) {                       // positive_index = i
+        int limit = 1;                                          // previous positive index, or 1
+        for (int q = i - 1; q >= 1; --q)
+          if (s2[q - 1] == 0 && s2[q] != 0) { limit = q; break; }
+        for (int j = i; j > limit; --j) {
+          out[j - 1] = dio_select(out[j], out[j + 1], cand, total_frames, base + j - 1, nb, allowed);
+          if (out[j - 1] == 0) break;
+        }
+      }
+      --i;
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------
+static int suitable_fft_size(int sample) {   // common.cpp:51-54
+  return (int)pow(2.0, (int)(log((double)sample) / kLog2) + 1.0);
+}
+
+struct DioHost {
+  DioMeta meta;
+  std::vector<double> lowcut, win;
+};
+
+static int dio_setup(Batch& b) {
+  if (b.dio_ready) return WM_OK;
+  const WorldMi355Params& p = b.p;
+  DioHost* H = new DioHost();
+  DioMeta& m = H->meta;
+  m.nb = 1 + (int)(log(p.f0_ceil / p.f0_floor) / kLog2 * p.channels_in_octave);      // dio.cpp:582-583
+  if (m.nb < 1 || m.nb > kMaxBands) { delete H; return WM_ERR_UNSUPPORTED; }
+  m.ratio = imax(imin(p.speed, 12), 1);                                                // :589
+  if (m.ratio != 1) { delete H; return WM_ERR_UNSUPPORTED; }                           // decimation: TODO
+  m.afs = (double)p.fs / m.ratio;
+  int woff = 0;
+  for (int i = 0; i < m.nb; ++i) {
+    m.boundary[i] = p.f0_floor * pow(2.0, (i + 1) / p.channels_in_octave);             // :585-586
+    m.hal[i] = matlab_round(m.afs / m.boundary[i] / 2.0);                              // :532
+    m.win_off[i] = woff;
+    woff += 4 * m.hal[i];
+  }
+  m.pad = 2 * m.hal[0];
+  m.cut = matlab_round(m.afs / 50.0);                                                  // :86
+  // Nuttall low-pass windows (dio.cpp:301, common.cpp:113-121)
+  H->win.resize((size_t)woff);
+  for (int i = 0; i < m.nb; ++i) {
+    const int n = 4 * m.hal[i];
+    for (int j = 0; j < n; ++j) {
+      double tmp = j / (n - 1.0);
+      H->win[(size_t)(m.win_off[i] + j)] = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) +
+                                           0.144232 * cos(4.0 * kPi * tmp) - 0.012604 * cos(6.0 * kPi * tmp);
+    }
+  }
+  // low-cut filter as a function of lag in [-cut, cut] (DesignLowCutFilter, dio.cpp:40-53)
+  {
+    const int N = 2 * m.cut + 1;
+    std::vector<double> lc((size_t)N);
+    double sum = 0.0;
+    for (int i = 1; i <= N; ++i) {
+      lc[(size_t)(i - 1)] = 0.5 - 0.5 * cos(i * 2.0 * kPi / (N + 1));
+      sum += lc[(size_t)(i - 1)];
+    }
+    H->lowcut.resize((size_t)N);
+    for (int i = 0; i < N; ++i) H->lowcut[(size_t)i] = -lc[(size_t)i] / sum;   // lag = i - cut
+    H->lowcut[(size_t)m.cut] += 1.0;
+  }
+  // per-utterance FFT size of the reference's circular convolution (dio.cpp:590-593)
+  std::vector<int> fftn((size_t)b.n_utt);
+  b.dio_z_off.assign((size_t)b.n_utt + 1, 0);
+  b.dio_ev_off.assign((size_t)b.n_utt + 1, 0);
+  for (int u = 0; u < b.n_utt; ++u) {
+    const int ylen = 1 + b.x_len[u] / m.ratio;
+    fftn[(size_t)u] = suitable_fft_size(ylen + 4 * (int)(1.0 + m.afs / m.boundary[0] / 2.0));
+    b.dio_z_off[(size_t)u + 1] = b.dio_z_off[(size_t)u] + ylen + 2 * m.pad;
+    b.dio_ev_off[(size_t)u + 1] = b.dio_ev_off[(size_t)u] + (int64_t)m.nb * 4 * (ylen / 2 + 2);
+  }
+  int rc = WM_OK;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (rc) return;
+    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  };
+  up((void**)&b.d_dio_lowcut, H->lowcut.data(), sizeof(double) * H->lowcut.size());
+  up((void**)&b.d_dio_win, H->win.data(), sizeof(double) * H->win.size());
+  up((void**)&b.d_dio_fft, fftn.data(), sizeof(int) * fftn.size());
+  up((void**)&b.d_dio_z_off, b.dio_z_off.data(), sizeof(int64_t) * b.dio_z_off.size());
+  up((void**)&b.d_dio_ev_off, b.dio_ev_off.data(), sizeof(int64_t) * b.dio_ev_off.size());
+  auto al = [&](void** dst, size_t bytes) {
+    if (rc) return;
+    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+  };
+  al((void**)&b.d_dio_mean, sizeof(double) * (size_t)b.n_utt);
+  al((void**)&b.d_dio_z, sizeof(double) * (size_t)b.dio_z_off[(size_t)b.n_utt]);
+  al((void**)&b.d_dio_events, sizeof(double) * (size_t)b.dio_ev_off[(size_t)b.n_utt]);
+  al((void**)&b.d_dio_ev_cnt, sizeof(int) * (size_t)b.n_utt * m.nb * 4);
+  al((void**)&b.d_dio_cand, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
+  al((void**)&b.d_dio_score, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
+  al((void**)&b.d_dio_ws, sizeof(double) * 3 * (size_t)b.total_f);
+  b.dio_host = H;
+  if (rc) return rc;
+  b.dio_ready = true;
+  return WM_OK;
+}
+
+void dio_free_host(void* h) { delete (DioHost*)h; }
+
+int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
+  int rc = dio_setup(b);
+  if (rc) return rc;
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const DioMeta& m = ((DioHost*)b.dio_host)->meta;
+  hipLaunchKernelGGL(dio_mean_kernel, dim3(b.n_utt), dim3(256), 0, st, d_x, b.d_x_off, b.d_x_len, b.d_dio_mean);
+  {
+    const int total_max = b.max_x_len + 1 + 2 * m.pad;
+    const int tiles = (total_max + kLcTile - 1) / kLcTile;
+    const size_t lds = sizeof(double) * (size_t)(kLcTile + 2 * m.cut + 2 * m.cut + 1);
+    hipLaunchKernelGGL(dio_lowcut_kernel, dim3(tiles, b.n_utt), dim3(256), lds, st, d_x, b.d_x_off, b.d_x_len,
+                       b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
+  }
+  {
+    const int ntap_max = 4 * m.hal[0];
+    const int zspan = kBandTile + ntap_max;
+    const int stride = (zspan + kBandK - 1) / kBandK + 1;
+    const size_t lds = sizeof(double) * (size_t)(kBandK * stride + ntap_max + kBandTile);
+    hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_x_len, b.d_dio_z_off,
+                       b.d_dio_z, b.d_dio_win, m, b.d_dio_ev_off, b.d_dio_events, b.d_dio_ev_cnt);
+  }
+  {
+    const int gx = (int)((b.total_f + 255) / 256);
+    hipLaunchKernelGGL(dio_candidate_kernel, dim3(gx, m.nb), dim3(256), 0, st, b.d_x_len, b.d_f_off,
+                       b.d_frame_utt, b.p.frame_period, m, b.p.f0_floor, b.p.f0_ceil, b.d_dio_ev_off, b.d_dio_events,
+                       b.d_dio_ev_cnt, b.total_f, b.d_dio_cand, b.d_dio_score);
+  }
+  hipLaunchKernelGGL(dio_fix_kernel, dim3(b.n_utt), dim3(256), 0, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,
+                     m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f, b.d_dio_ws, d_t, d_f0);
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm

@@ -1,0 +1,430 @@
+// synthesis.hip -- WORLD waveform synthesis for a batch of utterances.
+//
+// Replaces Synthesis and everything below it (externs/WORLD_v2/src/synthesis.cpp:19-397,
+// GetMinimumPhaseSpectrum common.cpp:182-220):
+//   synth_timebase_kernel  GetTimeBase :287-320 (+ :223-285): one wavefront per utterance;
+//                          the phase accumulation keeps the reference's strictly sequential
+//                          order (lane l adds increments 0..l one after another), so pulse
+//                          positions are bit-identical; pulses are compacted in order.
+//   synth_pulse_kernel     GetOneFrameSegment :183-221: one wavefront per pulse, 7 (voiced) or
+//                          4 (unvoiced) real FFTs of fft_size in LDS/registers.
+//   synth_ola_kernel       the overlap-add of :378-383 in gather form: every output sample sums
+//                          the responses that cover it in pulse order (deterministic, same
+//                          association as the reference's sequential +=).
+// The reference's randn() draws for pulse i are R[idx_i - idx_0 ...) of the universal table
+// (synthesis.cpp:341 reseed, :369 noise_size).
+#include <stdlib.h>
+
+#include "batch.hpp"
+#include "common.hpp"
+#include "fft.hpp"
+
+namespace wm {
+
+// coarse f0 / vuv knots of GetTemporalParametersForTimeBase (synthesis.cpp:223-240)
+__device__ __forceinline__ double coarse_f0(const double* __restrict__ f0, int nf, int j, double lowest) {
+  if (j < nf) {
+    const double v = f0[j];
+    return v < lowest ? 0.0 : v;
+  }
+  const int j2 = nf >= 2 ? nf - 2 : nf - 1;       // nf == 1 reads f0[-1] in the reference (undefined)
+  const double a = f0[nf - 1] < lowest ? 0.0 : f0[nf - 1];
+  const double b = f0[j2] < lowest ? 0.0 : f0[j2];
+  return a * 2 - b;
+}
+__device__ __forceinline__ double coarse_vuv(const double* __restrict__ f0, int nf, int j, double lowest) {
+  if (j < nf) return (f0[j] < lowest ? 0.0 : f0[j]) == 0.0 ? 0.0 : 1.0;
+  const double a = (f0[nf - 1] < lowest ? 0.0 : f0[nf - 1]) == 0.0 ? 0.0 : 1.0;
+  const int j2 = nf >= 2 ? nf - 2 : nf - 1;
+  const double b = (f0[j2] < lowest ? 0.0 : f0[j2]) == 0.0 ? 0.0 : 1.0;
+  return a * 2 - b;
+}
+
+__global__ __launch_bounds__(64) void synth_timebase_kernel(
+    const double* __restrict__ f0, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
+    int fs, double fp, double lowest_f0, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
+    double* __restrict__ vuv_out, int* __restrict__ pulse_cnt) {
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const double* f0u = f0 + f_off[u];
+  const int nf = (int)(f_off[u + 1] - f_off[u]);
+  const int64_t yb = y_off[u];
+  const int ylen = (int)(y_off[u + 1] - yb);
+  double carry = 0.0, prev_last = 0.0;
+  int count = 0;
+  for (int c0 = 0; c0 < ylen; c0 += 64) {
+    const int i = c0 + lane;
+    double inc = 0.0;
+    if (i < ylen) {
+      // interp1 (matlabfunctions.cpp:136-182) of the (nf+1)-knot coarse contours at t = i / fs
+      const double t = i / (double)fs;
+      int kg = (int)(t / fp) + 1;
+      if (kg > nf + 1) kg = nf + 1;
+      if (kg < 0) kg = 0;
+      while (kg <= nf && kg * fp <= t) ++kg;
+      while (kg > 0 && (kg - 1) * fp > t) --kg;
+      const int k = kg < 1 ? 1 : (kg > nf ? nf : kg);
+      const double x0 = (k - 1) * fp, x1 = k * fp;
+      const double h = x1 - x0;
+      const double s = (t - x0) / h;
+      const double fa = coarse_f0(f0u, nf, k - 1, lowest_f0), fb = coarse_f0(f0u, nf, k, lowest_f0);
+      const double va = coarse_vuv(f0u, nf, k - 1, lowest_f0), vb = coarse_vuv(f0u, nf, k, lowest_f0);
+      double fi = fa + s * (fb - fa);
+      const double vi = va + s * (vb - va);
+      const double vv = vi > 0.5 ? 1.0 : 0.0;                 // synthesis.cpp:303-307
+      fi = vv == 0.0 ? kDefaultF0 : fi;
+      vuv_out[yb + i] = vv;
+      inc = 2.0 * kPi * fi / fs;                              // :248-252
+    }
+    // total_phase[i] = total_phase[i-1] + inc[i], strictly in order (:250-252)
+    double t = carry;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const double sj = __shfl(inc, j, 64);
+      if (lane >= j) t += sj;
+    }
+    const double wrap = fmod(t, 2.0 * kPi);                   // :249, :253
+    double prev = __shfl_up(wrap, 1, 64);
+    if (lane == 0) prev = prev_last;
+    // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
+    const bool hit = i >= 1 && i < ylen && fabs(wrap - prev) > kPi;
+    const unsigned long long bal = __ballot(hit);
+    if (hit) {
+      const int dst = count + __popcll(bal & ((1ull << lane) - 1ull));
+      const double y1 = prev - 2.0 * kPi, y2 = wrap;          // :271-274
+      const double xx = -y1 / (y2 - y1);
+      pulse_idx[yb + dst] = i - 1;
+      pulse_shift[yb + dst] = xx / fs;
+    }
+    count += __popcll(bal);
+    carry = __shfl(t, 63, 64);
+    prev_last = __shfl(wrap, 63, 64);
+  }
+  if (lane == 0) pulse_cnt[u] = count;
+}
+
+__global__ void synth_dc_remover_kernel(int fft_size, double* __restrict__ dcr) {   // GetDCRemover :322-334
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double dc = 0.0;
+  const int h = fft_size / 2;
+  for (int i = 0; i < h; ++i) {
+    dcr[i] = 0.5 - 0.5 * cos(2.0 * kPi * (i + 1.0) / (1.0 + fft_size));
+    dcr[fft_size - i - 1] = dcr[i];
+    dc += dcr[i] * 2.0;
+  }
+  for (int i = 0; i < h; ++i) {
+    dcr[i] /= dc;
+    dcr[fft_size - i - 1] = dcr[i];
+  }
+}
+
+__device__ __forceinline__ double safe_ap(double v) {          // common.h:111-113
+  const double m = 0.999999999999 < v ? 0.999999999999 : v;
+  return 0.001 > m ? 0.001 : m;
+}
+
+// GetMinimumPhaseSpectrum (common.cpp:182-220) for one wavefront.  ls[0..H] (LDS) holds the
+// log spectrum; on exit mp[m] is the minimum-phase spectrum at bins lane + 64 m (m < M) and
+// mp[M] at bin H = N (all lanes compute it).  The cepstrum's imaginary parts (rounding noise of
+// a real symmetric transform) are dropped, so the reference's c2c becomes a second r2c.
+template <int N>
+__device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const FftTw<N>& tw, int lane,
+                                              cpx (&mp)[N / 64 + 1]) {
+  constexpr int M = N / 64, F = 2 * N, H = N;
+  cpx v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
+    v[m] = make_double2(ls[i0 <= H ? i0 : F - i0], ls[i1 <= H ? i1 : F - i1]);   // mirroring :184-187
+  }
+  rfft_forward<N>(v, img, img, tw, lane);
+  // folded cepstrum c[0]=C0, c[j]=2C[j] (0<j<H), c[H]=C[H], 0 above (:193-203), packed for the next r2c
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
+    double a = 0.0, b = 0.0;
+    if (i0 <= H) a = (i0 == 0 || i0 == H) ? img[i0].x : 2.0 * img[i0].x;
+    if (i1 < H) b = 2.0 * img[i1].x;
+    v[m] = make_double2(a, b);
+  }
+  rfft_forward<N>(v, img, img, tw, lane);
+#pragma unroll
+  for (int m = 0; m <= M; ++m) {
+    const int k = m < M ? lane + 64 * m : N;
+    const cpx s = img[k];
+    const double amp = exp(s.x / F);                              // :210-218
+    double sn, cs;
+    sincos(s.y / F, &sn, &cs);
+    mp[m] = make_double2(amp * cs, amp * sn);
+  }
+  __syncthreads();
+}
+
+// One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
+template <int F>
+__global__ __launch_bounds__(64) void synth_pulse_kernel(
+    const double* __restrict__ f0, const double* __restrict__ sp, const double* __restrict__ ap,
+    const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
+    int n_utt, const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift,
+    const double* __restrict__ vuv, const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs,
+    double fp, int64_t p_begin, int64_t p_end, double* __restrict__ resp) {
+  constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + H + 2];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  double* ls = smem + 2 * FftLds<N>::kElems;
+  const int lane = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane);
+
+  for (int64_t p = p_begin + blockIdx.x; p < p_end; p += gridDim.x) {
+    // utterance of this pulse: last u with p_off[u] <= p
+    int lo = 0, hi = n_utt;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (p_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int u = lo;
+    const int pi = (int)(p - p_off[u]);
+    const int np = (int)(p_off[u + 1] - p_off[u]);
+    const int64_t yb = y_off[u];
+    const int nf = (int)(f_off[u + 1] - f_off[u]);
+    const int idx = pulse_idx[yb + pi];
+    const int idx0 = pulse_idx[yb];
+    const int idx_next = pulse_idx[yb + imin(np - 1, pi + 1)];
+    const int noise_size = idx_next - idx;                          // synthesis.cpp:369
+    const double cvuv = vuv[yb + idx];
+    const double ctime = idx / (double)fs;                          // pulse_locations = time_axis[i]
+    const double shift = pulse_shift[yb + pi];
+
+    // ---- GetSpectralEnvelope / GetAperiodicRatio (:140-178) ----
+    const int ff = imin(nf - 1, (int)floor(ctime / fp));
+    const int fc = imin(nf - 1, (int)ceil(ctime / fp));
+    const double wgt = ctime / fp - ff;
+    const double* s0 = sp + (f_off[u] + ff) * (int64_t)(H + 1);
+    const double* s1 = sp + (f_off[u] + fc) * (int64_t)(H + 1);
+    const double* a0 = ap + (f_off[u] + ff) * (int64_t)(H + 1);
+    const double* a1 = ap + (f_off[u] + fc) * (int64_t)(H + 1);
+    double env[MB], rat[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const int k = m < M ? lane + 64 * m : H;
+      if (ff == fc) {
+        env[m] = fabs(s0[k]);
+        const double a = safe_ap(a0[k]);
+        rat[m] = a * a;
+      } else {
+        env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
+        const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
+        rat[m] = a * a;
+      }
+    }
+    const double rat0 = __shfl(rat[0], 0, 64);
+
+    // ---- GetPeriodicResponse (:105-138) ----
+    double xp[M];                       // periodic c2r output, x-index i = 2n + c for n < N/2 (first half)
+    double dc = 0.0;
+    const bool periodic = !(cvuv <= 0.5 || rat0 > 0.999);
+#pragma unroll
+    for (int m = 0; m < M; ++m) xp[m] = 0.0;
+    if (periodic) {
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m) ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+      if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
+      __syncthreads();
+      cpx mp[MB];
+      minimum_phase<N>(ls, img, tw, lane, mp);
+      const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {                                // :88-100
+        const int k = m < M ? lane + 64 * m : H;
+        const double re2 = cos(coef * k);
+        const double im2 = sqrt(1.0 - re2 * re2);
+        const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
+        if (m < M || lane == 0) img[k] = s;
+      }
+      cpx v[M];
+      rfft_backward<N>(img, v, img, tw, lane);
+      // fftshift + RemoveDCComponent (:73-82, :135-137): dc = sum of the shifted second half = x[0..H)
+#pragma unroll
+      for (int m = 0; m < M / 2; ++m) {
+        xp[2 * m] = v[m].x;
+        xp[2 * m + 1] = v[m].y;
+        dc += v[m].x + v[m].y;
+      }
+      dc = wave_sum(dc);
+      __syncthreads();
+    }
+
+    // ---- GetAperiodicResponse (:38-68) ----
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const int k = m < M ? lane + 64 * m : H;
+      const double val = cvuv != 0.0 ? log(env[m] * rat[m]) / 2.0 : log(env[m]) / 2.0;
+      if (m < M || lane == 0) ls[k] = val;
+    }
+    __syncthreads();
+    cpx mp[MB];
+    minimum_phase<N>(ls, img, tw, lane, mp);
+    // GetNoiseSpectrum (:19-33)
+    cpx v[M];
+    {
+      const int roff = idx - idx0;
+      double sum = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        const double n0 = i0 < noise_size ? randn_at(rtab, roff + i0) : 0.0;
+        const double n1 = i0 + 1 < noise_size ? randn_at(rtab, roff + i0 + 1) : 0.0;
+        v[m] = make_double2(n0, n1);
+        sum += n0 + n1;
+      }
+      const double avg = wave_sum(sum) / noise_size;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        if (i0 < noise_size) v[m].x -= avg;
+        if (i0 + 1 < noise_size) v[m].y -= avg;
+      }
+    }
+    rfft_forward<N>(v, img, img, tw, lane);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const int k = m < M ? lane + 64 * m : H;
+      const cpx ns = img[k];
+      const cpx s = make_double2(mp[m].x * ns.x - mp[m].y * ns.y, mp[m].x * ns.y + mp[m].y * ns.x);
+      if (m < M || lane == 0) img[k] = s;
+    }
+    rfft_backward<N>(img, v, img, tw, lane);
+
+    // ---- response = (periodic * sqrt(noise_size) + aperiodic) / fft_size (:211-215), fftshifted ----
+    const double sq = sqrt((double)noise_size);
+    double* out = resp + (p - p_begin) * (int64_t)F;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int n = lane + 64 * m;
+      const int i0 = 2 * n;                           // x-index; shifted position j = (i + H) mod F
+      double r0, r1;
+      if (m < M / 2) {                                // i < H  ->  j = i + H (second half)
+        const double p0 = periodic ? xp[2 * m] - dc * dcr[i0 + H] : 0.0;
+        const double p1 = periodic ? xp[2 * m + 1] - dc * dcr[i0 + 1 + H] : 0.0;
+        r0 = (p0 * sq + v[m].x) / F;
+        r1 = (p1 * sq + v[m].y) / F;
+        out[i0 + H] = r0;
+        out[i0 + 1 + H] = r1;
+      } else {                                        // i >= H ->  j = i - H (first half, periodic overwritten)
+        const double p0 = periodic ? -dc * dcr[i0 - H] : 0.0;
+        const double p1 = periodic ? -dc * dcr[i0 + 1 - H] : 0.0;
+        r0 = (p0 * sq + v[m].x) / F;
+        r1 = (p1 * sq + v[m].y) / F;
+        out[i0 - H] = r0;
+        out[i0 + 1 - H] = r1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// y[n] += sum over pulses p (of this utterance, within [p_begin, p_end)) covering n, in pulse order:
+// index = j + idx - F/2 + 1  (synthesis.cpp:378-383)  ->  j = n - idx + F/2 - 1.
+__global__ __launch_bounds__(256) void synth_ola_kernel(const int64_t* __restrict__ y_off,
+                                                        const int64_t* __restrict__ p_off,
+                                                        const int* __restrict__ pulse_idx, int fft_size,
+                                                        int64_t p_begin, int64_t p_end,
+                                                        const double* __restrict__ resp, double* __restrict__ y) {
+  const int u = blockIdx.y;
+  const int64_t yb = y_off[u];
+  const int ylen = (int)(y_off[u + 1] - yb);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  int64_t pa = p_off[u] > p_begin ? p_off[u] : p_begin;
+  int64_t pb = p_off[u + 1] < p_end ? p_off[u + 1] : p_end;
+  if (n >= ylen || pa >= pb) return;
+  const int h = fft_size / 2;
+  const int* pidx = pulse_idx + yb - p_off[u];        // pidx[p] = index of global pulse p
+  // first pulse with idx >= n - h
+  int64_t lo = pa, hi = pb;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (pidx[mid] < n - h) lo = mid + 1; else hi = mid;
+  }
+  double acc = y[yb + n];
+  for (int64_t p = lo; p < pb; ++p) {
+    const int idx = pidx[p];
+    if (idx > n + h - 1) break;
+    acc += resp[(p - p_begin) * (int64_t)fft_size + (n - idx + h - 1)];
+  }
+  y[yb + n] = acc;
+}
+
+int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int F = b.p.fft_size, fs = b.p.fs;
+  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  int rc = c.ensure_rng(b.rng_bound_synthesis());
+  if (rc) return rc;
+  if (!b.d_pulse_idx) {
+    auto al = [&](void** dst, size_t bytes) {
+      if (rc) return;
+      rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    };
+    al((void**)&b.d_pulse_idx, sizeof(int) * (size_t)b.total_y);
+    al((void**)&b.d_pulse_shift, sizeof(double) * (size_t)b.total_y);
+    al((void**)&b.d_vuv, sizeof(double) * (size_t)b.total_y);
+    al((void**)&b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt);
+    al((void**)&b.d_pulse_off, sizeof(int64_t) * ((size_t)b.n_utt + 1));
+    al((void**)&b.d_dc_remover, sizeof(double) * (size_t)F);
+    if (rc) return rc;
+    rc = wm_check(hipHostMalloc((void**)&b.h_pulse_cnt, sizeof(int) * (size_t)b.n_utt));
+    if (rc) return rc;
+    hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, st, F, b.d_dc_remover);
+  }
+  const double fp = b.p.frame_period / 1000.0;
+  const double lowest_f0 = fs / F + 1.0;                  // integer division as in synthesis.cpp:359
+  rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
+  if (rc) return rc;
+  hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, d_f0, b.d_f_off, b.d_y_off, fs, fp,
+                     lowest_f0, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_pulse_cnt);
+  rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
+                               hipMemcpyDeviceToHost, st));
+  if (rc) return rc;
+  rc = wm_check(hipStreamSynchronize(st));                // the pulse count sizes the response scratch
+  if (rc) return rc;
+  std::vector<int64_t> poff((size_t)b.n_utt + 1, 0);
+  for (int u = 0; u < b.n_utt; ++u) poff[(size_t)u + 1] = poff[(size_t)u] + b.h_pulse_cnt[u];
+  const int64_t total_p = poff[(size_t)b.n_utt];
+  rc = wm_check(hipMemcpyAsync(b.d_pulse_off, poff.data(), sizeof(int64_t) * poff.size(), hipMemcpyHostToDevice, st));
+  if (rc) return rc;
+  rc = wm_check(hipStreamSynchronize(st));                // poff is a local
+  if (rc) return rc;
+  if (total_p == 0) return WM_OK;
+  int64_t cap_mb = 4096;
+  if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
+  int64_t chunk = (cap_mb * 1024 * 1024 / 8) / F;
+  if (chunk < 1) chunk = 1;
+  if (chunk > total_p) chunk = total_p;
+  rc = c.ensure_scratch(chunk * F);
+  if (rc) return rc;
+  const int ola_tiles = (b.max_y_len + 255) / 256;
+  for (int64_t p0 = 0; p0 < total_p; p0 += chunk) {
+    const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
+    const int64_t np = p1 - p0;
+    const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
+#define WM_SY_CASE(FF)                                                                                          \
+  case FF:                                                                                                      \
+    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(grid), dim3(64), 0, st, d_f0, d_sp, d_ap, b.d_f_off,         \
+                       b.d_y_off, b.d_pulse_off, b.n_utt, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,              \
+                       b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);                                   \
+    break;
+    switch (F) {
+      WM_SY_CASE(1024)
+      WM_SY_CASE(2048)
+    }
+#undef WM_SY_CASE
+    hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(256), 0, st, b.d_y_off, b.d_pulse_off,
+                       b.d_pulse_idx, F, p0, p1, c.d_scratch, d_y);
+  }
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm

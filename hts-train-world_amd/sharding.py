@@ -1,0 +1,70 @@
+"""Utterance sharding across the GPUs of one node and the final feature gather.
+
+The reference processes utterances one after another in a shell loop
+(data/Makefile.in:125-242); they are independent, so the batch is partitioned across
+ranks with no data-path collective.  The only exchange is the final gather of the
+f0 / sp / ap arrays to rank 0 (which writes the feature files): a gather-v built from
+grouped point-to-point send/recv (RCCL over xGMI when the backend is "nccl", gloo on
+CPU in the tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def frame_count(n_samples: int, fs: int, frame_period: float) -> int:
+    """GetSamplesForDIO (externs/WORLD_v2/src/dio.cpp:638-640)."""
+    return int(1000.0 * n_samples / fs / frame_period) + 1
+
+
+def lpt_shards(costs, world_size: int) -> list[list[int]]:
+    """Longest-processing-time partition of utterance indices by cost (frame counts).
+
+    Deterministic: ties broken by index.  Every rank gets a (possibly empty) list."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0] * world_size
+    shards: list[list[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += costs[i]
+    for s in shards:
+        s.sort()
+    return shards
+
+
+def gather_features(tensors, frame_counts, dst: int = 0, group=None):
+    """Gather-v of per-rank feature slabs to ``dst``.
+
+    tensors: list of torch tensors whose first dimension is this rank's total frame count
+             (e.g. [f0 (T,), sp (T, bins), ap (T, bins)]).
+    frame_counts: this rank's per-utterance frame counts (python ints).
+    Returns on dst: (list of gathered tensors in rank order, list of per-rank frame-count
+    lists); elsewhere None.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts = [None] * world
+    dist.all_gather_object(counts, [int(c) for c in frame_counts], group=group)
+    totals = [sum(c) for c in counts]
+    if world == 1:
+        return [t for t in tensors], counts
+    ops, outs = [], []
+    if rank == dst:
+        offs = np.concatenate([[0], np.cumsum(totals)])
+        for t in tensors:
+            out = torch.empty((int(offs[-1]),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            out[offs[dst]:offs[dst + 1]].copy_(t)
+            for r in range(world):
+                if r != dst and totals[r] > 0:
+                    ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group))
+            outs.append(out)
+    elif totals[rank] > 0:
+        for t in tensors:
+            ops.append(dist.P2POp(dist.isend, t.contiguous(), dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return (outs, counts) if rank == dst else None

@@ -1,0 +1,225 @@
+"""ctypes host layer over libworld_mi355.so (the C ABI declared in include/).
+
+Mirrors the reference's per-utterance operator interface
+(externs/WORLD_v2/src/world/{dio,stonemask,cheaptrick,d4c,synthesis,harvest}.h)
+for numpy callers and adds ``WorldBatch`` for device-resident batches (torch
+tensors on ``cuda``).  torch is used only for device memory and streams.
+
+The library is mandatory: nothing here computes WORLD on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libworld_mi355.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+ERRORS = {1: "HIP error", 2: "bad argument", 3: "unsupported fft_size", 4: "no HIP device",
+          5: "unsupported configuration"}
+
+
+class WorldParams(C.Structure):
+    """include/world_mi355.h: WorldMi355Params."""
+    _fields_ = [("fs", C.c_int), ("frame_period", C.c_double), ("f0_floor", C.c_double),
+                ("f0_ceil", C.c_double), ("channels_in_octave", C.c_double), ("speed", C.c_int),
+                ("allowed_range", C.c_double), ("q1", C.c_double), ("fft_size", C.c_int),
+                ("d4c_threshold", C.c_double)]
+
+
+def build_library() -> None:
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j8"])
+
+
+_lib = None
+
+
+def load_library():
+    """Load libworld_mi355.so; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950); "
+                           "this package has no CPU path")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.WorldMi355LastError.restype = C.c_char_p
+    L.WorldMi355DefaultParams.argtypes = [C.c_int, C.c_double, C.POINTER(WorldParams)]
+    L.WorldMi355CreateContext.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.WorldMi355DestroyContext.argtypes = [vp]
+    L.WorldMi355SetStream.argtypes = [vp, vp]
+    L.WorldMi355Synchronize.argtypes = [vp]
+    L.WorldMi355CreateBatch.argtypes = [vp, C.POINTER(WorldParams), C.c_int, _ip, _ip, _ip, C.POINTER(vp)]
+    L.WorldMi355DestroyBatch.argtypes = [vp]
+    for name in ("TotalSamples", "TotalFrames", "TotalOutputSamples"):
+        f = getattr(L, "WorldMi355Batch" + name)
+        f.restype = C.c_int64
+        f.argtypes = [vp]
+    L.WorldMi355BatchFftSize.argtypes = [vp]
+    for name in ("SampleOffsets", "FrameOffsets", "OutputOffsets"):
+        f = getattr(L, "WorldMi355Batch" + name)
+        f.restype = C.POINTER(C.c_int64)
+        f.argtypes = [vp]
+    L.WorldMi355Dio.argtypes = [vp, vp, vp, vp]
+    L.WorldMi355Harvest.argtypes = [vp, vp, vp, vp]
+    L.WorldMi355StoneMask.argtypes = [vp, vp, vp, vp, vp]
+    L.WorldMi355CheapTrick.argtypes = [vp, vp, vp, vp, vp]
+    L.WorldMi355D4C.argtypes = [vp, vp, vp, vp, vp]
+    L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
+    L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.WorldMi355TestRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int, where: str) -> None:
+    if rc != 0:
+        msg = load_library().WorldMi355LastError()
+        raise RuntimeError(f"{where}: {ERRORS.get(rc, rc)} ({msg.decode() if msg else ''})")
+
+
+def default_params(fs: int, frame_period: float = 5.0, **over) -> WorldParams:
+    p = WorldParams()
+    load_library().WorldMi355DefaultParams(fs, frame_period, C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One HIP stream + the universal randn table on one device."""
+
+    def __init__(self, device: int | None = None, stream_ptr: int | None = None):
+        L = load_library()
+        h = C.c_void_p()
+        _check(L.WorldMi355CreateContext(-1 if device is None else device,
+                                         C.c_void_p(stream_ptr) if stream_ptr else None, C.byref(h)),
+               "CreateContext")
+        self.handle = h
+
+    def synchronize(self):
+        _check(load_library().WorldMi355Synchronize(self.handle), "Synchronize")
+
+    def close(self):
+        if self.handle:
+            load_library().WorldMi355DestroyContext(self.handle)
+            self.handle = None
+
+
+def _ints(a):
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=np.int32)
+    return arr, arr.ctypes.data_as(_ip)
+
+
+class WorldBatch:
+    """A batch of utterances resident in HBM (torch cuda tensors, float64).
+
+    x is the concatenation of the waveforms (see ``sample_offsets``); t, f0 have
+    ``total_frames`` entries, sp/ap ``total_frames x (fft_size/2+1)``.
+    """
+
+    def __init__(self, ctx: Context, params: WorldParams, x_lengths=None, f0_lengths=None, y_lengths=None):
+        L = load_library()
+        self.ctx = ctx
+        self.params = params
+        n = len(x_lengths) if x_lengths is not None else len(f0_lengths)
+        xa, xp = _ints(x_lengths)
+        fa, fp = _ints(f0_lengths)
+        ya, yp = _ints(y_lengths)
+        h = C.c_void_p()
+        _check(L.WorldMi355CreateBatch(ctx.handle, C.byref(params), n, xp, fp, yp, C.byref(h)), "CreateBatch")
+        self.handle = h
+        self.n_utt = n
+        self.total_samples = L.WorldMi355BatchTotalSamples(h)
+        self.total_frames = L.WorldMi355BatchTotalFrames(h)
+        self.total_out = L.WorldMi355BatchTotalOutputSamples(h)
+        self.fft_size = L.WorldMi355BatchFftSize(h)
+        self.bins = self.fft_size // 2 + 1
+        self.sample_offsets = np.ctypeslib.as_array(L.WorldMi355BatchSampleOffsets(h), (n + 1,)).copy()
+        self.frame_offsets = np.ctypeslib.as_array(L.WorldMi355BatchFrameOffsets(h), (n + 1,)).copy()
+        self.out_offsets = np.ctypeslib.as_array(L.WorldMi355BatchOutputOffsets(h), (n + 1,)).copy()
+
+    @staticmethod
+    def _p(t):
+        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float64", "cuda float64 contiguous"
+        return C.c_void_p(t.data_ptr())
+
+    def _new(self, *shape):
+        import torch
+        return torch.empty(*shape, dtype=torch.float64, device="cuda")
+
+    def dio(self, x):
+        t, f0 = self._new(self.total_frames), self._new(self.total_frames)
+        _check(load_library().WorldMi355Dio(self.handle, self._p(x), self._p(t), self._p(f0)), "Dio")
+        return t, f0
+
+    def harvest(self, x):
+        t, f0 = self._new(self.total_frames), self._new(self.total_frames)
+        _check(load_library().WorldMi355Harvest(self.handle, self._p(x), self._p(t), self._p(f0)), "Harvest")
+        return t, f0
+
+    def stonemask(self, x, t, f0):
+        out = self._new(self.total_frames)
+        _check(load_library().WorldMi355StoneMask(self.handle, self._p(x), self._p(t), self._p(f0), self._p(out)),
+               "StoneMask")
+        return out
+
+    def cheaptrick(self, x, t, f0, out=None):
+        sp = out if out is not None else self._new(self.total_frames, self.bins)
+        _check(load_library().WorldMi355CheapTrick(self.handle, self._p(x), self._p(t), self._p(f0), self._p(sp)),
+               "CheapTrick")
+        return sp
+
+    def d4c(self, x, t, f0, out=None):
+        ap = out if out is not None else self._new(self.total_frames, self.bins)
+        _check(load_library().WorldMi355D4C(self.handle, self._p(x), self._p(t), self._p(f0), self._p(ap)), "D4C")
+        return ap
+
+    def analyze(self, x, out=None):
+        """Dio -> StoneMask -> CheapTrick -> D4C (test/analysis.cpp:243-390)."""
+        if out is None:
+            out = (self._new(self.total_frames), self._new(self.total_frames),
+                   self._new(self.total_frames, self.bins), self._new(self.total_frames, self.bins))
+        t, f0, sp, ap = out
+        _check(load_library().WorldMi355Analyze(self.handle, self._p(x), self._p(t), self._p(f0), self._p(sp),
+                                                self._p(ap)), "Analyze")
+        return t, f0, sp, ap
+
+    def synthesize(self, f0, sp, ap, out=None):
+        y = out if out is not None else self._new(self.total_out)
+        _check(load_library().WorldMi355Synthesis(self.handle, self._p(f0), self._p(sp), self._p(ap), self._p(y)),
+               "Synthesis")
+        return y
+
+    def split_frames(self, a):
+        return [a[self.frame_offsets[u]:self.frame_offsets[u + 1]] for u in range(self.n_utt)]
+
+    def split_out(self, y):
+        return [y[self.out_offsets[u]:self.out_offsets[u + 1]] for u in range(self.n_utt)]
+
+    def close(self):
+        if self.handle:
+            load_library().WorldMi355DestroyBatch(self.handle)
+            self.handle = None
+
+
+def test_rfft(ctx: Context, x):
+    """Run the in-kernel wavefront real FFT on the rows of x (cuda float64 [count, n])."""
+    import torch
+    count, n = x.shape
+    re = torch.empty(count, n // 2 + 1, dtype=torch.float64, device="cuda")
+    im = torch.empty_like(re)
+    xb = torch.empty_like(x)
+    _check(load_library().WorldMi355TestRfft(ctx.handle, n, count, C.c_void_p(x.data_ptr()),
+                                             C.c_void_p(re.data_ptr()), C.c_void_p(im.data_ptr()),
+                                             C.c_void_p(xb.data_ptr())), "TestRfft")
+    ctx.synchronize()
+    return re, im, xb

@@ -1,0 +1,112 @@
+/*
+ * world_mi355.h -- batched, device-resident extension of WORLD's C API for MI355X.
+ *
+ * The drop-in boundary of this repo is WORLD's own public C ABI (include/world/,
+ * one header per reference header, same names/signatures/struct layouts).  Those
+ * entry points take HOST pointers, one utterance per call, exactly like the
+ * reference (externs/WORLD_v2/src/world/{dio,stonemask,cheaptrick,d4c,synthesis,harvest}.h).
+ *
+ * This header is the extension underneath them: a batch of utterances whose
+ * waveforms and features stay in HBM, processed by the same kernels.  The
+ * per-utterance functions are thin wrappers over a batch of one.  Everything is
+ * plain C: opaque handles, device pointers as `double*`, sizes as int/int64_t,
+ * int error codes (0 = ok) -- no torch, no C++ types.
+ *
+ * Layout of a batch (B utterances):
+ *   x   : double[sum x_length]          concatenated waveforms, utterance u at x_offset[u]
+ *   t,f0: double[sum f0_length]         frames concatenated, utterance u at frame_offset[u]
+ *   sp,ap: double[sum f0_length][fft_size/2+1]   row-major, same frame order
+ *   y   : double[sum y_length]          synthesised waveforms at y_offset[u]
+ * with f0_length[u] = GetSamplesForDIO(fs, x_length[u], frame_period)  (dio.cpp:638-640)
+ * and  y_length[u]  = int((f0_length-1)*frame_period/1000*fs)+1        (test/synth.cpp:259)
+ * unless given explicitly.
+ */
+#ifndef WORLD_MI355_H_
+#define WORLD_MI355_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK 0
+#define WM_ERR_HIP 1              /* a HIP runtime call failed; see WorldMi355LastError() */
+#define WM_ERR_BAD_ARG 2
+#define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048} */
+#define WM_ERR_NO_DEVICE 4        /* no HIP device: the product path never falls back to CPU */
+#define WM_ERR_UNSUPPORTED 5
+
+typedef struct WorldMi355Context WorldMi355Context;
+typedef struct WorldMi355Batch WorldMi355Batch;
+
+/* All option fields of the reference's four option structs in one POD
+ * (dio.h:16-23, cheaptrick.h:16-20, d4c.h:16-18, harvest.h:16-20). */
+typedef struct {
+  int fs;
+  double frame_period;        /* ms */
+  double f0_floor;            /* DIO / Harvest */
+  double f0_ceil;
+  double channels_in_octave;  /* DIO */
+  int speed;                  /* DIO decimation ratio 1..12 */
+  double allowed_range;       /* DIO */
+  double q1;                  /* CheapTrick */
+  int fft_size;               /* CheapTrick / D4C / Synthesis; 0 = GetFFTSizeForCheapTrick(fs) */
+  double d4c_threshold;       /* D4C */
+} WorldMi355Params;
+
+/* Defaults as the reference's analysis CLI sets them (test/analysis.cpp:93-203):
+ * floor 71, ceil 800, 2 ch/oct, speed 1, range 0.1, q1 -0.15, threshold 0 (NOT 0.85). */
+void WorldMi355DefaultParams(int fs, double frame_period, WorldMi355Params* p);
+
+/* device < 0: current device.  stream == NULL: the context creates its own. */
+int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** out);
+void WorldMi355DestroyContext(WorldMi355Context* ctx);
+int WorldMi355SetStream(WorldMi355Context* ctx, void* hip_stream);
+int WorldMi355Synchronize(WorldMi355Context* ctx);
+const char* WorldMi355LastError(void);
+
+/* f0_lengths / y_lengths may be NULL (derived as documented above).  For a
+ * synthesis-only batch pass x_lengths = NULL and give f0_lengths (+ y_lengths). */
+int WorldMi355CreateBatch(WorldMi355Context* ctx, const WorldMi355Params* params, int n_utt,
+                          const int* x_lengths, const int* f0_lengths, const int* y_lengths,
+                          WorldMi355Batch** out);
+void WorldMi355DestroyBatch(WorldMi355Batch* b);
+int64_t WorldMi355BatchTotalSamples(const WorldMi355Batch* b);
+int64_t WorldMi355BatchTotalFrames(const WorldMi355Batch* b);
+int64_t WorldMi355BatchTotalOutputSamples(const WorldMi355Batch* b);
+int WorldMi355BatchFftSize(const WorldMi355Batch* b);
+const int64_t* WorldMi355BatchSampleOffsets(const WorldMi355Batch* b);  /* host, n_utt+1 */
+const int64_t* WorldMi355BatchFrameOffsets(const WorldMi355Batch* b);   /* host, n_utt+1 */
+const int64_t* WorldMi355BatchOutputOffsets(const WorldMi355Batch* b);  /* host, n_utt+1 */
+
+/* Stage entry points; every pointer is a DEVICE pointer.  Asynchronous on the
+ * context's stream unless stated.  Same meaning as the reference functions:
+ *   Dio        dio.cpp:642-647        StoneMask  stonemask.cpp:211-217
+ *   CheapTrick cheaptrick.cpp:200-228 D4C        d4c.cpp:337-397
+ *   Synthesis  synthesis.cpp:338-397 (synchronises once internally: the pulse count
+ *              decides the size of the overlap-add scratch)
+ *   Harvest    harvest.cpp:1223-1255 */
+int WorldMi355Dio(WorldMi355Batch* b, const double* x, double* t, double* f0);
+int WorldMi355StoneMask(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
+                        double* refined_f0);
+int WorldMi355CheapTrick(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
+                         double* sp);
+int WorldMi355D4C(WorldMi355Batch* b, const double* x, const double* t, const double* f0, double* ap);
+int WorldMi355Synthesis(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
+                        double* y);
+int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0);
+
+/* Dio -> StoneMask -> CheapTrick -> D4C, as test/analysis.cpp:243-390 chains them. */
+int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
+                      double* ap);
+
+/* Test hook: forward/backward real FFT of `count` rows of length n (512..4096) through the
+ * in-kernel wavefront FFT; layouts as fft.cpp:26-72 (re/im split, n/2+1 bins). */
+int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
+                       double* im, double* x_back);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WORLD_MI355_H_ */

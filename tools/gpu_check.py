@@ -1,0 +1,70 @@
+"""Quick on-GPU parity report (stage by stage) against the oracle; prints max errors."""
+import importlib, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("hts-train-world_amd")
+from oracle.bindings import Oracle
+W, sd = pkg.world, pkg.synth_data
+
+def rep(name, a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    d = np.abs(a - b)
+    print(f"  {name:10s} max|d|={d.max():.3e} rmse={np.sqrt(np.mean(d**2)):.3e} max|ref|={np.abs(b).max():.3e} argmax={np.unravel_index(d.argmax(), d.shape)}", flush=True)
+
+def main():
+    fs = 16000
+    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+    o = Oracle()
+    # FFT
+    for n in (1024, 2048, 4096):
+        x = torch.randn(64, n, dtype=torch.float64, device="cuda")
+        re, im, xb = W.test_rfft(ctx, x)
+        ref = np.fft.rfft(x.cpu().numpy(), axis=1)
+        print(f"rfft{n}: max|d| fwd {np.abs(re.cpu().numpy() + 1j*im.cpu().numpy() - ref).max():.3e}  roundtrip/n {np.abs(xb.cpu().numpy()/n - x.cpu().numpy()).max():.3e}", flush=True)
+    nutt = int(os.environ.get("NUTT", "3"))
+    xs = [sd.make_utterance(i, fs, (2.0, 4.0)) for i in range(nutt)]
+    p = W.default_params(fs, 5.0)
+    b = W.WorldBatch(ctx, p, x_lengths=[len(x) for x in xs])
+    xcat = torch.from_numpy(np.concatenate(xs)).cuda()
+    stages = os.environ.get("STAGES", "dio,sm,ct,d4c,syn").split(",")
+    # oracle
+    O = []
+    for x in xs:
+        t, f0 = o.dio(x, fs); f0r = o.stonemask(x, fs, t, f0)
+        sp = o.cheaptrick(x, fs, t, f0r); ap = o.d4c(x, fs, t, f0r, 1024, 0.0)
+        y = o.synthesis(f0r, sp, ap, 1024, 5.0, fs)
+        O.append((t, f0, f0r, sp, ap, y))
+    cat = lambda k: np.concatenate([r[k] for r in O])
+    t_o, f0_o, f0r_o, sp_o, ap_o, y_o = (cat(k) for k in range(6))
+    dt = lambda a: torch.from_numpy(a).cuda()
+    if "dio" in stages:
+        t, f0 = b.dio(xcat); torch.cuda.synchronize()
+        print("DIO"); rep("t", t.cpu(), t_o); rep("f0", f0.cpu(), f0_o)
+        print("   voiced mismatch:", int(((f0.cpu().numpy() > 0) != (f0_o > 0)).sum()), "of", len(f0_o))
+    if "sm" in stages:
+        f0r = b.stonemask(xcat, dt(t_o), dt(f0_o)); torch.cuda.synchronize()
+        print("StoneMask"); rep("f0r", f0r.cpu(), f0r_o)
+    if "ct" in stages:
+        sp = b.cheaptrick(xcat, dt(t_o), dt(f0r_o)); torch.cuda.synchronize()
+        print("CheapTrick"); rep("sp", sp.cpu(), sp_o)
+        rel = np.abs(sp.cpu().numpy() - sp_o) / sp_o
+        print("   max rel", rel.max())
+    if "d4c" in stages:
+        ap = b.d4c(xcat, dt(t_o), dt(f0r_o)); torch.cuda.synchronize()
+        print("D4C"); rep("ap", ap.cpu(), ap_o)
+    if "syn" in stages:
+        y = b.synthesize(dt(f0r_o), dt(sp_o), dt(ap_o)); torch.cuda.synchronize()
+        print("Synthesis"); rep("y", y.cpu(), y_o)
+    if "all" in stages or len(stages) == 5:
+        t0 = time.time()
+        t, f0, sp, ap = b.analyze(xcat); y = b.synthesize(f0, sp, ap); torch.cuda.synchronize()
+        print("Pipeline (%.1f ms)" % ((time.time() - t0) * 1e3)); rep("f0", f0.cpu(), f0r_o); rep("sp", sp.cpu(), sp_o); rep("ap", ap.cpu(), ap_o); rep("y", y.cpu(), y_o)
+        for _ in range(2):
+            torch.cuda.synchronize(); t0 = time.time()
+            t, f0, sp, ap = b.analyze(xcat); y = b.synthesize(f0, sp, ap); torch.cuda.synchronize()
+            print("   again: %.2f ms for %d frames" % ((time.time() - t0) * 1e3, b.total_frames))
+
+if __name__ == "__main__":
+    main()
