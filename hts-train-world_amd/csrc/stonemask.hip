@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const int hw = (int)(1.5 * fs / f + 1.0);                      // :189
     const int L = 2 * hw + 1;
     const double wlen = (2.0 * hw + 1.0) / fs;                     // :190
-    const int fftn = (int)pow(2.0, 2.0 + (int)(log(hw * 2.0 + 1.0) / kLog2));   // :194-195
+    // :194-195; a power of two by shift (device pow() is not guaranteed exact for 2^n)
+    const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
     __syncthreads();
     for (int i = lane; i < L; i += 64) {
       const double bt = (double)(-hw + i) / fs;

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(64) void synth_timebase_kernel(
     const double* __restrict__ f0, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
     int fs, double fp, double lowest_f0, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
     double* __restrict__ vuv_out, int* __restrict__ pulse_cnt) {
+  // The pulse positions of unvoiced stretches sit exactly on phase-wrap ties (500 Hz * 32
+  // samples = one period), so the accumulated phase has to match the reference bit for bit:
+  // no FMA contraction anywhere in this kernel.
+#pragma clang fp contract(off)
   const int u = blockIdx.x, lane = threadIdx.x;
   const double* f0u = f0 + f_off[u];
   const int nf = (int)(f_off[u + 1] - f_off[u]);
