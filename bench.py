@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- WORLD analysis+synthesis frames/sec on MI355X (BASELINE.json's metric).
+
+One "step" = one pass of the hot path over one batch of synthetic 16 kHz utterances that is
+already resident in HBM: Dio -> StoneMask -> CheapTrick -> D4C (analysis) then Synthesis from the
+features just produced, every utterance of the batch, fp64 as the reference computes.  Workload at
+N=1 is BASELINE.json configs[1]: 256 synthetic utterances of 2-8 s.  With --gpus N every rank owns
+its own 256 utterances (weak scaling, no data-path collective); `--gather` adds the RCCL gather-v
+of the float32 feature files to rank 0 inside the step.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- dominant kernel (d4c_kernel): algorithmic bytes per launch / HIP-event duration
+                  measured on the launch stream, against the 8 TB/s HBM peak; the FP64 figures that
+                  actually bound the path are reported beside it.
+  cpu_baseline -- the reference WORLD (oracle/_ref, kind "reference") or this repo's C restatement
+                  (kind "port") timed single-threaded on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector peak
+# Algorithmic bytes per frame, fp64 C-API layout, 16 kHz / 5 ms / fft 1024:
+#   analysis  : 80 samples*8 + t 8 + f0 8 + sp 513*8 + ap 513*8 = 8864
+#   synthesis : f0 8 + sp 4104 + ap 4104 + 80*8                 = 8856
+BYTES_PER_FRAME = 8864 + 8856
+FLOPS_PER_FRAME = 0.7e6
+# d4c_kernel alone: reads its 80 new samples + t + f0 + ap0 (664 B), writes one ap row (4104 B)
+D4C_BYTES_PER_FRAME = 80 * 8 + 8 + 8 + 8 + 513 * 8
+D4C_FLOPS_PER_VOICED_FRAME = 6 * 2.5 * 2048 * 11   # 6 real FFTs of 2048 (+ scans etc., not counted)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--dur", type=float, nargs=2, default=(2.0, 8.0))
+    ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = importlib.import_module("hts-train-world_amd")
+    W, sd, sh = pkg.world, pkg.synth_data, pkg.sharding
+    fs, fp = 16000, 5.0
+
+    # ---- synthetic workload (not timed) ----
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(16, ncpu // max(1, world)))
+    xs = sd.make_batch(args.utts, fs, tuple(args.dur), first=rank * args.utts, workers=workers)
+    lens = [len(x) for x in xs]
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+    batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=lens)
+    frames = int(batch.total_frames)
+    outs = (torch.empty(frames, dtype=torch.float64, device="cuda"), torch.empty(frames, dtype=torch.float64, device="cuda"),
+            torch.empty(frames, batch.bins, dtype=torch.float64, device="cuda"),
+            torch.empty(frames, batch.bins, dtype=torch.float64, device="cuda"))
+    y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
+    frame_counts = np.diff(batch.frame_offsets).tolist()
+
+    def step():
+        t, f0, sp, ap = batch.analyze(x, out=outs)
+        batch.synthesize(f0, sp, ap, out=y)
+        if args.gather and world > 1:
+            # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
+            sh.gather_features([f0.float(), sp.float(), ap.float()], frame_counts, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = {}
+    for k in ("dio_lowcut_kernel", "dio_band_kernel", "dio_candidate_kernel", "dio_fix_kernel", "stonemask_kernel",
+              "cheaptrick_kernel", "d4c_lovetrain_kernel", "d4c_kernel", "synth_timebase_kernel",
+              "synth_pulse_kernel", "synth_ola_kernel"):
+        ms, n = ctx.timing_query(k)
+        kernel_ms[k] = (ms, n)
+    ctx.timing_enable(False)
+
+    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, total_frames = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, total_frames = elapsed, float(frames)
+
+    if rank == 0:
+        value = total_frames * args.steps / elapsed_max
+        d4c_ms, d4c_n = kernel_ms["d4c_kernel"]
+        d4c_avg_s = d4c_ms / max(1, d4c_n) * 1e-3
+        voiced = int((outs[1] > 0).sum().item())
+        roof = {
+            "bound": "hbm", "kernel": "d4c_kernel",
+            "achieved": round(frames * D4C_BYTES_PER_FRAME / d4c_avg_s / 1e9, 3) if d4c_avg_s > 0 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(frames * D4C_BYTES_PER_FRAME / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if d4c_avg_s > 0 else None,
+            "traffic": None,
+            "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": frames,
+            "bytes_per_unit": D4C_BYTES_PER_FRAME,
+            "note": "FP64-FFT/LDS bound, not HBM bound (SURVEY.md 8d); fp64 figures beside it",
+            "fp64": {"achieved_tflops": round(voiced * D4C_FLOPS_PER_VOICED_FRAME / d4c_avg_s / 1e12, 3) if d4c_avg_s > 0 else None,
+                     "peak_tflops": FP64_PEAK_TFLOPS,
+                     "frac": round(voiced * D4C_FLOPS_PER_VOICED_FRAME / d4c_avg_s / 1e12 / FP64_PEAK_TFLOPS, 5) if d4c_avg_s > 0 else None},
+            "pipeline": {"achieved_gbs": round(value / world * BYTES_PER_FRAME / 1e9, 3),
+                         "frac_hbm": round(value / world * BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS, 6),
+                         "achieved_fp64_tflops": round(value / world * FLOPS_PER_FRAME / 1e12, 4)},
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_ms.items()},
+        }
+        cpu = None
+        parity = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, parity = cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, args.cpu_utts)
+        line = {
+            "metric": "WORLD analysis+synthesis frames/sec @16kHz, 5ms hop",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: batch of %d synthetic 16 kHz utterances (%g-%g s) per GPU, "
+                                   "Dio+StoneMask+CheapTrick+D4C then Synthesis, fp64, features resident in HBM"
+                                   % (args.utts, args.dur[0], args.dur[1]),
+                       "fs": fs, "frame_period_ms": fp, "fft_size": batch.fft_size,
+                       "utterances_per_gpu": args.utts, "frames_per_gpu": frames,
+                       "parallelism": "utterance-sharded x%d%s" % (world, "+gather" if args.gather else "")},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if parity:
+            line["parity"] = parity
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, n_cpu):
+    """Time the CPU path single-threaded on the first n_cpu utterances of the same workload and
+    check the GPU results of those utterances against it (the checker, never the thing shipped)."""
+    from oracle.bindings import Oracle, Reference
+    lib = Reference() if Reference.available() else Oracle()
+    F = batch.fft_size
+    n_cpu = min(n_cpu, len(xs))
+    t_f0, t_sp, t_ap, t_y = outs[1].cpu().numpy(), outs[2].cpu().numpy(), outs[3].cpu().numpy(), y.cpu().numpy()
+    fo, yo = batch.frame_offsets, batch.out_offsets
+    frames = 0
+    df0 = 0.0
+    se_sp = se_ap = 0.0
+    cnt = 0
+    dy = 0.0
+    t0 = time.perf_counter()
+    cpu_time = 0.0
+    for u in range(n_cpu):
+        x = xs[u]
+        a = time.perf_counter()
+        t, f0 = lib.dio(x, fs, fp)
+        f0 = lib.stonemask(x, fs, t, f0)
+        sp = lib.cheaptrick(x, fs, t, f0, -0.15, F)
+        ap = lib.d4c(x, fs, t, f0, F, 0.0)
+        yy = lib.synthesis(f0, sp, ap, F, fp, fs)
+        cpu_time += time.perf_counter() - a
+        frames += len(f0)
+        g = slice(fo[u], fo[u + 1])
+        df0 = max(df0, float(np.abs(t_f0[g] - f0).max()))
+        se_sp += float(((t_sp[g] - sp) ** 2).sum())
+        se_ap += float(((t_ap[g] - ap) ** 2).sum())
+        cnt += sp.size
+        dy = max(dy, float(np.abs(t_y[yo[u]:yo[u + 1]] - yy).max()))
+        if time.perf_counter() - t0 > 40.0:
+            n_cpu = u + 1
+            break
+    cpu = {"value": round(frames / cpu_time, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
+           "sample": "first %d utterances of the same batch (%d frames), Dio+StoneMask+CheapTrick+D4C+Synthesis, "
+                     "single thread, %.1f s" % (n_cpu, frames, cpu_time)}
+    parity = {"vs": lib.kind, "utterances": n_cpu, "max_abs_dF0_hz": df0, "sp_rmse": (se_sp / cnt) ** 0.5,
+              "ap_rmse": (se_ap / cnt) ** 0.5, "max_abs_dy": dy}
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/world_mi355.h"
@@ -29,6 +32,25 @@ struct Context {
   int64_t scratch_cap = 0;           // in doubles
   int ensure_rng(int64_t count);     // grow + (re)generate, returns error code
   int ensure_scratch(int64_t doubles);
+  // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
+  bool timing = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> timed;
+  void timing_clear();
+};
+
+// RAII bracket: records a start/stop event pair around the launches in its scope.
+struct TimedScope {
+  Context* c;
+  hipEvent_t a = nullptr, b = nullptr;
+  TimedScope(Context* ctx, const char* name) : c(ctx) {
+    if (!c->timing) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, c->stream);
+    c->timed[name].push_back(std::make_pair(a, b));
+  }
+  ~TimedScope() {
+    if (b) (void)hipEventRecord(b, c->stream);
+  }
 };
 
 struct Batch {

@@ -99,6 +99,7 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (!h) return;
   Context& c = h->c;
   hipStreamSynchronize(c.stream);
+  c.timing_clear();
   if (c.d_rng) hipFree(c.d_rng);
   if (c.d_scratch) hipFree(c.d_scratch);
   if (c.own_stream) hipStreamDestroy(c.stream);
@@ -218,6 +219,27 @@ int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f
   rc = rc ? rc : launch_cheaptrick(b, x, t, f0, sp);
   rc = rc ? rc : launch_d4c(b, x, t, f0, ap);
   return rc;
+}
+int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
+  Context& c = h->c;
+  int rc = wm_check(hipStreamSynchronize(c.stream));
+  c.timing_clear();
+  c.timing = on != 0;
+  return rc;
+}
+int WorldMi355TimingQuery(WorldMi355Context* h, const char* kernel, double* total_ms, int* launches) {
+  Context& c = h->c;
+  int rc = wm_check(hipStreamSynchronize(c.stream));
+  if (rc) return rc;
+  *total_ms = 0.0;
+  *launches = 0;
+  auto it = c.timed.find(kernel);
+  if (it == c.timed.end()) return WM_OK;
+  for (auto& pr : it->second) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { *total_ms += ms; *launches += 1; }
+  }
+  return WM_OK;
 }
 int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
                        double* im, double* x_back) {

@@ -162,11 +162,14 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
     hipLaunchKernelGGL(cheaptrick_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,    \
                        b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng, b.p.fs, b.p.q1, tf, d_sp);  \
     break;
+  {
+  TimedScope ts_(b.ctx, "cheaptrick_kernel");
   switch (F) {
     WM_CT_CASE(1024)
     WM_CT_CASE(2048)
     default:
       return WM_ERR_UNSUPPORTED_FFT;
+  }
   }
 #undef WM_CT_CASE
   return wm_check(hipGetLastError());

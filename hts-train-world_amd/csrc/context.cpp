@@ -67,6 +67,12 @@ int Context::ensure_scratch(int64_t doubles) {
   return WM_OK;
 }
 
+void Context::timing_clear() {
+  for (auto& kv : timed)
+    for (auto& pr : kv.second) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  timed.clear();
+}
+
 int64_t Batch::rng_bound_cheaptrick() const {
   // per frame: window 2*hw+1 <= fft_size+1 (hw < (fft_size-3)/2 by the f0 floor) + fft_size/2+1
   return (int64_t)max_f0_len * (p.fft_size + 1 + p.fft_size / 2 + 1) + 64;

@@ -399,10 +399,13 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,   \
                        b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, b.d_ap0);                  \
     break;
-  switch (FL) {
-    WM_LT_CASE(1024)
-    WM_LT_CASE(2048)
-    WM_LT_CASE(4096)
+  {
+    TimedScope ts_(b.ctx, "d4c_lovetrain_kernel");
+    switch (FL) {
+      WM_LT_CASE(1024)
+      WM_LT_CASE(2048)
+      WM_LT_CASE(4096)
+    }
   }
 #undef WM_LT_CASE
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
@@ -413,10 +416,13 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
                        b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs,        \
                        b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap);                                   \
     break;
-  switch (FD) {
-    WM_D4C_CASE(1024)
-    WM_D4C_CASE(2048)
-    WM_D4C_CASE(4096)
+  {
+    TimedScope ts_(b.ctx, "d4c_kernel");
+    switch (FD) {
+      WM_D4C_CASE(1024)
+      WM_D4C_CASE(2048)
+      WM_D4C_CASE(4096)
+    }
   }
 #undef WM_D4C_CASE
   return wm_check(hipGetLastError());

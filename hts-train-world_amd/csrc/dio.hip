@@ -473,6 +473,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     const int total_max = b.max_x_len + 1 + 2 * m.pad;
     const int tiles = (total_max + kLcTile - 1) / kLcTile;
     const size_t lds = sizeof(double) * (size_t)(kLcTile + 2 * m.cut + 2 * m.cut + 1);
+    TimedScope ts_(b.ctx, "dio_lowcut_kernel");
     hipLaunchKernelGGL(dio_lowcut_kernel, dim3(tiles, b.n_utt), dim3(256), lds, st, d_x, b.d_x_off, b.d_x_len,
                        b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
   }
@@ -481,17 +482,22 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     const int zspan = kBandTile + ntap_max;
     const int stride = (zspan + kBandK - 1) / kBandK + 1;
     const size_t lds = sizeof(double) * (size_t)(kBandK * stride + ntap_max + kBandTile);
+    TimedScope ts_(b.ctx, "dio_band_kernel");
     hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_x_len, b.d_dio_z_off,
                        b.d_dio_z, b.d_dio_win, m, b.d_dio_ev_off, b.d_dio_events, b.d_dio_ev_cnt);
   }
   {
     const int gx = (int)((b.total_f + 255) / 256);
+    TimedScope ts_(b.ctx, "dio_candidate_kernel");
     hipLaunchKernelGGL(dio_candidate_kernel, dim3(gx, m.nb), dim3(256), 0, st, b.d_x_len, b.d_f_off,
                        b.d_frame_utt, b.p.frame_period, m, b.p.f0_floor, b.p.f0_ceil, b.d_dio_ev_off, b.d_dio_events,
                        b.d_dio_ev_cnt, b.total_f, b.d_dio_cand, b.d_dio_score);
   }
+  {
+  TimedScope ts_(b.ctx, "dio_fix_kernel");
   hipLaunchKernelGGL(dio_fix_kernel, dim3(b.n_utt), dim3(256), 0, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,
                      m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f, b.d_dio_ws, d_t, d_f0);
+  }
   return wm_check(hipGetLastError());
 }
 

@@ -129,6 +129,7 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   const int64_t tf = b.total_f;
   const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   if (grid <= 0) return WM_OK;
+  TimedScope ts_(b.ctx, "stonemask_kernel");
   hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
                      b.d_frame_utt, d_t, d_f0, fs, tf, d_out);
   return wm_check(hipGetLastError());

@@ -387,8 +387,11 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   const double lowest_f0 = fs / F + 1.0;                  // integer division as in synthesis.cpp:359
   rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
   if (rc) return rc;
+  {
+  TimedScope ts_(b.ctx, "synth_timebase_kernel");
   hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, d_f0, b.d_f_off, b.d_y_off, fs, fp,
                      lowest_f0, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_pulse_cnt);
+  }
   rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
                                hipMemcpyDeviceToHost, st));
   if (rc) return rc;
@@ -420,11 +423,15 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
                        b.d_y_off, b.d_pulse_off, b.n_utt, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,              \
                        b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);                                   \
     break;
-    switch (F) {
-      WM_SY_CASE(1024)
-      WM_SY_CASE(2048)
+    {
+      TimedScope ts_(b.ctx, "synth_pulse_kernel");
+      switch (F) {
+        WM_SY_CASE(1024)
+        WM_SY_CASE(2048)
+      }
     }
 #undef WM_SY_CASE
+    TimedScope ts2_(b.ctx, "synth_ola_kernel");
     hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(256), 0, st, b.d_y_off, b.d_pulse_off,
                        b.d_pulse_idx, F, p0, p1, c.d_scratch, d_y);
   }

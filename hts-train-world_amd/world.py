@@ -74,6 +74,8 @@ def load_library():
     L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
     L.WorldMi355TestRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.WorldMi355TimingEnable.argtypes = [vp, C.c_int]
+    L.WorldMi355TimingQuery.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -105,6 +107,17 @@ class Context:
 
     def synchronize(self):
         _check(load_library().WorldMi355Synchronize(self.handle), "Synchronize")
+
+    def timing_enable(self, on: bool = True):
+        """Record HIP events on the context's stream around every kernel launch."""
+        _check(load_library().WorldMi355TimingEnable(self.handle, 1 if on else 0), "TimingEnable")
+
+    def timing_query(self, kernel: str):
+        """(total milliseconds, launches) of `kernel` since timing_enable(); synchronises."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        _check(load_library().WorldMi355TimingQuery(self.handle, kernel.encode(), C.byref(ms), C.byref(n)),
+               "TimingQuery")
+        return ms.value, n.value
 
     def close(self):
         if self.handle:

@@ -101,6 +101,14 @@ int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0
 int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
                       double* ap);
 
+/* Per-kernel timing with HIP events recorded on the context's stream around each launch of the
+ * named kernels ("dio_lowcut_kernel", "dio_band_kernel", "stonemask_kernel", "cheaptrick_kernel",
+ * "d4c_lovetrain_kernel", "d4c_kernel", "synth_timebase_kernel", "synth_pulse_kernel",
+ * "synth_ola_kernel").  Enable clears earlier records; Query synchronises the stream and returns
+ * the summed duration and the number of launches since Enable. */
+int WorldMi355TimingEnable(WorldMi355Context* ctx, int on);
+int WorldMi355TimingQuery(WorldMi355Context* ctx, const char* kernel, double* total_ms, int* launches);
+
 /* Test hook: forward/backward real FFT of `count` rows of length n (512..4096) through the
  * in-kernel wavefront FFT; layouts as fft.cpp:26-72 (re/im split, n/2+1 bins). */
 int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
