@@ -83,14 +83,10 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) c.num_cu = prop.multiProcessorCount;
   c.frame_grid = c.num_cu * 16;
-  if (hip_stream) {
-    c.stream = (hipStream_t)hip_stream;
-    c.own_stream = false;
-  } else {
-    int rc = wm_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    if (rc) { delete h; return rc; }
-    c.own_stream = true;
-  }
+  // NULL selects the legacy default stream (stream 0): it orders with every blocking stream, which
+  // is what callers that allocate and copy with plain hipMemcpy / torch's default stream expect.
+  c.stream = (hipStream_t)hip_stream;
+  c.own_stream = false;
   *out = h;
   return WM_OK;
 }

@@ -59,7 +59,7 @@ typedef struct {
  * floor 71, ceil 800, 2 ch/oct, speed 1, range 0.1, q1 -0.15, threshold 0 (NOT 0.85). */
 void WorldMi355DefaultParams(int fs, double frame_period, WorldMi355Params* p);
 
-/* device < 0: current device.  stream == NULL: the context creates its own. */
+/* device < 0: current device.  stream == NULL: the legacy default stream (stream 0). */
 int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** out);
 void WorldMi355DestroyContext(WorldMi355Context* ctx);
 int WorldMi355SetStream(WorldMi355Context* ctx, void* hip_stream);

@@ -146,7 +146,7 @@ class Oracle:
 
     def decimate(self, x, r):
         x = _c(x)
-        y = np.zeros((len(x) - 1) // r + 1 + 2)
+        y = np.zeros((len(x) - 1) // r + 1 + 32)
         self.lib.orc_decimate(_p(x), len(x), r, _p(y))
         return y[: (len(x) - 1) // r + 1]
 
@@ -351,7 +351,7 @@ class Reference(WorldCApi):
 
     def decimate(self, x, r):
         x = _c(x)
-        y = np.zeros((len(x) - 1) // r + 1 + 2)
+        y = np.zeros((len(x) - 1) // r + 1 + 32)
         self.lib.decimate(_p(x), len(x), r, _p(y))
         return y[: (len(x) - 1) // r + 1]
 
