@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--dur", type=float, nargs=2, default=(2.0, 8.0))
     ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the CPU baseline sample")
+    ap.add_argument("--cpu-utts", type=int, default=48, help="utterances of the CPU baseline sample")
+    ap.add_argument("--workers", type=int, default=0, help="processes for synthetic data generation (0 = auto)")
     return ap.parse_args()
 
 
@@ -74,7 +75,7 @@ def main():
 
     # ---- synthetic workload (not timed) ----
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(16, ncpu // max(1, world)))
+    workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
     xs = sd.make_batch(args.utts, fs, tuple(args.dur), first=rank * args.utts, workers=workers)
     lens = [len(x) for x in xs]
     x = torch.from_numpy(np.concatenate(xs)).cuda()
