@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
 }
 
 template <int F>
-__global__ __launch_bounds__(64) void cheaptrick_kernel(
+__global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, double q1,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void cheaptrick_kernel(
   constexpr int kWork = kImg > kSeg ? kImg : kSeg;
   __shared__ __attribute__((aligned(16))) double smem[(H + 2) + kWork];
   double* pw = smem;                                           // [H+1] power / log spectrum
-  double* work = smem + (H + 2);                               // FFT image | spectrum | scan scratch
+  double* work = smem + (H + 2);                               // frame | FFT image | spectrum | scan scratch
   cpx* img = reinterpret_cast<cpx*>(work);
 
   const int lane = threadIdx.x;
@@ -74,44 +74,28 @@ __global__ __launch_bounds__(64) void cheaptrick_kernel(
 
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
     const int u = frame_utt[frame];
-    const double* xu = x + x_off[u];
-    const int xl = x_len[u];
     const double f0v = f0[frame];
     const double cf0 = f0v <= f0_floor ? kDefaultF0 : f0v;     // cheaptrick.cpp:217
-    const double pos = tpos[frame];
     const int roff = rng_off[frame];
+    cpx v[M];
 
     // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) ----
-    cpx v[M];
-    const FrameWindow fw = windowed_waveform<M, kHann, true>(xu, xl, fs, cf0, pos, 3.0, rtab, roff, lane, v);
-    const int L = fw.L;
+    const FrameWindow fw = windowed_waveform_lds<kHann, true>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0,
+                                                              rtab, roff, lane, work, F);
+    load_packed<N>(work, lane, v);
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
     rfft_forward<N>(v, img, img, tw, lane);
-    {
-      double p[M + 1];
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        cpx s = img[lane + 64 * m];
-        p[m] = s.x * s.x + s.y * s.y;
-      }
-      cpx sn = img[N];
-      p[M] = sn.x * sn.x + sn.y * sn.y;
-#pragma unroll
-      for (int m = 0; m < M; ++m) pw[lane + 64 * m] = p[m];
-      if (lane == 0) pw[N] = p[M];
+    for (int k = lane; k <= H; k += 64) {
+      const cpx s = img[k];
+      pw[k] = s.x * s.x + s.y * s.y;
     }
     __syncthreads();
     dc_correction_lds(pw, cf0, fs, F, work, lane);
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
-    double sm[M + 1];
-    linear_smoothing_lds<M + 1>(pw, cf0 * 2.0 / 3.0, fs, F, work, sm, lane);
-#pragma unroll
-    for (int m = 0; m <= M; ++m) {
-      const int i = lane + 64 * m;
-      if (i <= H) pw[i] = log(sm[m] + fabs(randn_at(rtab, roff + L + i)) * kEps);
-    }
+    linear_smoothing_lds(pw, cf0 * 2.0 / 3.0, fs, F, work, pw, lane);
+    for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fw.L + i)) * kEps);
     __syncthreads();
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
@@ -121,28 +105,29 @@ __global__ __launch_bounds__(64) void cheaptrick_kernel(
       v[m] = make_double2(pw[i0 <= H ? i0 : F - i0], pw[i1 <= H ? i1 : F - i1]);
     }
     rfft_forward<N>(v, img, img, tw, lane);
-#pragma unroll
-    for (int m = 0; m <= M; ++m) {
-      const int i = lane + 64 * m;
-      if (i <= H) {
+    {
+      // lifters at quefrency i/fs: sin(pi f0 q)/(pi f0 q) and (1-2q1) + 2 q1 cos(2 pi f0 q);
+      // angle pi*f0*i/fs advances by a rotation per 64 bins; cos(2a) = 1 - 2 sin^2(a)
+      CosGen g;
+      g.init(cf0 / fs, lane, 64);
+      for (int i = lane; i <= H; i += 64) {
         double sl = 1.0, cl = (1.0 - 2.0 * q1) + 2.0 * q1;
         if (i > 0) {
-          double quef = (double)i / fs;
-          sl = sin(kPi * cf0 * quef) / (kPi * cf0 * quef);
-          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * kPi * quef * cf0);
+          const double quef = (double)i / fs;
+          sl = g.s / (kPi * cf0 * quef);
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * g.s * g.s);
         }
         img[i] = make_double2(img[i].x * sl * cl / F, 0.0);
+        g.next();
       }
     }
     rfft_backward<N>(img, v, img, tw, lane);
-    double* row = sp + frame * (int64_t)(H + 1);
+    __syncthreads();
 #pragma unroll
-    for (int m = 0; m < M / 2; ++m) {
-      const int n = lane + 64 * m;
-      row[2 * n] = exp(v[m].x);
-      row[2 * n + 1] = exp(v[m].y);
-    }
-    if (lane == 0) row[H] = exp(v[M / 2].x);
+    for (int m = 0; m < M; ++m) img[lane + 64 * m] = v[m];       // x[2n], x[2n+1] -> work[0..F)
+    __syncthreads();
+    double* row = sp + frame * (int64_t)(H + 1);
+    for (int i = lane; i <= H; i += 64) row[i] = exp(work[i]);
     __syncthreads();
   }
 }

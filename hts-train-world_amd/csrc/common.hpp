@@ -92,13 +92,12 @@ __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs,
   __syncthreads();
 }
 
-// LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[m] registers for
-// bins lane + 64 m, m < MB.  seg is an LDS scratch of >= half + 2*b + 1 doubles
-// (b = int(width*fft_size/fs)+1).  The cumulative sum is blocked per lane and
-// stitched by a wave scan (the reference's is sequential, common.cpp:38-41).
-template <int MB>
+// LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[0..half] (LDS; may alias in).
+// seg is an LDS scratch of >= half + 2*b + 1 doubles (b = int(width*fft_size/fs)+1).  The
+// cumulative sum is blocked per lane and stitched by a wave scan (the reference's is sequential,
+// common.cpp:38-41).  Ends with a barrier.
 __device__ __forceinline__ void linear_smoothing_lds(const double* in, double width, int fs, int fft_size,
-                                                     double* seg, double (&out)[MB], int lane) {
+                                                     double* seg, double* out, int lane) {
   const int half = fft_size / 2;
   const int b = (int)(width * fft_size / fs) + 1;
   const int len = half + 2 * b + 1;
@@ -111,23 +110,18 @@ __device__ __forceinline__ void linear_smoothing_lds(const double* in, double wi
     run += in[src] * fs / fft_size;
     seg[i] = run;
   }
-  double incl = wave_scan_incl(run, lane);
-  double carry = incl - run;
-  __syncthreads();
-  for (int i = beg; i < end; ++i) seg[i] += carry;
+  const double incl = wave_scan_incl(run, lane);
+  const double carry = incl - run;
+  for (int i = beg; i < end; ++i) seg[i] += carry;        // own chunk: no barrier needed before
   __syncthreads();
   const double origin = -(b - 0.5) * fs / fft_size;
   const double step = (double)fs / fft_size;
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    int i = lane + 64 * m;
-    out[m] = 0.0;
-    if (i <= half) {
-      double lo_x = (double)i / fft_size * fs - width / 2.0;
-      double lo = interp1q_lds(origin, step, seg, len, lo_x);
-      double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
-      out[m] = (hi - lo) / width;
-    }
+#pragma unroll 2
+  for (int i = lane; i <= half; i += 64) {
+    const double lo_x = (double)i / fft_size * fs - width / 2.0;
+    const double lo = interp1q_lds(origin, step, seg, len, lo_x);
+    const double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
+    out[i] = (hi - lo) / width;
   }
   __syncthreads();
 }

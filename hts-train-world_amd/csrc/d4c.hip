@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void d4c_offsets_kernel(const double* __restri
 // D4CLoveTrainSub (d4c.cpp:225-250): aperiodicity0 = cum[boundary1] / cum[boundary2]
 // over the power spectrum with bins <= boundary0 zeroed.
 template <int FL>
-__global__ __launch_bounds__(64) void d4c_lovetrain_kernel(
+__global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, int64_t total_frames,
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(64) void d4c_lovetrain_kernel(
     const int u = frame_utt[frame];
     const double cf0 = f0v > 40.0 ? f0v : 40.0;
     cpx v[M];
-    windowed_waveform<M, kBlackman, false>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0, rtab,
-                                            rng_off[frame], lane, v);
+    windowed_waveform_lds<kBlackman, false>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0, rtab,
+                                            rng_off[frame], lane, smem, FL);
+    load_packed<N>(smem, lane, v);
     rfft_forward<N>(v, img, img, tw, lane);
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -129,7 +130,7 @@ struct D4CTables {
 
 // FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
 template <int FD>
-__global__ __launch_bounds__(64) void d4c_kernel(
+__global__ __launch_bounds__(64, 2) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
@@ -176,11 +177,12 @@ __global__ __launch_bounds__(64) void d4c_kernel(
       const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
       const int ro = roff + side * Lw;
       cpx v[M];
-      const FrameWindow fw = windowed_waveform<M, kBlackman, false>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane, v);
+      const FrameWindow fw = windowed_waveform_lds<kBlackman, false>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
+                                                                     smem, FD);
       double pwr = 0.0;                                   // d4c.cpp:96-100
-#pragma unroll
-      for (int m = 0; m < M; ++m) pwr += v[m].x * v[m].x + v[m].y * v[m].y;
+      for (int i = lane; i < fw.L; i += 64) pwr += smem[i] * smem[i];
       const double nrm = sqrt(wave_sum(pwr));
+      load_packed<N>(smem, lane, v);
 #pragma unroll
       for (int m = 0; m < M; ++m) { v[m].x /= nrm; v[m].y /= nrm; }
       rfft_forward<N>(v, img, img, tw, lane);
@@ -189,13 +191,9 @@ __global__ __launch_bounds__(64) void d4c_kernel(
       for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
       s1[M] = img[N];
       // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
-      rebuild_waveform<M, kBlackman>(xu, xl, fw, rtab, ro, lane, v);
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const int i0 = 2 * (lane + 64 * m);
-        v[m].x = v[m].x / nrm * (i0 + 1.0);
-        v[m].y = v[m].y / nrm * (i0 + 2.0);
-      }
+      __syncthreads();
+      rebuild_ramped_lds<kBlackman>(xu, xl, fw, rtab, ro, nrm, lane, smem, FD);
+      load_packed<N>(smem, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -222,7 +220,8 @@ __global__ __launch_bounds__(64) void d4c_kernel(
     double gd[MB];
     {
       cpx v[M];
-      windowed_waveform<M, kHann, false>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, v);
+      windowed_waveform_lds<kHann, false>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
+      load_packed<N>(smem, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
 #pragma unroll
@@ -239,26 +238,24 @@ __global__ __launch_bounds__(64) void d4c_kernel(
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
       if (lane == 0) arr[N] = p[M];
       __syncthreads();
-      dc_correction_lds(arr, cf0, fs, FD, seg, lane);
-      double sp[MB];
-      linear_smoothing_lds<MB>(arr, cf0, fs, FD, seg, sp, lane);
-      // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
-#pragma unroll
-      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / sp[m];
-      if (lane == 0) arr[N] = sc[M] / sp[M];
-      __syncthreads();
     }
-    linear_smoothing_lds<MB>(arr, cf0 / 2.0, fs, FD, seg, gd, lane);
+    dc_correction_lds(arr, cf0, fs, FD, seg, lane);
+    linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
-    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
-    if (lane == 0) arr[N] = gd[M];
+    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
+    if (lane == 0) arr[N] = sc[M] / arr[N];
     __syncthreads();
-    {
-      double sg[MB];
-      linear_smoothing_lds<MB>(arr, cf0, fs, FD, seg, sg, lane);
+    linear_smoothing_lds(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
 #pragma unroll
-      for (int m = 0; m < MB; ++m) gd[m] -= sg[m];
-    }
+    for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
+    gd[M] = arr[N];
+    __syncthreads();
+    linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+#pragma unroll
+    for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
+    gd[M] -= arr[N];
+    __syncthreads();
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
     const int wl = tab.window_length;

@@ -104,14 +104,21 @@ template <> struct Dft<16> {
   }
 };
 
-// multiply a[r] by w^r, r = 1..R-1, powers built by a shallow product tree
+// multiply a[r] by w^r, r = 1..R-1.  Two interleaved chains stepping by w^2 keep only three
+// complex values live (register pressure matters more here than the ~R/2 ulp of chain error).
 template <int R> __device__ __forceinline__ void apply_twiddle_powers(cpx (&a)[R], cpx w) {
-  cpx p[R];
-  p[1] = w;
+  const cpx w2 = cmul(w, w);
+  cpx odd = w, even = w2;
+  a[1] = cmul(a[1], odd);
 #pragma unroll
-  for (int r = 2; r < R; ++r) p[r] = (r & 1) ? cmul(p[r - 1], w) : cmul(p[r / 2], p[r / 2]);
-#pragma unroll
-  for (int r = 1; r < R; ++r) a[r] = cmul(a[r], p[r]);
+  for (int r = 2; r < R; r += 2) {
+    a[r] = cmul(a[r], even);
+    if (r + 1 < R) {
+      odd = cmul(odd, w2);
+      a[r + 1] = cmul(a[r + 1], odd);
+    }
+    if (r + 2 < R) even = cmul(even, w2);
+  }
 }
 
 template <int N> struct FftCfg;
@@ -165,6 +172,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     const int j = lane + 64 * b;
 #pragma unroll
     for (int r = 0; r < R1; ++r) lds[fft_pad<N>(j * R1 + r)] = a[r];
+    __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: bounds the live registers
   }
   __syncthreads();
 #pragma unroll
@@ -182,6 +190,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     const int base = (j / R1) * (R1 * R2) + (j % R1);
 #pragma unroll
     for (int r = 0; r < R2; ++r) lds[fft_pad<N>(base + r * R1)] = a[r];
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
 #pragma unroll
@@ -196,6 +205,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     Dft<R3>::run(a);
 #pragma unroll
     for (int r = 0; r < R3; ++r) v[b + r * S3] = a[r];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
