@@ -48,3 +48,12 @@ def test_analysis_synthesis_vs_reference_vectors(oracle, name):
     y = oracle.synthesis(g["f0"], sp, ap, F, fp, fs)
     np.testing.assert_allclose(y[::ss], g["y_sub"], atol=1e-9, rtol=0)
     np.testing.assert_allclose(checks(y), g["y_check"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["harvest_16k", "harvest_48k_1ms"])
+def test_harvest_vs_reference_vectors(oracle, name):
+    g, x = load(name)
+    t, f0 = oracle.harvest(x, int(g["fs"]), float(g["frame_period"]))
+    np.testing.assert_array_equal(t, g["t"])
+    assert ((f0 > 0) == (g["f0"] > 0)).all()
+    np.testing.assert_allclose(f0, g["f0"], atol=1e-8, rtol=0)

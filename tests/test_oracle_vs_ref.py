@@ -62,3 +62,21 @@ def test_primitives(oracle, reference):
                                       reference.dc_correction(spec, f0, 16000, 2048))
         np.testing.assert_array_equal(oracle.linear_smoothing(spec, f0, 16000, 2048),
                                       reference.linear_smoothing(spec, f0, 16000, 2048))
+
+
+@pytest.mark.parametrize("index,fs,dur,fp", [(3, 16000, 1.5, 5.0), (4, 48000, 0.8, 1.0), (7, 22050, 1.2, 5.0),
+                                              (13, 44100, 0.7, 1.0), (14, 8000, 1.5, 5.0)])
+def test_harvest(oracle, reference, index, fs, dur, fp):
+    x = sd.make_utterance(index, fs, duration=dur)
+    tr, fr = reference.harvest(x, fs, fp)
+    to, fo = oracle.harvest(x, fs, fp)
+    np.testing.assert_array_equal(tr, to)
+    assert ((fr > 0) == (fo > 0)).all()
+    np.testing.assert_allclose(fo, fr, atol=1e-8, rtol=0)
+
+
+def test_harvest_options(oracle, reference):
+    x = sd.make_utterance(15, 16000, duration=1.0)
+    tr, fr = reference.harvest(x, 16000, 5.0, 50.0, 500.0)
+    to, fo = oracle.harvest(x, 16000, 5.0, 50.0, 500.0)
+    np.testing.assert_allclose(fo, fr, atol=1e-8, rtol=0)
