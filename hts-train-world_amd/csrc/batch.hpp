@@ -91,6 +91,7 @@ struct Batch {
   int* d_dio_ev_cnt = nullptr;       // [utt][band][4]
   double* d_dio_cand = nullptr;      // [band][total_f]
   double* d_dio_score = nullptr;     // [band][total_f]
+  void* harvest_ws = nullptr;        // HarvestWs (harvest.hip)
   // Synthesis workspace
   int* d_pulse_idx = nullptr;        // [total_y]
   double* d_pulse_shift = nullptr;   // [total_y]

@@ -19,6 +19,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "zcfilter.hpp"
 
 namespace wm {
 
@@ -95,11 +96,9 @@ __global__ __launch_bounds__(256) void dio_lowcut_kernel(
   }
 }
 
-// One workgroup per (utterance, band): Nuttall FIR over the low-cut signal, then the four
-// ZeroCrossingEngine passes (dio.cpp:357-435) as an ordered stream compaction.
+// One workgroup per (utterance, band): Nuttall FIR over the low-cut signal + the four
+// ZeroCrossingEngine passes (dio.cpp:296-435), see zcfilter.hpp.
 // events layout per (utt, band): 4 lists of `cap` fine edges.
-constexpr int kBandK = 8;                       // outputs per thread
-constexpr int kBandTile = 256 * kBandK;         // samples per tile
 __global__ __launch_bounds__(256) void dio_band_kernel(
     const int* __restrict__ x_len, const int64_t* __restrict__ z_off, const double* __restrict__ z,
     const double* __restrict__ win, DioMeta meta, const int64_t* __restrict__ ev_off,
@@ -107,127 +106,12 @@ __global__ __launch_bounds__(256) void dio_band_kernel(
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int u = blockIdx.y, band = blockIdx.x;
   const int ylen = x_len[u] + 1;
-  const int hal = meta.hal[band], ntap = 4 * hal;
+  const int hal = meta.hal[band];
   const int cap = ylen / 2 + 2;
-  // LDS: transposed z tile (element e at [(e % K) * stride + e / K]), window taps, filtered tile
-  const int zspan = kBandTile + ntap;                           // elements needed per tile
-  const int stride = (zspan + kBandK - 1) / kBandK + 1;
-  double* zt = lds;                                             // [K * stride]
-  double* w = zt + kBandK * stride;                             // [ntap]
-  double* s = w + ntap;                                         // [kBandTile] filtered samples
-  __shared__ int wave_cnt[4][4];                                // [type][wave]
-  __shared__ int run_cnt[4];
-  const double* zu = z + z_off[u] + meta.pad;                   // zu[m], m in [-pad, ylen+pad)
-  const double* wb = win + meta.win_off[band];
-  for (int j = threadIdx.x; j < ntap; j += 256) w[j] = wb[j];
-  if (threadIdx.x < 4) run_cnt[threadIdx.x] = 0;
-  double* ev = events + ev_off[u] + (int64_t)band * 4 * cap;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int step = kBandTile - 2;                               // tiles overlap by 2 (s[i+1], s[i+2] look-ahead)
-
-  for (int n0 = 0; n0 < ylen; n0 += step) {
-    __syncthreads();
-    // filtered[n] = sum_{k<ntap} w[k] z[n + 2 hal - k]  (dio.cpp:310-337); tile element e <-> z index
-    // zbase + e with zbase = n0 + 2 hal - (ntap - 1)
-    const int zbase = n0 + 2 * hal - (ntap - 1);
-    for (int e = threadIdx.x; e < zspan; e += 256) {
-      const int m = zbase + e;
-      const double val = (m >= -meta.pad && m < ylen + meta.pad) ? zu[m] : 0.0;
-      zt[(e % kBandK) * stride + e / kBandK] = val;
-    }
-    __syncthreads();
-    // thread t: outputs n0 + t*K + q, q < K; output q at tap k reads element e = t*K + q + (ntap-1) - k
-    {
-      double acc[kBandK];
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
-      const int t = threadIdx.x;
-      // sliding register window over elements t*K + c, c descending
-      double r[kBandK];                                          // r[q] = element for output q at current tap
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) {
-        const int e = t * kBandK + q + (ntap - 1);
-        r[q] = zt[(e % kBandK) * stride + e / kBandK];
-      }
-      for (int k = 0; k < ntap; ++k) {
-        const double wk = w[k];
-#pragma unroll
-        for (int q = 0; q < kBandK; ++q) acc[q] += wk * r[q];
-        // shift: next tap needs elements one lower; r[q] <- r[q-1], r[0] <- new element
-#pragma unroll
-        for (int q = kBandK - 1; q > 0; --q) r[q] = r[q - 1];
-        const int e = t * kBandK + (ntap - 1) - (k + 1);
-        r[0] = e >= 0 ? zt[(e % kBandK) * stride + e / kBandK] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
-    }
-    __syncthreads();
-    // ---- zero crossings over samples i in [n0, n0 + step) ----
-    for (int rowb = 0; rowb < step; rowb += 256) {
-      const int li = rowb + threadIdx.x;          // local index
-      const int i = n0 + li;
-      bool f[4] = {false, false, false, false};
-      double fine[4] = {0.0, 0.0, 0.0, 0.0};
-      if (li < step && i < ylen - 1) {
-        const double a = s[li], b = s[li + 1];
-        // type 0: positive -> non-positive (dio.cpp:361-363); type 1 on the negated signal (:419-422)
-        f[0] = 0.0 < a && b <= 0.0;
-        f[1] = 0.0 < -a && -b <= 0.0;
-        if (f[0] || f[1]) fine[f[0] ? 0 : 1] = (i + 1) - a / (b - a);          // :378-382
-        if (i < ylen - 2) {
-          const double c = s[li + 2];
-          const double p0 = b - a, p1 = c - b;     // (-s[i]) - (-s[i+1]) (:424-425)
-          f[2] = 0.0 < p0 && p1 <= 0.0;
-          f[3] = 0.0 < -p0 && -p1 <= 0.0;
-          if (f[2] || f[3]) fine[f[2] ? 2 : 3] = (i + 1) - p0 / (p1 - p0);
-        }
-      }
-      unsigned long long bal[4];
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        bal[ty] = __ballot(f[ty]);
-        if (lane == 0) wave_cnt[ty][wv] = __popcll(bal[ty]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        int base = run_cnt[ty];
-        for (int q = 0; q < wv; ++q) base += wave_cnt[ty][q];
-        if (f[ty]) {
-          const int rank = __popcll(bal[ty] & ((1ull << lane) - 1ull));
-          const int dst = base + rank;
-          if (dst < cap) ev[(int64_t)ty * cap + dst] = fine[ty];
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < 4) {
-        int tot = 0;
-        for (int q = 0; q < 4; ++q) tot += wave_cnt[threadIdx.x][q];
-        run_cnt[threadIdx.x] += tot;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) ev_cnt[((int64_t)u * meta.nb + band) * 4 + threadIdx.x] = imin(run_cnt[threadIdx.x], cap);
-}
-
-// interp1 (matlabfunctions.cpp:136-182) over a zero-crossing track given by its fine edges:
-// locations[j] = (e[j] + e[j+1]) / 2 / fs, intervals[j] = fs / (e[j+1] - e[j]), j < n (dio.cpp:384-387)
-__device__ __forceinline__ double dio_track(const double* __restrict__ e, int n, double fs, double t) {
-  int lo = 0, hi = n;                         // upper_bound on locations
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
-    if (loc <= t) lo = mid + 1; else hi = mid;
-  }
-  const int k = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-  const double x0 = (e[k - 1] + e[k]) / 2.0 / fs, x1 = (e[k] + e[k + 1]) / 2.0 / fs;
-  const double y0 = fs / (e[k] - e[k - 1]), y1 = fs / (e[k + 1] - e[k]);
-  const double h = x1 - x0;
-  const double sfrac = (t - x0) / h;
-  return y0 + sfrac * (y1 - y0);
+  // filtered[n] = sum_{k < 4 hal} w[k] z[n + 2 hal - k]  (dio.cpp:310-337)
+  filter_and_events(z + z_off[u] + meta.pad, -meta.pad, ylen + meta.pad, ylen, win + meta.win_off[band], 4 * hal,
+                    2 * hal, events + ev_off[u] + (int64_t)band * 4 * cap, cap,
+                    ev_cnt + ((int64_t)u * meta.nb + band) * 4, lds);
 }
 
 __global__ __launch_bounds__(256) void dio_candidate_kernel(
@@ -255,7 +139,7 @@ __global__ __launch_bounds__(256) void dio_candidate_kernel(
     const double t = (int)(frame - f_off[u]) * frame_period / 1000.0;   // temporal_positions, dio.cpp:608-609
     double v[4];
 #pragma unroll
-    for (int ty = 0; ty < 4; ++ty) v[ty] = dio_track(ev + (int64_t)ty * cap, nint[ty], meta.afs, t);
+    for (int ty = 0; ty < 4; ++ty) v[ty] = zc_track(ev + (int64_t)ty * cap, nint[ty], meta.afs, t);
     c = (v[0] + v[1] + v[2] + v[3]) / 4.0;          // dio.cpp:446-457
     sc = sqrt(((v[0] - c) * (v[0] - c) + (v[1] - c) * (v[1] - c) + (v[2] - c) * (v[2] - c) +
                (v[3] - c) * (v[3] - c)) / 3.0);
@@ -478,10 +362,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
   }
   {
-    const int ntap_max = 4 * m.hal[0];
-    const int zspan = kBandTile + ntap_max;
-    const int stride = (zspan + kBandK - 1) / kBandK + 1;
-    const size_t lds = sizeof(double) * (size_t)(kBandK * stride + ntap_max + kBandTile);
+    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles(4 * m.hal[0]);
     TimedScope ts_(b.ctx, "dio_band_kernel");
     hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_x_len, b.d_dio_z_off,
                        b.d_dio_z, b.d_dio_win, m, b.d_dio_ev_off, b.d_dio_events, b.d_dio_ev_cnt);

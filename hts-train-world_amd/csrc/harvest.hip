@@ -1,11 +1,873 @@
-// harvest.hip -- Harvest F0 estimation (externs/WORLD_v2/src/harvest.cpp:43-1262).
-// Not implemented on the device yet: the entry point reports WM_ERR_UNSUPPORTED (there is
-// deliberately no CPU fallback).
+// harvest.hip -- Harvest F0 estimation for a batch of utterances.
+//
+// Replaces Harvest / HarvestGeneralBody and everything below it
+// (externs/WORLD_v2/src/harvest.cpp:43-1262) plus decimate (matlabfunctions.cpp:27-125, 184-210):
+//
+//   hv_decim_fwd/bwd_kernel  zero-phase 3rd-order IIR decimation; each thread runs the recursion
+//                            over its own chunk after a 512-sample warm-up (pole radius <= 0.89,
+//                            so the warm-up state equals the sequential state to < 1e-26)
+//   hv_mean_kernel           mean removal over y_length                       harvest.cpp:81-86
+//   hv_band_kernel           152 cos-modulated Nuttall band-pass FIRs + four zero-crossing event
+//                            lists per channel (zcfilter.hpp)                 :99-238
+//   hv_raw_kernel            per (frame, channel) interp1 of the four tracks  :240-293, 334-343
+//   hv_detect_kernel         runs of >= 10 voiced channels -> candidates      :348-412
+//   hv_refine_kernel         instantaneous-frequency refinement of every (frame, overlapped
+//                            candidate): direct DFT at <= 6 bins instead of two FFTs  :417-631
+//   hv_remove_kernel         RemoveUnreliableCandidates                       :652-688
+//   hv_contour_kernel        SearchF0Base, FixStep1-4, SmoothF0Contour, final resampling
+//                            (:693-1113, 1246-1251); sequential along time, one workgroup per
+//                            utterance, sections of the zero-lag Butterworth in parallel.
+//
+// The band filters are evaluated as time-domain FIRs: the reference's FFT size leaves more than
+// the filter length of zero padding (harvest.cpp:1164-1165), so its circular convolution is the
+// linear one.
+#include <math.h>
+
 #include "batch.hpp"
+#include "common.hpp"
+#include "fft.hpp"
+#include "zcfilter.hpp"
 
 namespace wm {
-int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
-  (void)b; (void)d_x; (void)d_t; (void)d_f0;
-  return WM_ERR_UNSUPPORTED;
+
+constexpr int kHvOverlap = 7;
+
+struct HvMeta {
+  int nch;          // number_of_channels (harvest.cpp:1151-1153)
+  int r;            // decimation ratio
+  double afs;       // actual_fs
+  int lag;          // edge padding of GetWaveformAndSpectrumSub (:50-51)
+  int cpf;          // candidates per frame before overlap = matlab_round(nch / 10.0)
+  int maxc;         // max_candidates = cpf * 7 (:1180-1181)
+  int ntap_max;
+  double a0, a1, a2, b0, b1;   // decimation IIR (matlabfunctions.cpp:27-113)
+};
+
+struct HarvestWs {
+  HvMeta m;
+  std::vector<int> ylen, nb1;
+  std::vector<int64_t> yoff, toff, evoff, boff, mdoff, smoff;
+  int64_t tot_y = 0, tot_t = 0, tot_ev = 0, tot_b = 0, tot_md = 0, tot_sm = 0;
+  int* d_ylen = nullptr; int* d_nb1 = nullptr;
+  int64_t *d_yoff = nullptr, *d_toff = nullptr, *d_evoff = nullptr, *d_boff = nullptr, *d_mdoff = nullptr,
+          *d_smoff = nullptr;
+  int* d_bframe_utt = nullptr;                 // [tot_b]
+  double* d_bf = nullptr; int* d_half = nullptr; int* d_tapoff = nullptr; double* d_taps = nullptr;
+  double* d_y = nullptr; double* d_tmp = nullptr;
+  double* d_events = nullptr; int* d_evcnt = nullptr;
+  double* d_raw = nullptr; double* d_offc = nullptr; int* d_cnt = nullptr; int* d_ncand1 = nullptr;
+  double *d_rc = nullptr, *d_rs = nullptr, *d_rc2 = nullptr, *d_rs2 = nullptr;
+  double* d_work = nullptr;                    // [8][tot_b] contour work arrays
+  int* d_bl = nullptr;                         // [2][tot_b + 8 n_utt] boundary lists
+  double* d_md = nullptr;                      // banded multi-channel contours
+  int* d_sec = nullptr;                        // [3][tot_b/4 ...] section descriptors (lo, hi, off)
+  double* d_sm = nullptr;                      // smoothing scratch
+  std::vector<void*> owned;
+};
+
+// ---- decimation ---------------------------------------------------------------------------
+__device__ __forceinline__ double hv_nx(const double* __restrict__ x, int n, int lag, int j) {
+  // new_x of GetWaveformAndSpectrumSub (harvest.cpp:55-59): x edge-padded by lag samples
+  return x[imin(n - 1, imax(0, j - lag))];
 }
+__device__ __forceinline__ double hv_dec_in(const double* __restrict__ x, int n, int lag, int nn, int i) {
+  // tmp1 of decimate (matlabfunctions.cpp:189-192): new_x reflect-padded by 9 samples
+  if (i < 9) return 2 * hv_nx(x, n, lag, 0) - hv_nx(x, n, lag, 9 - i);
+  if (i >= 9 + nn) return 2 * hv_nx(x, n, lag, nn - 1) - hv_nx(x, n, lag, nn - 2 - (i - (9 + nn)));
+  return hv_nx(x, n, lag, i - 9);
+}
+
+constexpr int kDecChunk = 256, kDecWarm = 512;
+
+// pass 1: tmp2[i] = IIR(tmp1)[i]
+__global__ __launch_bounds__(64) void hv_decim_fwd_kernel(const double* __restrict__ x,
+                                                          const int64_t* __restrict__ x_off,
+                                                          const int* __restrict__ x_len, HvMeta m,
+                                                          const int64_t* __restrict__ toff,
+                                                          double* __restrict__ tmp) {
+#pragma clang fp contract(off)
+  const int u = blockIdx.y;
+  const int n = x_len[u], nn = n + 2 * m.lag, len = nn + 18;
+  const int c0 = (blockIdx.x * 64 + threadIdx.x) * kDecChunk;
+  if (c0 >= len) return;
+  const double* xu = x + x_off[u];
+  double* out = tmp + toff[u];
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+  const int start = imax(0, c0 - kDecWarm);
+  const int end = imin(len, c0 + kDecChunk);
+  for (int i = start; i < end; ++i) {
+    const double wt = hv_dec_in(xu, n, m.lag, nn, i) + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
+    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
+    w2 = w1; w1 = w0; w0 = wt;
+    if (i >= c0) out[i] = o;
+  }
+}
+
+// pass 2 on the reversed pass-1 output; only the decimated samples are kept:
+// y[c] = tmp1_final[nbeg + c r + 8] (matlabfunctions.cpp:201-206), then y[lag/r + i] (harvest.cpp:62)
+__global__ __launch_bounds__(64) void hv_decim_bwd_kernel(const int* __restrict__ x_len, HvMeta m,
+                                                          const int64_t* __restrict__ toff,
+                                                          const double* __restrict__ tmp,
+                                                          const int64_t* __restrict__ yoff,
+                                                          const int* __restrict__ ylen_a, double* __restrict__ y) {
+#pragma clang fp contract(off)
+  const int u = blockIdx.y;
+  const int n = x_len[u], nn = n + 2 * m.lag, len = nn + 18;
+  const int c0 = (blockIdx.x * 64 + threadIdx.x) * kDecChunk;
+  if (c0 >= len) return;
+  const double* in = tmp + toff[u];
+  double* yu = y + yoff[u];
+  const int ylen = ylen_a[u];
+  const int nout = (nn - 1) / m.r + 1;
+  const int nbeg = m.r - m.r * nout + nn;
+  const int shift = m.lag / m.r;
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+  const int start = imax(0, c0 - kDecWarm);
+  const int end = imin(len, c0 + kDecChunk);
+  for (int i = start; i < end; ++i) {
+    const double wt = in[len - 1 - i] + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
+    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
+    w2 = w1; w1 = w0; w0 = wt;
+    if (i >= c0) {
+      const int j = len - 1 - i;                 // index in the final (re-reversed) array
+      const int q = j - 8 - nbeg;                // = c * r
+      if (q >= 0 && q % m.r == 0 && q + nbeg < nn + 9) {
+        const int c = q / m.r - shift;
+        if (c >= 0 && c < ylen) yu[c] = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hv_copy_kernel(const double* __restrict__ x,
+                                                      const int64_t* __restrict__ x_off,
+                                                      const int* __restrict__ x_len,
+                                                      const int64_t* __restrict__ yoff, double* __restrict__ y) {
+  const int u = blockIdx.y;
+  const int n = x_len[u];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[yoff[u] + i] = x[x_off[u] + i];
+}
+
+// y -= mean(y) over y_length (harvest.cpp:81-86)
+__global__ __launch_bounds__(256) void hv_mean_kernel(const int64_t* __restrict__ yoff,
+                                                      const int* __restrict__ ylen_a, double* __restrict__ y) {
+  __shared__ double part[4];
+  const int u = blockIdx.x;
+  double* yu = y + yoff[u];
+  const int n = ylen_a[u];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += yu[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const double mean = (part[0] + part[1] + part[2] + part[3]) / n;
+  for (int i = threadIdx.x; i < n; i += 256) yu[i] -= mean;
+}
+
+// ---- filterbank + events --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_band_kernel(const int64_t* __restrict__ yoff,
+                                                      const int* __restrict__ ylen_a, const double* __restrict__ y,
+                                                      const double* __restrict__ taps,
+                                                      const int* __restrict__ tapoff, const int* __restrict__ half,
+                                                      int nch, const int64_t* __restrict__ evoff,
+                                                      double* __restrict__ events, int* __restrict__ evcnt) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int u = blockIdx.y, ch = blockIdx.x;
+  const int ylen = ylen_a[u];
+  const int cap = ylen / 2 + 2;
+  const int hf = half[ch];
+  // filtered[n] = sum_k bp[k] y[n + (half + 1) - k], k < 2 half + 1 (harvest.cpp:101-142)
+  filter_and_events(y + yoff[u], 0, ylen, ylen, taps + tapoff[ch], 2 * hf + 1, hf + 1,
+                    events + evoff[u] + (int64_t)ch * 4 * cap, cap, evcnt + ((int64_t)u * nch + ch) * 4, lds);
+}
+
+// raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
+__global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bframe_utt,
+                                                     const int64_t* __restrict__ boff,
+                                                     const int* __restrict__ ylen_a, HvMeta m,
+                                                     const double* __restrict__ bf, double f0_floor, double f0_ceil,
+                                                     const int64_t* __restrict__ evoff,
+                                                     const double* __restrict__ events,
+                                                     const int* __restrict__ evcnt, int64_t tot_b,
+                                                     double* __restrict__ raw) {
+  const int ch = blockIdx.y;
+  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fr >= tot_b) return;
+  const int u = bframe_utt[fr];
+  const int cap = ylen_a[u] / 2 + 2;
+  const int* cnt = evcnt + ((int64_t)u * m.nch + ch) * 4;
+  const double* ev = events + evoff[u] + (int64_t)ch * 4 * cap;
+  int nint[4];
+  bool ok = true;
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    nint[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;
+    ok = ok && nint[ty] > 2;                                   // CheckEvent(n - 2), :263-266
+  }
+  double c = 0.0;
+  if (ok) {
+    const double t = (int)(fr - boff[u]) * 1 / 1000.0;         // basic frame period 1 ms (:1174-1175)
+    double v[4];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) v[ty] = zc_track(ev + (int64_t)ty * cap, nint[ty], m.afs, t);
+    c = (v[0] + v[1] + v[2] + v[3]) / 4.0;
+    const double b = bf[ch];
+    if (c > b * 1.1 || c < b * 0.9 || c > f0_ceil || c < f0_floor) c = 0.0;   // :243-252
+  }
+  raw[fr * m.nch + ch] = c;
+}
+
+// DetectOfficialF0Candidates (harvest.cpp:348-412): one thread per frame
+__global__ __launch_bounds__(256) void hv_detect_kernel(const int* __restrict__ bframe_utt, HvMeta m,
+                                                        const double* __restrict__ raw, int64_t tot_b,
+                                                        double* __restrict__ offc, int* __restrict__ cnt,
+                                                        int* __restrict__ ncand1) {
+  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fr >= tot_b) return;
+  const double* row = raw + fr * m.nch;
+  double* out = offc + fr * m.cpf;
+  int k = 0;
+  int prev = 0, st = 0;                         // vuv[0] = 0
+  for (int j = 1; j < m.nch; ++j) {
+    const int v = (j == m.nch - 1) ? 0 : (row[j] > 0 ? 1 : 0);
+    const int d = v - prev;
+    if (d == 1) st = j;
+    if (d == -1) {
+      const int ed = j;
+      if (ed - st >= 10) {
+        double tmp = 0.0;
+        for (int q = st; q < ed; ++q) tmp += row[q];
+        tmp /= (ed - st);
+        if (k < m.cpf) out[k] = tmp;
+        ++k;
+      }
+    }
+    prev = v;
+  }
+  if (k > m.cpf) k = m.cpf;
+  for (int q = k; q < m.cpf; ++q) out[q] = 0.0;
+  cnt[fr] = k;
+  if (k > 0) atomicMax(&ncand1[bframe_utt[fr]], k);
+}
+
+// RefineF0Candidates (harvest.cpp:622-631) over the overlapped candidate table that
+// OverlapF0Candidates (:417-429) would build: slot s = j + ncand1 * blk reads frame k - blk
+// (blk = 1..3) or k + blk - 3 (blk = 4..6); out-of-range or unwritten entries are zero.
+template <int NB>
+__device__ __forceinline__ void hv_dft_bins(const double* __restrict__ ys, int ylen, const double* mw, int L,
+                                            int basic, const int (&bin)[NB], int nh, int fftn, int lane,
+                                            double (&pw)[NB], double (&num)[NB]) {
+  cpx mainv[NB], diffv[NB], w[NB], st[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    mainv[b] = make_double2(0.0, 0.0);
+    diffv[b] = make_double2(0.0, 0.0);
+    w[b] = cis_neg2pi((double)(((long long)bin[b] * lane) % fftn) / (double)fftn);
+    st[b] = cis_neg2pi((double)(((long long)bin[b] * 64) % fftn) / (double)fftn);
+  }
+  for (int i = lane; i < L; i += 64) {
+    const double xi = ys[imax(0, imin(ylen - 1, basic + i - 1))];   // :481-484
+    const double mm = mw[i];
+    double d;                                                       // :462-468
+    if (i == 0) d = -mw[1] / 2.0;
+    else if (i == L - 1) d = mw[L - 2] / 2.0;
+    else d = -(mw[i + 1] - mw[i - 1]) / 2.0;
+    const double am = xi * mm, ad = xi * d;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nh) {
+        mainv[b].x += am * w[b].x; mainv[b].y += am * w[b].y;
+        diffv[b].x += ad * w[b].x; diffv[b].y += ad * w[b].y;
+        w[b] = cmul(w[b], st[b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const double mr = wave_sum(mainv[b].x), mi = wave_sum(mainv[b].y);
+    const double dr = wave_sum(diffv[b].x), di = wave_sum(diffv[b].y);
+    num[b] = mr * di - mi * dr;                                     // :565-566
+    pw[b] = mr * mr + mi * mi;                                      // :567-568
+  }
+}
+
+__global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ bframe_utt,
+                                                       const int64_t* __restrict__ boff,
+                                                       const int* __restrict__ nb1_a, HvMeta m,
+                                                       const int64_t* __restrict__ yoff,
+                                                       const int* __restrict__ ylen_a, const double* __restrict__ y,
+                                                       const double* __restrict__ offc,
+                                                       const int* __restrict__ ncand1_a, double f0_floor,
+                                                       double f0_ceil, int64_t tot_b, double* __restrict__ rc,
+                                                       double* __restrict__ rs) {
+  extern __shared__ __attribute__((aligned(16))) double mw[];
+  const int lane = threadIdx.x;
+  for (int64_t fr = blockIdx.x; fr < tot_b; fr += gridDim.x) {
+    const int u = bframe_utt[fr];
+    const int k = (int)(fr - boff[u]);
+    const int nb1 = nb1_a[u];
+    const int nc1 = ncand1_a[u];
+    const double* ys = y + yoff[u];
+    const int ylen = ylen_a[u];
+    const double pos = k * 1 / 1000.0;
+    const double fs = m.afs;
+    for (int s = 0; s < nc1 * kHvOverlap; ++s) {
+      const int blk = s / nc1, j = s - blk * nc1;
+      const int src = blk == 0 ? k : (blk <= 3 ? k - blk : k + (blk - 3));
+      double f0 = 0.0;
+      if (src >= 0 && src < nb1) f0 = offc[(boff[u] + src) * m.cpf + j];
+      double rf0 = 0.0, rscore = 0.0;
+      if (f0 > 0.0) {                                              // GetRefinedF0 :589-617
+        const int hw = (int)(1.5 * fs / f0 + 1.0);
+        const int L = 2 * hw + 1;
+        const double wlen = (2.0 * hw + 1.0) / fs;
+        const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
+        const double bt0 = (-hw + 0) / fs;
+        const int basic = matlab_round((pos + bt0) * fs + 0.001);  // GetBaseIndex :434-441
+        __syncthreads();
+        for (int i = lane; i < L; i += 64) {                       // GetMainWindow :446-456
+          const double tm = ((basic + i) - 1.0) / fs - pos;
+          mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * tm / wlen) + 0.08 * cos(4.0 * kPi * tm / wlen);
+        }
+        __syncthreads();
+        const int nh = imin((int)(fs / 2.0 / f0), 6);              // :571-572
+        int bin[6];
+        double pw[6], num[6];
+#pragma unroll
+        for (int h = 0; h < 6; ++h) bin[h] = matlab_round(f0 * fftn / fs * (h + 1));   // FixF0 :515
+        hv_dft_bins<6>(ys, ylen, mw, L, basic, bin, nh, fftn, lane, pw, num);
+        double numer = 0.0, denom = 0.0, sc = 0.0;
+#pragma unroll
+        for (int h = 0; h < 6; ++h) {
+          if (h < nh) {
+            const double p = bin[h] <= fftn / 2 ? pw[h] : 0.0;
+            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs / fftn + num[h] / p * fs / 2.0 / kPi;
+            const double amp = sqrt(p);
+            numer += amp * inst;
+            denom += amp * (h + 1.0);
+            sc += fabs((inst / (h + 1.0) - f0) / f0);
+          }
+        }
+        rf0 = numer / (denom + kSafe);
+        rscore = 1.0 / (sc / nh + kSafe);
+        if (rf0 < f0_floor || rf0 > f0_ceil || rscore < 2.5) { rf0 = 0.0; rscore = 0.0; }   // :610-614
+      }
+      if (lane == 0) {
+        rc[fr * m.maxc + s] = rf0;
+        rs[fr * m.maxc + s] = rscore;
+      }
+    }
+  }
+}
+
+// RemoveUnreliableCandidates (harvest.cpp:652-688): one thread per (frame, slot); neighbours are
+// read from the unmodified table.  Rows 0 and T-1 of the reference's scratch are uninitialised
+// memory; they read as zero here (as in the oracle).
+__global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ bframe_utt,
+                                                        const int64_t* __restrict__ boff,
+                                                        const int* __restrict__ nb1_a, HvMeta m,
+                                                        const int* __restrict__ ncand1_a,
+                                                        const double* __restrict__ rc,
+                                                        const double* __restrict__ rs, int64_t tot_b,
+                                                        double* __restrict__ rc2, double* __restrict__ rs2) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t fr = id / m.maxc;
+  const int s = (int)(id - fr * m.maxc);
+  if (fr >= tot_b) return;
+  const int u = bframe_utt[fr];
+  const int nc = ncand1_a[u] * kHvOverlap;
+  if (s >= nc) return;
+  const int k = (int)(fr - boff[u]);
+  const int nb1 = nb1_a[u];
+  double c = rc[fr * m.maxc + s], sc = rs[fr * m.maxc + s];
+  if (k >= 1 && k < nb1 - 1 && c != 0) {
+    double e[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int nk = side == 0 ? k + 1 : k - 1;
+      const bool zero_row = nk == 0 || nk == nb1 - 1;
+      const double* row = rc + (fr + (side == 0 ? 1 : -1)) * m.maxc;
+      double best = 1.0;                                           // SelectBestF0 with allowed_range 1.0
+      for (int q = 0; q < nc; ++q) {
+        const double v = zero_row ? 0.0 : row[q];
+        const double er = fabs(c - v) / c;
+        if (er > best) continue;
+        best = er;
+      }
+      e[side] = best;
+    }
+    const double me = e[0] < e[1] ? e[0] : e[1];
+    if (!(me <= 0.05)) { c = 0; sc = 0; }
+  }
+  rc2[fr * m.maxc + s] = c;
+  rs2[fr * m.maxc + s] = sc;
+}
+
+// ---- contour logic (sequential along time) -------------------------------------------------
+struct HvCand {                     // candidate table of one utterance after pruning
+  const double* c; const double* s; int nc; int stride;
+};
+
+// SelectBestF0 (harvest.cpp:636-650)
+__device__ __forceinline__ double hv_select(double ref, const double* __restrict__ c, int n, double allowed) {
+  double best = 0.0, be = allowed;
+  for (int i = 0; i < n; ++i) {
+    const double e = fabs(ref - c[i]) / ref;
+    if (e > be) continue;
+    best = c[i];
+    be = e;
+  }
+  return best;
+}
+
+// GetBoundaryList (harvest.cpp:727-743)
+__device__ int hv_boundaries(const double* f0, int n, int* list) {
+  int cnt = 0, prev = 0;
+  for (int i = 1; i < n; ++i) {
+    const int v = (i == n - 1) ? 0 : (f0[i] > 0 ? 1 : 0);
+    if (v - prev != 0) { list[cnt] = i - cnt % 2; cnt++; }
+    prev = v;
+  }
+  return cnt;
+}
+
+struct HvSec { int lo, hi; int64_t off; };     // banded row of multi_channel_f0
+__device__ __forceinline__ double hv_get(const double* md, const HvSec& s, int j) {
+  return (j >= s.lo && j <= s.hi) ? md[s.off + (j - s.lo)] : 0.0;
+}
+__device__ __forceinline__ void hv_set(double* md, const HvSec& s, int j, double v) {
+  if (j >= s.lo && j <= s.hi) md[s.off + (j - s.lo)] = v;
+}
+
+// ExtendF0 (harvest.cpp:791-820)
+__device__ int hv_extend_f0(int origin, int last_point, int shift, const HvCand& cd, double allowed, double* md,
+                            const HvSec& sec) {
+  double tmp_f0 = hv_get(md, sec, origin);
+  int shifted_origin = origin;
+  const int distance = last_point > origin ? last_point - origin : origin - last_point;
+  int count = 0;
+  for (int i = 0; i <= distance; ++i) {
+    const int idx = origin + shift * i;
+    const double v = hv_select(tmp_f0, cd.c + (int64_t)(idx + shift) * cd.stride, cd.nc, allowed);
+    hv_set(md, sec, idx + shift, v);
+    if (v == 0.0) {
+      count++;
+    } else {
+      tmp_f0 = v;
+      count = 0;
+      shifted_origin = idx + shift;
+    }
+    if (count == 4) break;
+  }
+  return shifted_origin;
+}
+
+// SearchScore (harvest.cpp:901-907)
+__device__ __forceinline__ double hv_search_score(double f0, const double* c, const double* s, int n) {
+  double score = 0.0;
+  for (int i = 0; i < n; ++i)
+    if (f0 == c[i] && score < s[i]) score = s[i];
+  return score;
+}
+
+constexpr int kSmLag = 300;      // SmoothF0Contour lag (harvest.cpp:1085)
+constexpr int kSmPar = 32;       // sections filtered concurrently
+
+__global__ __launch_bounds__(256) void hv_contour_kernel(
+    const int64_t* __restrict__ boff, const int* __restrict__ nb1_a, HvMeta m, const int* __restrict__ ncand1_a,
+    const double* __restrict__ rc2, const double* __restrict__ rs2, int64_t tot_b, int n_utt,
+    double* __restrict__ work, int* __restrict__ blist, const int64_t* __restrict__ mdoff, double* __restrict__ mdata,
+    int* __restrict__ secd, const int64_t* __restrict__ smoff, double* __restrict__ smbuf,
+    const int64_t* __restrict__ f_off, double frame_period, double* __restrict__ t_out, double* __restrict__ f0_out) {
+  const int u = blockIdx.x;
+  const int nf = nb1_a[u];
+  const int64_t b0 = boff[u];
+  const int nc = ncand1_a[u] * kHvOverlap;
+  HvCand cd;
+  cd.c = rc2 + b0 * m.maxc; cd.s = rs2 + b0 * m.maxc; cd.nc = nc; cd.stride = m.maxc;
+  double* c1 = work + 0 * tot_b + b0;
+  double* c2 = work + 1 * tot_b + b0;
+  double* best = work + 2 * tot_b + b0;
+  double* smooth = work + 3 * tot_b + b0;
+  int* bl = blist + (b0 + 8 * u);
+  int* bl2 = blist + (tot_b + 8 * (int64_t)n_utt) + (b0 + 8 * u);      // up to nf + 600 boundaries? (<= nf+8 used)
+  double* md = mdata + mdoff[u];
+  // section descriptors: lo[], hi[], off[] (as int offsets relative to md)
+  const int sec_cap = nf / 4 + 8;
+  int* s_lo = secd + 3 * (b0 / 4 + 8 * (int64_t)u);
+  int* s_hi = s_lo + sec_cap;
+  int* s_of = s_hi + sec_cap;
+  __shared__ int sh_n;
+
+  // SearchF0Base (:693-705) and FixStep1 (:710-722, allowed 0.008); entries the reference leaves
+  // unwritten (f0_base == 0) are zero here
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    double bs = 0.0, bv = 0.0;
+    const double* cr = cd.c + (int64_t)i * cd.stride;
+    const double* sr = cd.s + (int64_t)i * cd.stride;
+    for (int j = 0; j < nc; ++j)
+      if (sr[j] > bs) { bv = cr[j]; bs = sr[j]; }
+    c1[i] = bv;
+    smooth[i] = 0.0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    double v = 0.0;
+    if (i >= 2 && c1[i] != 0.0) {
+      const double ref = c1[i - 1] * 2 - c1[i - 2];
+      v = (fabs((c1[i] - ref) / ref) > 0.008 && fabs((c1[i] - c1[i - 1])) / c1[i - 1] > 0.008) ? 0.0 : c1[i];
+    }
+    c2[i] = v;
+  }
+  __syncthreads();
+
+  if (threadIdx.x == 0) {
+    // FixStep2 (:748-762, minimum 6): c2 -> c1
+    for (int i = 0; i < nf; ++i) c1[i] = c2[i];
+    int nb = hv_boundaries(c2, nf, bl);
+    for (int i = 0; i < nb / 2; ++i) {
+      if (bl[i * 2 + 1] - bl[i * 2] >= 6) continue;
+      for (int j = bl[i * 2]; j <= bl[i * 2 + 1]; ++j) c1[j] = 0.0;
+    }
+    // FixStep3 (:968-995, allowed 0.18): c1 -> c2
+    for (int i = 0; i < nf; ++i) c2[i] = c1[i];
+    nb = hv_boundaries(c1, nf, bl);
+    const int nsec = nb / 2;
+    int64_t used = 0;
+    for (int i = 0; i < nsec; ++i) {                               // GetMultiChannelF0 :767-778 (banded)
+      HvSec sc;
+      sc.lo = imax(0, bl[i * 2] - 102);
+      sc.hi = imin(nf - 1, bl[i * 2 + 1] + 102);
+      sc.off = used;
+      used += sc.hi - sc.lo + 1;
+      s_lo[i] = sc.lo; s_hi[i] = sc.hi; s_of[i] = (int)sc.off;
+      for (int j = sc.lo; j <= sc.hi; ++j) md[sc.off + (j - sc.lo)] = (j >= bl[i * 2] && j <= bl[i * 2 + 1]) ? c1[j] : 0.0;
+    }
+    for (int i = 0; i < nsec; ++i) {                               // Extend :861-878 (in place)
+      HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
+      bl[i * 2 + 1] = hv_extend_f0(bl[i * 2 + 1], imin(nf - 2, bl[i * 2 + 1] + 100), 1, cd, 0.18, md, sc);
+      bl[i * 2] = hv_extend_f0(bl[i * 2], imax(1, bl[i * 2] - 100), -1, cd, 0.18, md, sc);
+    }
+    int nchn = 0;                                                  // ExtendSub :840-856
+    {
+      double mean_f0 = 0.0;                                        // not reset between sections (quirk)
+      for (int i = 0; i < nsec; ++i) {
+        HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
+        const int st = bl[i * 2], ed = bl[i * 2 + 1];
+        for (int j = st; j < ed; ++j) mean_f0 += hv_get(md, sc, j);
+        mean_f0 /= ed - st;
+        if (2200.0 / mean_f0 < ed - st) {                          // Swap :826-838
+          int tv;
+          tv = s_lo[nchn]; s_lo[nchn] = s_lo[i]; s_lo[i] = tv;
+          tv = s_hi[nchn]; s_hi[nchn] = s_hi[i]; s_hi[i] = tv;
+          tv = s_of[nchn]; s_of[nchn] = s_of[i]; s_of[i] = tv;
+          tv = bl[nchn * 2]; bl[nchn * 2] = bl[i * 2]; bl[i * 2] = tv;
+          tv = bl[nchn * 2 + 1]; bl[nchn * 2 + 1] = bl[i * 2 + 1]; bl[i * 2 + 1] = tv;
+          nchn++;
+        }
+      }
+    }
+    if (nchn != 0) {                                               // MergeF0 :937-963
+      int* order = bl2;                                            // scratch: nchn ints
+      for (int i = 0; i < nchn; ++i) order[i] = i;                 // MakeSortedOrder :883-896
+      for (int i = 1; i < nchn; ++i)
+        for (int j = i - 1; j >= 0; --j) {
+          if (bl[order[j] * 2] > bl[order[i] * 2]) { const int tv = order[i]; order[i] = order[j]; order[j] = tv; }
+          else break;
+        }
+      {
+        HvSec s0; s0.lo = s_lo[0]; s0.hi = s_hi[0]; s0.off = s_of[0];
+        for (int i = 0; i < nf; ++i) c2[i] = hv_get(md, s0, i);
+      }
+      for (int i = 1; i < nchn; ++i) {
+        const int o = order[i];
+        HvSec so; so.lo = s_lo[o]; so.hi = s_hi[o]; so.off = s_of[o];
+        if (bl[o * 2] - bl[1] > 0) {
+          for (int j = bl[o * 2]; j <= bl[o * 2 + 1]; ++j) c2[j] = hv_get(md, so, j);
+          bl[0] = bl[o * 2];
+          bl[1] = bl[o * 2 + 1];
+        } else {                                                   // MergeF0Sub :912-932
+          const int st1 = bl[0], ed1 = bl[1], st2 = bl[o * 2], ed2 = bl[o * 2 + 1];
+          if (st1 <= st2 && ed1 >= ed2) {
+            bl[1] = ed1;
+          } else {
+            double sc1 = 0.0, sc2 = 0.0;
+            for (int k = st2; k <= ed1; ++k) {
+              const double* cr = cd.c + (int64_t)k * cd.stride;
+              const double* sr = cd.s + (int64_t)k * cd.stride;
+              sc1 += hv_search_score(c2[k], cr, sr, nc);
+              sc2 += hv_search_score(hv_get(md, so, k), cr, sr, nc);
+            }
+            if (sc1 > sc2) for (int k = ed1; k <= ed2; ++k) c2[k] = hv_get(md, so, k);
+            else for (int k = st2; k <= ed2; ++k) c2[k] = hv_get(md, so, k);
+            bl[1] = ed2;
+          }
+        }
+      }
+    }
+    // FixStep4 (:1000-1022, threshold 9): c2 -> best
+    for (int i = 0; i < nf; ++i) best[i] = c2[i];
+    nb = hv_boundaries(c2, nf, bl);
+    for (int i = 0; i < nb / 2 - 1; ++i) {
+      const int distance = bl[(i + 1) * 2] - bl[i * 2 + 1] - 1;
+      if (distance >= 9) continue;
+      const double tmp0 = c2[bl[i * 2 + 1]] + 1, tmp1 = c2[bl[(i + 1) * 2]] - 1;
+      const double coef = (tmp1 - tmp0) / (distance + 1.0);
+      int count = 1;
+      for (int j = bl[i * 2 + 1] + 1; j <= bl[(i + 1) * 2] - 1; ++j) best[j] = tmp0 + coef * count++;
+    }
+    // SmoothF0Contour (:1079-1113): boundaries of the zero-padded contour.  The padded array is
+    // `best` shifted by lag, so boundaries are those of best (with its first/last frame forced
+    // unvoiced only by the padding, i.e. not forced) shifted by lag.
+    {
+      int cnt = 0, prev = 0;
+      const int nn = nf + 2 * kSmLag;
+      for (int i = 1; i < nn; ++i) {
+        const int j = i - kSmLag;
+        const int v = (i == nn - 1) ? 0 : ((j >= 0 && j < nf && best[j] > 0) ? 1 : 0);
+        if (v - prev != 0) { bl[cnt] = i - cnt % 2; cnt++; }
+        prev = v;
+      }
+      sh_n = cnt / 2;
+    }
+  }
+  __syncthreads();
+  // FilteringF0 (:1049-1074) per section, kSmPar sections at a time, one thread each
+  {
+    const int nsec = sh_n;
+    const int nn = nf + 2 * kSmLag;
+    const double fb0 = 0.0078202080334971724, fb1 = 0.015640416066994345;
+    const double fa0 = 1.7347257688092754, fa1 = -0.76600660094326412;
+    double* sm = smbuf + smoff[u];
+    for (int base = 0; base < nsec; base += kSmPar) {
+      const int sidx = base + threadIdx.x;
+      if (threadIdx.x < kSmPar && sidx < nsec) {
+#pragma clang fp contract(off)
+        const int st = bl[sidx * 2], ed = bl[sidx * 2 + 1];          // padded coordinates
+        double* tmp = sm + (int64_t)threadIdx.x * nn;
+        const double xs = best[st - kSmLag], xe = best[ed - kSmLag];
+        double w0 = 0.0, w1 = 0.0;
+        for (int i = 0; i < nn; ++i) {
+          const double xi = i < st ? xs : (i > ed ? xe : best[i - kSmLag]);
+          const double wt = xi + fa0 * w0 + fa1 * w1;
+          tmp[nn - i - 1] = fb0 * wt + fb1 * w0 + fb0 * w1;
+          w1 = w0; w0 = wt;
+        }
+        w0 = w1 = 0.0;
+        for (int i = 0; i < nn; ++i) {
+          const double wt = tmp[i] + fa0 * w0 + fa1 * w1;
+          const double o = fb0 * wt + fb1 * w0 + fb0 * w1;
+          w1 = w0; w0 = wt;
+          const int j = nn - i - 1;
+          if (j >= st && j <= ed) smooth[j - kSmLag] = o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // final resampling to the requested frame period (:1230-1251)
+  const int64_t fo = f_off[u];
+  const int nout = (int)(f_off[u + 1] - fo);
+  for (int i = threadIdx.x; i < nout; i += 256) {
+    const double t = i * frame_period / 1000.0;
+    t_out[fo + i] = t;
+    f0_out[fo + i] = frame_period == 1.0 ? smooth[i] : smooth[imin(nf - 1, matlab_round(t * 1000.0))];
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static const double kDecA[13][3] = {
+    {0, 0, 0}, {0, 0, 0},
+    {0.041156734567757189, -0.42599112459189636, 0.041037215479961225},
+    {0.95039378983237421, -0.67429146741526791, 0.15412211621346475},
+    {1.4499664446880227, -0.98943497080950582, 0.24578252340690215},
+    {1.7610939654280557, -1.2554914843859768, 0.3237186507788215},
+    {1.9715352749512141, -1.4686795689225347, 0.3893908434965701},
+    {2.1225239019534703, -1.6395144861046302, 0.44469707800587366},
+    {2.2357462340187593, -1.7780899984041358, 0.49152555365968692},
+    {2.3236003491759578, -1.8921545617463598, 0.53148928133729068},
+    {2.3936475118069387, -1.9873904075111861, 0.5658879979027055},
+    {2.450743295230728, -2.06794904601978, 0.59574774438332101},
+    {2.4981398605924205, -2.1368928194784025, 0.62187513816221485}};
+static const double kDecB[13][2] = {
+    {0, 0}, {0, 0},
+    {0.16797464681802227, 0.50392394045406674},
+    {0.071221945171178636, 0.21366583551353591},
+    {0.036710750339322612, 0.11013225101796784},
+    {0.021334858522387423, 0.06400457556716227},
+    {0.013469181309343825, 0.040407543928031475},
+    {0.0090366882681608418, 0.027110064804482525},
+    {0.0063522763407111993, 0.019056829022133598},
+    {0.0046331164041389372, 0.013899349212416812},
+    {0.0034818622251927556, 0.010445586675578267},
+    {0.0026822508007163792, 0.0080467524021491377},
+    {0.0021097275904709001, 0.0063291827714127002}};
+
+static int hv_setup(Batch& b) {
+  if (b.harvest_ws) return WM_OK;
+  HarvestWs* W = new HarvestWs();
+  b.harvest_ws = W;
+  HvMeta& m = W->m;
+  const WorldMi355Params& p = b.p;
+  const double adj_floor = p.f0_floor * 0.9, adj_ceil = p.f0_ceil * 1.1;
+  m.nch = 1 + (int)(log(adj_ceil / adj_floor) / kLog2 * 40);                 // :1151-1153
+  m.r = imax(imin(matlab_round(p.fs / 8000.0), 12), 1);                      // :1227, :1160
+  m.afs = (double)p.fs / m.r;
+  m.lag = m.r == 1 ? 0 : (int)(ceil(140.0 / m.r) * m.r);
+  m.cpf = matlab_round(m.nch / 10.0);
+  m.maxc = m.cpf * kHvOverlap;
+  m.a0 = kDecA[m.r][0]; m.a1 = kDecA[m.r][1]; m.a2 = kDecA[m.r][2];
+  m.b0 = kDecB[m.r][0]; m.b1 = kDecB[m.r][1];
+  std::vector<double> bf((size_t)m.nch), taps;
+  std::vector<int> half((size_t)m.nch), tapoff((size_t)m.nch);
+  m.ntap_max = 0;
+  for (int i = 0; i < m.nch; ++i) {
+    bf[(size_t)i] = adj_floor * pow(2.0, (i + 1) / 40.0);                    // :1155-1157
+    const int hf = matlab_round(m.afs / bf[(size_t)i] * 2.0);               // :101
+    half[(size_t)i] = hf;
+    tapoff[(size_t)i] = (int)taps.size();
+    const int n = 2 * hf + 1;
+    for (int k = 0; k < n; ++k) {                                            // :103-106
+      const double tmp = k / (n - 1.0);
+      const double w = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) + 0.144232 * cos(4.0 * kPi * tmp) -
+                       0.012604 * cos(6.0 * kPi * tmp);
+      taps.push_back(w * cos(2 * kPi * bf[(size_t)i] * (k - hf) / m.afs));
+    }
+    m.ntap_max = imax(m.ntap_max, n);
+  }
+  const int n_utt = b.n_utt;
+  W->ylen.resize((size_t)n_utt); W->nb1.resize((size_t)n_utt);
+  W->yoff.assign((size_t)n_utt + 1, 0); W->toff.assign((size_t)n_utt + 1, 0); W->evoff.assign((size_t)n_utt + 1, 0);
+  W->boff.assign((size_t)n_utt + 1, 0); W->mdoff.assign((size_t)n_utt + 1, 0); W->smoff.assign((size_t)n_utt + 1, 0);
+  for (int u = 0; u < n_utt; ++u) {
+    const int n = b.x_len[(size_t)u];
+    const int yl = (int)ceil((double)n / m.r);                               // :1161-1162
+    const int nb1 = (int)(1000.0 * n / p.fs / 1) + 1;                        // GetSamplesForHarvest, 1 ms
+    W->ylen[(size_t)u] = yl; W->nb1[(size_t)u] = nb1;
+    W->yoff[(size_t)u + 1] = W->yoff[(size_t)u] + yl;
+    W->toff[(size_t)u + 1] = W->toff[(size_t)u] + n + 2 * m.lag + 18;
+    W->evoff[(size_t)u + 1] = W->evoff[(size_t)u] + (int64_t)m.nch * 4 * (yl / 2 + 2);
+    W->boff[(size_t)u + 1] = W->boff[(size_t)u] + nb1;
+    W->mdoff[(size_t)u + 1] = W->mdoff[(size_t)u] + 28LL * nb1 + 512;
+    W->smoff[(size_t)u + 1] = W->smoff[(size_t)u] + (int64_t)kSmPar * (nb1 + 2 * kSmLag);
+  }
+  W->tot_y = W->yoff[(size_t)n_utt]; W->tot_t = W->toff[(size_t)n_utt]; W->tot_ev = W->evoff[(size_t)n_utt];
+  W->tot_b = W->boff[(size_t)n_utt]; W->tot_md = W->mdoff[(size_t)n_utt]; W->tot_sm = W->smoff[(size_t)n_utt];
+  std::vector<int> bfu((size_t)W->tot_b);
+  for (int u = 0; u < n_utt; ++u)
+    for (int64_t i = W->boff[(size_t)u]; i < W->boff[(size_t)u + 1]; ++i) bfu[(size_t)i] = u;
+
+  int rc = WM_OK;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (rc) return;
+    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    if (!rc) W->owned.push_back(*dst);
+    if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  };
+  auto al = [&](void** dst, size_t bytes) {
+    if (rc) return;
+    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    if (!rc) W->owned.push_back(*dst);
+  };
+  up((void**)&W->d_ylen, W->ylen.data(), sizeof(int) * (size_t)n_utt);
+  up((void**)&W->d_nb1, W->nb1.data(), sizeof(int) * (size_t)n_utt);
+  up((void**)&W->d_yoff, W->yoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_toff, W->toff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_evoff, W->evoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_boff, W->boff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_mdoff, W->mdoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_smoff, W->smoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
+  up((void**)&W->d_bframe_utt, bfu.data(), sizeof(int) * bfu.size());
+  up((void**)&W->d_bf, bf.data(), sizeof(double) * bf.size());
+  up((void**)&W->d_half, half.data(), sizeof(int) * half.size());
+  up((void**)&W->d_tapoff, tapoff.data(), sizeof(int) * tapoff.size());
+  up((void**)&W->d_taps, taps.data(), sizeof(double) * taps.size());
+  al((void**)&W->d_y, sizeof(double) * (size_t)W->tot_y);
+  if (m.r > 1) al((void**)&W->d_tmp, sizeof(double) * (size_t)W->tot_t);
+  al((void**)&W->d_events, sizeof(double) * (size_t)W->tot_ev);
+  al((void**)&W->d_evcnt, sizeof(int) * (size_t)n_utt * m.nch * 4);
+  al((void**)&W->d_raw, sizeof(double) * (size_t)W->tot_b * m.nch);
+  al((void**)&W->d_offc, sizeof(double) * (size_t)W->tot_b * m.cpf);
+  al((void**)&W->d_cnt, sizeof(int) * (size_t)W->tot_b);
+  al((void**)&W->d_ncand1, sizeof(int) * (size_t)n_utt);
+  al((void**)&W->d_rc, sizeof(double) * (size_t)W->tot_b * m.maxc);
+  al((void**)&W->d_rs, sizeof(double) * (size_t)W->tot_b * m.maxc);
+  al((void**)&W->d_rc2, sizeof(double) * (size_t)W->tot_b * m.maxc);
+  al((void**)&W->d_rs2, sizeof(double) * (size_t)W->tot_b * m.maxc);
+  al((void**)&W->d_work, sizeof(double) * 4 * (size_t)W->tot_b);
+  al((void**)&W->d_bl, sizeof(int) * 2 * ((size_t)W->tot_b + 8 * (size_t)n_utt));
+  al((void**)&W->d_md, sizeof(double) * (size_t)W->tot_md);
+  al((void**)&W->d_sec, sizeof(int) * 3 * ((size_t)W->tot_b / 4 + 8 * (size_t)n_utt + 8));
+  al((void**)&W->d_sm, sizeof(double) * (size_t)W->tot_sm);
+  return rc;
+}
+
+void harvest_free(void* p) {
+  HarvestWs* W = (HarvestWs*)p;
+  if (!W) return;
+  for (void* q : W->owned) (void)hipFree(q);
+  delete W;
+}
+
+int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
+  if (b.total_x <= 0) return WM_ERR_BAD_ARG;
+  int rc = hv_setup(b);
+  if (rc) return rc;
+  HarvestWs& W = *(HarvestWs*)b.harvest_ws;
+  const HvMeta& m = W.m;
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int n_utt = b.n_utt;
+  if (m.r > 1) {
+    const int len_max = b.max_x_len + 2 * m.lag + 18;
+    const int blocks = (len_max + 64 * kDecChunk - 1) / (64 * kDecChunk);
+    TimedScope ts_(b.ctx, "hv_decimate");
+    (void)hipMemsetAsync(W.d_y, 0, sizeof(double) * (size_t)W.tot_y, st);
+    hipLaunchKernelGGL(hv_decim_fwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len, m,
+                       W.d_toff, W.d_tmp);
+    hipLaunchKernelGGL(hv_decim_bwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, b.d_x_len, m, W.d_toff, W.d_tmp,
+                       W.d_yoff, W.d_ylen, W.d_y);
+  } else {
+    hipLaunchKernelGGL(hv_copy_kernel, dim3(64, n_utt), dim3(256), 0, st, d_x, b.d_x_off, b.d_x_len, W.d_yoff, W.d_y);
+  }
+  hipLaunchKernelGGL(hv_mean_kernel, dim3(n_utt), dim3(256), 0, st, W.d_yoff, W.d_ylen, W.d_y);
+  {
+    TimedScope ts_(b.ctx, "hv_band_kernel");
+    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles(m.ntap_max);
+    hipLaunchKernelGGL(hv_band_kernel, dim3(m.nch, n_utt), dim3(256), lds, st, W.d_yoff, W.d_ylen, W.d_y, W.d_taps,
+                       W.d_tapoff, W.d_half, m.nch, W.d_evoff, W.d_events, W.d_evcnt);
+  }
+  const int gx = (int)((W.tot_b + 255) / 256);
+  {
+    TimedScope ts_(b.ctx, "hv_raw_kernel");
+    hipLaunchKernelGGL(hv_raw_kernel, dim3(gx, m.nch), dim3(256), 0, st, W.d_bframe_utt, W.d_boff, W.d_ylen, m,
+                       W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.d_evoff, W.d_events, W.d_evcnt, W.tot_b, W.d_raw);
+  }
+  (void)hipMemsetAsync(W.d_ncand1, 0, sizeof(int) * (size_t)n_utt, st);
+  hipLaunchKernelGGL(hv_detect_kernel, dim3(gx), dim3(256), 0, st, W.d_bframe_utt, m, W.d_raw, W.tot_b, W.d_offc,
+                     W.d_cnt, W.d_ncand1);
+  {
+    TimedScope ts_(b.ctx, "hv_refine_kernel");
+    const int lmax = 2 * (int)(1.5 * m.afs / b.p.f0_floor + 1.0) + 1;
+    const size_t lds = sizeof(double) * (size_t)(lmax + 2);
+    const int grid = (int)(W.tot_b < (int64_t)c.frame_grid ? W.tot_b : (int64_t)c.frame_grid);
+    hipLaunchKernelGGL(hv_refine_kernel, dim3(grid), dim3(64), lds, st, W.d_bframe_utt, W.d_boff, W.d_nb1, m,
+                       W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, W.tot_b, W.d_rc,
+                       W.d_rs);
+  }
+  {
+    const int64_t items = W.tot_b * m.maxc;
+    hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, W.d_bframe_utt,
+                       W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc, W.d_rs, W.tot_b, W.d_rc2, W.d_rs2);
+  }
+  {
+    TimedScope ts_(b.ctx, "hv_contour_kernel");
+    hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(256), 0, st, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc2,
+                       W.d_rs2, W.tot_b, n_utt, W.d_work, W.d_bl, W.d_mdoff, W.d_md, W.d_sec, W.d_smoff, W.d_sm,
+                       b.d_f_off, b.p.frame_period, d_t, d_f0);
+  }
+  return wm_check(hipGetLastError());
+}
+
 }  // namespace wm

@@ -225,3 +225,33 @@ def test_full_size_properties(gpu, oracle):
         np.testing.assert_allclose(apn[g], r["ap"], atol=AP_TOL, rtol=0)
         np.testing.assert_allclose(yn[b.out_offsets[u]:b.out_offsets[u + 1]], r["y"], atol=Y_TOL, rtol=0)
     b.close()
+
+
+@pytest.mark.parametrize("fs,fp,idxs,dur", [(16000, 5.0, [3, 6], (1.0, 2.0)), (48000, 1.0, [4, 8], (0.8, 1.6)),
+                                             (22050, 5.0, [7], (1.2, 1.2)), (8000, 5.0, [14], (1.5, 1.5))])
+def test_harvest_against_oracle(gpu, oracle, fs, fp, idxs, dur):
+    """BASELINE config 3 shape (Harvest, 48 kHz, 1 ms) and friends; parity on f0 only."""
+    torch, W, ctx = gpu
+    xs = [sd.make_utterance(i, fs, dur) for i in idxs]
+    b = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(x) for x in xs])
+    t, f0 = b.harvest(torch.from_numpy(np.concatenate(xs)).cuda())
+    ro = [oracle.harvest(x, fs, fp) for x in xs]
+    np.testing.assert_array_equal(t.cpu().numpy(), np.concatenate([r[0] for r in ro]))
+    fo = np.concatenate([r[1] for r in ro])
+    f0 = f0.cpu().numpy()
+    assert ((f0 > 0) == (fo > 0)).all()
+    assert np.abs(f0 - fo).max() < 0.1          # the bar
+    np.testing.assert_allclose(f0, fo, atol=F0_TOL, rtol=0)
+    b.close()
+
+
+def test_harvest_golden_and_c_api(pkg):
+    g = np.load(os.path.join(GOLDEN, "harvest_48k_1ms.npz"))
+    x = sd.make_utterance(int(g["index"]), int(g["fs"]), duration=float(g["duration"]))
+    t, f0 = pkg.capi.harvest(x, int(g["fs"]), float(g["frame_period"]))
+    np.testing.assert_array_equal(t, g["t"])
+    np.testing.assert_allclose(f0, g["f0"], atol=F0_TOL, rtol=0)
+    g = np.load(os.path.join(GOLDEN, "harvest_16k.npz"))
+    x = sd.make_utterance(int(g["index"]), int(g["fs"]), duration=float(g["duration"]))
+    t, f0 = pkg.capi.harvest(x, int(g["fs"]), float(g["frame_period"]))
+    np.testing.assert_allclose(f0, g["f0"], atol=F0_TOL, rtol=0)
