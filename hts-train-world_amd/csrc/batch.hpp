@@ -79,6 +79,12 @@ struct Batch {
   double* d_dio_win = nullptr;       // Nuttall low-pass windows, all bands
   int* d_dio_fft = nullptr;          // [n_utt] the reference's fft_size (circular indexing)
   double* d_dio_ws = nullptr;        // [3][total_f] contour work arrays
+  int* d_dio_ylen = nullptr;         // [n_utt] y_length = 1 + N / speed
+  double* d_dio_y = nullptr;         // decimated signals (speed > 1)
+  double* d_dio_tmp = nullptr;       // decimation pass-1 output
+  int64_t* d_dio_yoff = nullptr;
+  int64_t* d_dio_toff = nullptr;
+  int64_t dio_tot_y = 0;
   int dio_bands = 0;
   double* d_dio_mean = nullptr;      // [n_utt]
   double* d_dio_z = nullptr;         // low-cut output, per utterance y_len + 2*pad

@@ -19,6 +19,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "decimate.hpp"
 #include "zcfilter.hpp"
 
 namespace wm {
@@ -36,19 +37,22 @@ struct DioMeta {
   double afs;                   // actual_fs
 };
 
-__global__ __launch_bounds__(256) void dio_mean_kernel(const double* __restrict__ x,
-                                                       const int64_t* __restrict__ x_off,
-                                                       const int* __restrict__ x_len, double* __restrict__ mean) {
+// src is x itself (speed 1: y_length = N + 1, the extra sample is zero) or the decimated signal
+// (speed > 1: all y_length samples materialised, zeros beyond decimate's output).
+__global__ __launch_bounds__(256) void dio_mean_kernel(const double* __restrict__ src,
+                                                       const int64_t* __restrict__ src_off,
+                                                       const int* __restrict__ src_len,
+                                                       const int* __restrict__ ylen_a, double* __restrict__ mean) {
   __shared__ double part[4];
   const int u = blockIdx.x;
-  const double* xu = x + x_off[u];
-  const int n = x_len[u];
+  const double* xu = src + src_off[u];
+  const int n = src_len[u];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += xu[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) mean[u] = (part[0] + part[1] + part[2] + part[3]) / (n + 1);   // y_length = N + 1
+  if (threadIdx.x == 0) mean[u] = (part[0] + part[1] + part[2] + part[3]) / ylen_a[u];   // dio.cpp:74-77
 }
 
 // circular, zero-padded, mean-removed signal of the reference (dio.cpp:63-79)
@@ -64,11 +68,11 @@ __device__ __forceinline__ double dio_y(const double* __restrict__ xu, int n, in
 constexpr int kLcTile = 1024;
 __global__ __launch_bounds__(256) void dio_lowcut_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
-    const double* __restrict__ mean, const int* __restrict__ fft_sizes, const double* __restrict__ lowcut,
-    DioMeta meta, const int64_t* __restrict__ z_off, double* __restrict__ z) {
+    const int* __restrict__ ylen_a, const double* __restrict__ mean, const int* __restrict__ fft_sizes,
+    const double* __restrict__ lowcut, DioMeta meta, const int64_t* __restrict__ z_off, double* __restrict__ z) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int u = blockIdx.y;
-  const int n = x_len[u], ylen = n + 1, fftn = fft_sizes[u];
+  const int n = x_len[u], ylen = ylen_a[u], fftn = fft_sizes[u];
   const int cut = meta.cut, ntap = 2 * cut + 1;
   const int total = ylen + 2 * meta.pad;
   const int m0 = blockIdx.x * kLcTile;              // tile start in z-storage coordinates
@@ -100,12 +104,12 @@ __global__ __launch_bounds__(256) void dio_lowcut_kernel(
 // ZeroCrossingEngine passes (dio.cpp:296-435), see zcfilter.hpp.
 // events layout per (utt, band): 4 lists of `cap` fine edges.
 __global__ __launch_bounds__(256) void dio_band_kernel(
-    const int* __restrict__ x_len, const int64_t* __restrict__ z_off, const double* __restrict__ z,
+    const int* __restrict__ ylen_a, const int64_t* __restrict__ z_off, const double* __restrict__ z,
     const double* __restrict__ win, DioMeta meta, const int64_t* __restrict__ ev_off,
     double* __restrict__ events, int* __restrict__ ev_cnt) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int u = blockIdx.y, band = blockIdx.x;
-  const int ylen = x_len[u] + 1;
+  const int ylen = ylen_a[u];
   const int hal = meta.hal[band];
   const int cap = ylen / 2 + 2;
   // filtered[n] = sum_{k < 4 hal} w[k] z[n + 2 hal - k]  (dio.cpp:310-337)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void dio_band_kernel(
 }
 
 __global__ __launch_bounds__(256) void dio_candidate_kernel(
-    const int* __restrict__ x_len, const int64_t* __restrict__ f_off, const int* __restrict__ frame_utt,
+    const int* __restrict__ ylen_a, const int64_t* __restrict__ f_off, const int* __restrict__ frame_utt,
     double frame_period, DioMeta meta, double f0_floor, double f0_ceil,
     const int64_t* __restrict__ ev_off, const double* __restrict__ events, const int* __restrict__ ev_cnt,
     int64_t total_frames, double* __restrict__ cand, double* __restrict__ score) {
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void dio_candidate_kernel(
   const int64_t frame = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (frame >= total_frames) return;
   const int u = frame_utt[frame];
-  const int ylen = x_len[u] + 1;
+  const int ylen = ylen_a[u];
   const int cap = ylen / 2 + 2;
   const int* cnt = ev_cnt + ((int64_t)u * meta.nb + band) * 4;
   const double* ev = events + ev_off[u] + (int64_t)band * 4 * cap;
@@ -272,7 +276,6 @@ static int dio_setup(Batch& b) {
   m.nb = 1 + (int)(log(p.f0_ceil / p.f0_floor) / kLog2 * p.channels_in_octave);      // dio.cpp:582-583
   if (m.nb < 1 || m.nb > kMaxBands) { delete H; return WM_ERR_UNSUPPORTED; }
   m.ratio = imax(imin(p.speed, 12), 1);                                                // :589
-  if (m.ratio != 1) { delete H; return WM_ERR_UNSUPPORTED; }                           // decimation: TODO
   m.afs = (double)p.fs / m.ratio;
   int woff = 0;
   for (int i = 0; i < m.nb; ++i) {
@@ -307,11 +310,15 @@ static int dio_setup(Batch& b) {
     H->lowcut[(size_t)m.cut] += 1.0;
   }
   // per-utterance FFT size of the reference's circular convolution (dio.cpp:590-593)
-  std::vector<int> fftn((size_t)b.n_utt);
+  std::vector<int> fftn((size_t)b.n_utt), ylens((size_t)b.n_utt);
+  std::vector<int64_t> yoff((size_t)b.n_utt + 1, 0), toff((size_t)b.n_utt + 1, 0);
   b.dio_z_off.assign((size_t)b.n_utt + 1, 0);
   b.dio_ev_off.assign((size_t)b.n_utt + 1, 0);
   for (int u = 0; u < b.n_utt; ++u) {
-    const int ylen = 1 + b.x_len[u] / m.ratio;
+    const int ylen = 1 + b.x_len[u] / m.ratio;                                          // dio.cpp:590
+    ylens[(size_t)u] = ylen;
+    yoff[(size_t)u + 1] = yoff[(size_t)u] + ylen;
+    toff[(size_t)u + 1] = toff[(size_t)u] + b.x_len[u] + 18;
     fftn[(size_t)u] = suitable_fft_size(ylen + 4 * (int)(1.0 + m.afs / m.boundary[0] / 2.0));
     b.dio_z_off[(size_t)u + 1] = b.dio_z_off[(size_t)u] + ylen + 2 * m.pad;
     b.dio_ev_off[(size_t)u + 1] = b.dio_ev_off[(size_t)u] + (int64_t)m.nb * 4 * (ylen / 2 + 2);
@@ -325,6 +332,12 @@ static int dio_setup(Batch& b) {
   up((void**)&b.d_dio_lowcut, H->lowcut.data(), sizeof(double) * H->lowcut.size());
   up((void**)&b.d_dio_win, H->win.data(), sizeof(double) * H->win.size());
   up((void**)&b.d_dio_fft, fftn.data(), sizeof(int) * fftn.size());
+  up((void**)&b.d_dio_ylen, ylens.data(), sizeof(int) * ylens.size());
+  if (m.ratio > 1) {
+    up((void**)&b.d_dio_yoff, yoff.data(), sizeof(int64_t) * yoff.size());
+    up((void**)&b.d_dio_toff, toff.data(), sizeof(int64_t) * toff.size());
+    b.dio_tot_y = yoff[(size_t)b.n_utt];
+  }
   up((void**)&b.d_dio_z_off, b.dio_z_off.data(), sizeof(int64_t) * b.dio_z_off.size());
   up((void**)&b.d_dio_ev_off, b.dio_ev_off.data(), sizeof(int64_t) * b.dio_ev_off.size());
   auto al = [&](void** dst, size_t bytes) {
@@ -332,6 +345,10 @@ static int dio_setup(Batch& b) {
     rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
   };
   al((void**)&b.d_dio_mean, sizeof(double) * (size_t)b.n_utt);
+  if (m.ratio > 1) {
+    al((void**)&b.d_dio_y, sizeof(double) * (size_t)yoff[(size_t)b.n_utt]);
+    al((void**)&b.d_dio_tmp, sizeof(double) * (size_t)toff[(size_t)b.n_utt]);
+  }
   al((void**)&b.d_dio_z, sizeof(double) * (size_t)b.dio_z_off[(size_t)b.n_utt]);
   al((void**)&b.d_dio_events, sizeof(double) * (size_t)b.dio_ev_off[(size_t)b.n_utt]);
   al((void**)&b.d_dio_ev_cnt, sizeof(int) * (size_t)b.n_utt * m.nb * 4);
@@ -352,25 +369,41 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const DioMeta& m = ((DioHost*)b.dio_host)->meta;
-  hipLaunchKernelGGL(dio_mean_kernel, dim3(b.n_utt), dim3(256), 0, st, d_x, b.d_x_off, b.d_x_len, b.d_dio_mean);
+  // speed > 1: decimate first (dio.cpp:68-70); the rest of the chain then reads the decimated signal
+  const double* src = d_x;
+  const int64_t* src_off = b.d_x_off;
+  const int* src_len = b.d_x_len;
+  if (m.ratio > 1) {
+    const DecMeta dm = make_dec_meta(m.ratio, 0);
+    const int len_max = b.max_x_len + 18;
+    const int blocks = (len_max + 64 * kDecChunk - 1) / (64 * kDecChunk);
+    (void)hipMemsetAsync(b.d_dio_y, 0, sizeof(double) * (size_t)b.dio_tot_y, st);
+    hipLaunchKernelGGL(decim_fwd_kernel, dim3(blocks, b.n_utt), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len, dm,
+                       b.d_dio_toff, b.d_dio_tmp);
+    hipLaunchKernelGGL(decim_bwd_kernel, dim3(blocks, b.n_utt), dim3(64), 0, st, b.d_x_len, dm, b.d_dio_toff,
+                       b.d_dio_tmp, b.d_dio_yoff, b.d_dio_ylen, b.d_dio_y);
+    src = b.d_dio_y; src_off = b.d_dio_yoff; src_len = b.d_dio_ylen;
+  }
+  hipLaunchKernelGGL(dio_mean_kernel, dim3(b.n_utt), dim3(256), 0, st, src, src_off, src_len, b.d_dio_ylen,
+                     b.d_dio_mean);
   {
-    const int total_max = b.max_x_len + 1 + 2 * m.pad;
+    const int total_max = b.max_x_len / m.ratio + 1 + 2 * m.pad;
     const int tiles = (total_max + kLcTile - 1) / kLcTile;
     const size_t lds = sizeof(double) * (size_t)(kLcTile + 2 * m.cut + 2 * m.cut + 1);
     TimedScope ts_(b.ctx, "dio_lowcut_kernel");
-    hipLaunchKernelGGL(dio_lowcut_kernel, dim3(tiles, b.n_utt), dim3(256), lds, st, d_x, b.d_x_off, b.d_x_len,
-                       b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
+    hipLaunchKernelGGL(dio_lowcut_kernel, dim3(tiles, b.n_utt), dim3(256), lds, st, src, src_off, src_len,
+                       b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
   }
   {
     const size_t lds = sizeof(double) * (size_t)zc_lds_doubles(4 * m.hal[0]);
     TimedScope ts_(b.ctx, "dio_band_kernel");
-    hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_x_len, b.d_dio_z_off,
+    hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_dio_ylen, b.d_dio_z_off,
                        b.d_dio_z, b.d_dio_win, m, b.d_dio_ev_off, b.d_dio_events, b.d_dio_ev_cnt);
   }
   {
     const int gx = (int)((b.total_f + 255) / 256);
     TimedScope ts_(b.ctx, "dio_candidate_kernel");
-    hipLaunchKernelGGL(dio_candidate_kernel, dim3(gx, m.nb), dim3(256), 0, st, b.d_x_len, b.d_f_off,
+    hipLaunchKernelGGL(dio_candidate_kernel, dim3(gx, m.nb), dim3(256), 0, st, b.d_dio_ylen, b.d_f_off,
                        b.d_frame_utt, b.p.frame_period, m, b.p.f0_floor, b.p.f0_ceil, b.d_dio_ev_off, b.d_dio_events,
                        b.d_dio_ev_cnt, b.total_f, b.d_dio_cand, b.d_dio_score);
   }

@@ -25,6 +25,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "decimate.hpp"
 #include "fft.hpp"
 #include "zcfilter.hpp"
 
@@ -40,7 +41,6 @@ struct HvMeta {
   int cpf;          // candidates per frame before overlap = matlab_round(nch / 10.0)
   int maxc;         // max_candidates = cpf * 7 (:1180-1181)
   int ntap_max;
-  double a0, a1, a2, b0, b1;   // decimation IIR (matlabfunctions.cpp:27-113)
 };
 
 struct HarvestWs {
@@ -64,80 +64,6 @@ struct HarvestWs {
   double* d_sm = nullptr;                      // smoothing scratch
   std::vector<void*> owned;
 };
-
-// ---- decimation ---------------------------------------------------------------------------
-__device__ __forceinline__ double hv_nx(const double* __restrict__ x, int n, int lag, int j) {
-  // new_x of GetWaveformAndSpectrumSub (harvest.cpp:55-59): x edge-padded by lag samples
-  return x[imin(n - 1, imax(0, j - lag))];
-}
-__device__ __forceinline__ double hv_dec_in(const double* __restrict__ x, int n, int lag, int nn, int i) {
-  // tmp1 of decimate (matlabfunctions.cpp:189-192): new_x reflect-padded by 9 samples
-  if (i < 9) return 2 * hv_nx(x, n, lag, 0) - hv_nx(x, n, lag, 9 - i);
-  if (i >= 9 + nn) return 2 * hv_nx(x, n, lag, nn - 1) - hv_nx(x, n, lag, nn - 2 - (i - (9 + nn)));
-  return hv_nx(x, n, lag, i - 9);
-}
-
-constexpr int kDecChunk = 256, kDecWarm = 512;
-
-// pass 1: tmp2[i] = IIR(tmp1)[i]
-__global__ __launch_bounds__(64) void hv_decim_fwd_kernel(const double* __restrict__ x,
-                                                          const int64_t* __restrict__ x_off,
-                                                          const int* __restrict__ x_len, HvMeta m,
-                                                          const int64_t* __restrict__ toff,
-                                                          double* __restrict__ tmp) {
-#pragma clang fp contract(off)
-  const int u = blockIdx.y;
-  const int n = x_len[u], nn = n + 2 * m.lag, len = nn + 18;
-  const int c0 = (blockIdx.x * 64 + threadIdx.x) * kDecChunk;
-  if (c0 >= len) return;
-  const double* xu = x + x_off[u];
-  double* out = tmp + toff[u];
-  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  const int start = imax(0, c0 - kDecWarm);
-  const int end = imin(len, c0 + kDecChunk);
-  for (int i = start; i < end; ++i) {
-    const double wt = hv_dec_in(xu, n, m.lag, nn, i) + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
-    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
-    w2 = w1; w1 = w0; w0 = wt;
-    if (i >= c0) out[i] = o;
-  }
-}
-
-// pass 2 on the reversed pass-1 output; only the decimated samples are kept:
-// y[c] = tmp1_final[nbeg + c r + 8] (matlabfunctions.cpp:201-206), then y[lag/r + i] (harvest.cpp:62)
-__global__ __launch_bounds__(64) void hv_decim_bwd_kernel(const int* __restrict__ x_len, HvMeta m,
-                                                          const int64_t* __restrict__ toff,
-                                                          const double* __restrict__ tmp,
-                                                          const int64_t* __restrict__ yoff,
-                                                          const int* __restrict__ ylen_a, double* __restrict__ y) {
-#pragma clang fp contract(off)
-  const int u = blockIdx.y;
-  const int n = x_len[u], nn = n + 2 * m.lag, len = nn + 18;
-  const int c0 = (blockIdx.x * 64 + threadIdx.x) * kDecChunk;
-  if (c0 >= len) return;
-  const double* in = tmp + toff[u];
-  double* yu = y + yoff[u];
-  const int ylen = ylen_a[u];
-  const int nout = (nn - 1) / m.r + 1;
-  const int nbeg = m.r - m.r * nout + nn;
-  const int shift = m.lag / m.r;
-  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  const int start = imax(0, c0 - kDecWarm);
-  const int end = imin(len, c0 + kDecChunk);
-  for (int i = start; i < end; ++i) {
-    const double wt = in[len - 1 - i] + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
-    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
-    w2 = w1; w1 = w0; w0 = wt;
-    if (i >= c0) {
-      const int j = len - 1 - i;                 // index in the final (re-reversed) array
-      const int q = j - 8 - nbeg;                // = c * r
-      if (q >= 0 && q % m.r == 0 && q + nbeg < nn + 9) {
-        const int c = q / m.r - shift;
-        if (c >= 0 && c < ylen) yu[c] = o;
-      }
-    }
-  }
-}
 
 __global__ __launch_bounds__(256) void hv_copy_kernel(const double* __restrict__ x,
                                                       const int64_t* __restrict__ x_off,
@@ -677,33 +603,6 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
 }
 
 // ---- host side ------------------------------------------------------------------------------
-static const double kDecA[13][3] = {
-    {0, 0, 0}, {0, 0, 0},
-    {0.041156734567757189, -0.42599112459189636, 0.041037215479961225},
-    {0.95039378983237421, -0.67429146741526791, 0.15412211621346475},
-    {1.4499664446880227, -0.98943497080950582, 0.24578252340690215},
-    {1.7610939654280557, -1.2554914843859768, 0.3237186507788215},
-    {1.9715352749512141, -1.4686795689225347, 0.3893908434965701},
-    {2.1225239019534703, -1.6395144861046302, 0.44469707800587366},
-    {2.2357462340187593, -1.7780899984041358, 0.49152555365968692},
-    {2.3236003491759578, -1.8921545617463598, 0.53148928133729068},
-    {2.3936475118069387, -1.9873904075111861, 0.5658879979027055},
-    {2.450743295230728, -2.06794904601978, 0.59574774438332101},
-    {2.4981398605924205, -2.1368928194784025, 0.62187513816221485}};
-static const double kDecB[13][2] = {
-    {0, 0}, {0, 0},
-    {0.16797464681802227, 0.50392394045406674},
-    {0.071221945171178636, 0.21366583551353591},
-    {0.036710750339322612, 0.11013225101796784},
-    {0.021334858522387423, 0.06400457556716227},
-    {0.013469181309343825, 0.040407543928031475},
-    {0.0090366882681608418, 0.027110064804482525},
-    {0.0063522763407111993, 0.019056829022133598},
-    {0.0046331164041389372, 0.013899349212416812},
-    {0.0034818622251927556, 0.010445586675578267},
-    {0.0026822508007163792, 0.0080467524021491377},
-    {0.0021097275904709001, 0.0063291827714127002}};
-
 static int hv_setup(Batch& b) {
   if (b.harvest_ws) return WM_OK;
   HarvestWs* W = new HarvestWs();
@@ -717,8 +616,6 @@ static int hv_setup(Batch& b) {
   m.lag = m.r == 1 ? 0 : (int)(ceil(140.0 / m.r) * m.r);
   m.cpf = matlab_round(m.nch / 10.0);
   m.maxc = m.cpf * kHvOverlap;
-  m.a0 = kDecA[m.r][0]; m.a1 = kDecA[m.r][1]; m.a2 = kDecA[m.r][2];
-  m.b0 = kDecB[m.r][0]; m.b1 = kDecB[m.r][1];
   std::vector<double> bf((size_t)m.nch), taps;
   std::vector<int> half((size_t)m.nch), tapoff((size_t)m.nch);
   m.ntap_max = 0;
@@ -824,9 +721,10 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     const int blocks = (len_max + 64 * kDecChunk - 1) / (64 * kDecChunk);
     TimedScope ts_(b.ctx, "hv_decimate");
     (void)hipMemsetAsync(W.d_y, 0, sizeof(double) * (size_t)W.tot_y, st);
-    hipLaunchKernelGGL(hv_decim_fwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len, m,
+    const DecMeta dm = make_dec_meta(m.r, m.lag);
+    hipLaunchKernelGGL(decim_fwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len, dm,
                        W.d_toff, W.d_tmp);
-    hipLaunchKernelGGL(hv_decim_bwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, b.d_x_len, m, W.d_toff, W.d_tmp,
+    hipLaunchKernelGGL(decim_bwd_kernel, dim3(blocks, n_utt), dim3(64), 0, st, b.d_x_len, dm, W.d_toff, W.d_tmp,
                        W.d_yoff, W.d_ylen, W.d_y);
   } else {
     hipLaunchKernelGGL(hv_copy_kernel, dim3(64, n_utt), dim3(256), 0, st, d_x, b.d_x_off, b.d_x_len, W.d_yoff, W.d_y);

@@ -255,3 +255,24 @@ def test_harvest_golden_and_c_api(pkg):
     x = sd.make_utterance(int(g["index"]), int(g["fs"]), duration=float(g["duration"]))
     t, f0 = pkg.capi.harvest(x, int(g["fs"]), float(g["frame_period"]))
     np.testing.assert_allclose(f0, g["f0"], atol=F0_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("kw", [dict(speed=2), dict(speed=4), dict(speed=11), dict(speed=12, frame_period=10.0),
+                                dict(f0_floor=50.0, f0_ceil=600.0), dict(channels_in_octave=4.0, allowed_range=0.05),
+                                dict(frame_period=1.0)])
+def test_dio_option_sweep(gpu, oracle, kw):
+    """DioOption fields (dio.h:16-23), including the decimated speeds (dio.cpp:68-70, :589-591)."""
+    torch, W, ctx = gpu
+    fs = 16000 if kw.get("speed", 1) < 8 else 48000
+    xs = [sd.make_utterance(40, fs, duration=0.9), sd.make_utterance(41, fs, duration=1.3)]
+    fp = kw.get("frame_period", 5.0)
+    p = W.default_params(fs, fp, **{k: v for k, v in kw.items() if k != "frame_period"})
+    b = W.WorldBatch(ctx, p, x_lengths=[len(x) for x in xs])
+    t, f0 = b.dio(torch.from_numpy(np.concatenate(xs)).cuda())
+    ro = [oracle.dio(x, fs, fp, kw.get("f0_floor", 71.0), kw.get("f0_ceil", 800.0),
+                     kw.get("channels_in_octave", 2.0), kw.get("speed", 1), kw.get("allowed_range", 0.1)) for x in xs]
+    np.testing.assert_array_equal(t.cpu().numpy(), np.concatenate([r[0] for r in ro]))
+    fo = np.concatenate([r[1] for r in ro])
+    assert ((f0.cpu().numpy() > 0) == (fo > 0)).all()
+    np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+    b.close()
