@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=48, help="utterances of the CPU baseline sample")
     ap.add_argument("--workers", type=int, default=0, help="processes for synthetic data generation (0 = auto)")
+    ap.add_argument("--workload", choices=["analysis_synthesis", "harvest", "synthesis"], default="analysis_synthesis",
+                    help="analysis_synthesis = configs[1] (the headline metric); harvest = configs[2] (48 kHz, 1 ms, "
+                         "64 utterances); synthesis = configs[4] (Synthesis only from precomputed features)")
     return ap.parse_args()
 
 
@@ -72,6 +75,8 @@ def main():
     pkg = importlib.import_module("hts-train-world_amd")
     W, sd, sh = pkg.world, pkg.synth_data, pkg.sharding
     fs, fp = 16000, 5.0
+    if args.workload != "analysis_synthesis":
+        return side_workload(args, torch, dist, W, sd, rank, world)
 
     # ---- synthetic workload (not timed) ----
     ncpu = os.cpu_count() or 1
@@ -170,6 +175,90 @@ def main():
         }
         if parity:
             line["parity"] = parity
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def side_workload(args, torch, dist, W, sd, rank, world):
+    """configs[2] (Harvest) and configs[4] (Synthesis only): same contract, separate metric names."""
+    ncpu = os.cpu_count() or 1
+    workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
+    if args.workload == "harvest":
+        fs, fp = 48000, 1.0
+        utts = args.utts if args.utts != 256 else 64
+    else:
+        fs, fp = 16000, 5.0
+        utts = args.utts if args.utts != 256 else 1024
+    xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+    batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(v) for v in xs])
+    frames = int(batch.total_frames)
+    if args.workload == "harvest":
+        names = ("hv_decimate", "hv_band_kernel", "hv_raw_kernel", "hv_refine_kernel", "hv_contour_kernel")
+        step = lambda: batch.harvest(x)
+    else:
+        t, f0, sp, ap = batch.analyze(x)
+        y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
+        names = ("synth_timebase_kernel", "synth_pulse_kernel", "synth_ola_kernel")
+        step = lambda: batch.synthesize(f0, sp, ap, out=y)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms = {k: ctx.timing_query(k)[0] / args.steps for k in names}
+    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax, tsum = tt.clone(), tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total = float(tmax[0]), float(tsum[1])
+    else:
+        total = float(frames)
+    if rank == 0:
+        value = total * args.steps / elapsed
+        bpf = 400 if args.workload == "harvest" else 8856          # SURVEY.md section 8d
+        line = {"metric": "WORLD %s frames/sec" % ("Harvest @48kHz, 1ms hop" if args.workload == "harvest"
+                                                    else "Synthesis-only @16kHz, 5ms hop"),
+                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "configs[%d]: %d synthetic utterances (%g-%g s) per GPU, fs %d, hop %g ms"
+                                       % (2 if args.workload == "harvest" else 4, utts, args.dur[0], args.dur[1], fs, fp),
+                           "frames_per_gpu": frames},
+                "roofline": {"bound": "hbm", "achieved": round(value / world * bpf / 1e9, 3), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(value / world * bpf / 1e9 / HBM_PEAK_GBS, 7),
+                             "traffic": None, "bytes_per_unit": bpf, "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
+                "cpu_baseline": None}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "harvest":
+            from oracle.bindings import Oracle, Reference
+            lib = Reference() if Reference.available() else Oracle()
+            got = batch.harvest(x)[1].cpu().numpy()
+            nfr, tcpu, df0 = 0, 0.0, 0.0
+            for u in range(min(len(xs), 6)):
+                a = time.perf_counter()
+                tc, fc = lib.harvest(xs[u], fs, fp)
+                tcpu += time.perf_counter() - a
+                nfr += len(fc)
+                df0 = max(df0, float(np.abs(got[batch.frame_offsets[u]:batch.frame_offsets[u + 1]] - fc).max()))
+                if tcpu > 30:
+                    break
+            line["cpu_baseline"] = {"value": round(nfr / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
+                                    "sample": "first utterances of the same batch (%d frames), %.1f s" % (nfr, tcpu)}
+            line["parity"] = {"vs": lib.kind, "max_abs_dF0_hz": df0}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
