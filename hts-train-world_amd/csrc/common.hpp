@@ -32,38 +32,57 @@ __device__ __forceinline__ double randn_at(const uint32_t* __restrict__ tab, int
 }
 
 // ---- wavefront collectives (64 lanes) ----------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Built on DPP row shifts / row broadcasts (gfx9 family) instead of ds_bpermute shuffles: six
+// dependent VALU steps with no LDS round trip.  The six steps are a complete inclusive scan over
+// the 64 lanes, so the same sequence serves sums, maxima (lane 63 holds the total, broadcast with
+// v_readlane) and prefix sums.  Lanes that receive no source read 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true);
+  return __hiloint2double(hi2, lo2);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_get_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+__device__ __forceinline__ double lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum across lanes (lane argument kept for call-site compatibility)
+__device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/ = 0) {
+  v += dpp_get<0x111, 0xf, 0xf>(v);      // row_shr:1
+  v += dpp_get<0x112, 0xf, 0xf>(v);      // row_shr:2
+  v += dpp_get<0x114, 0xf, 0xf>(v);      // row_shr:4
+  v += dpp_get<0x118, 0xf, 0xf>(v);      // row_shr:8
+  v += dpp_get<0x142, 0xa, 0xf>(v);      // row_bcast:15 -> rows 1, 3
+  v += dpp_get<0x143, 0xc, 0xf>(v);      // row_bcast:31 -> rows 2, 3
   return v;
 }
+__device__ __forceinline__ double wave_sum(double v) { return lane63(wave_scan_incl(v)); }
+// maximum of NON-NEGATIVE values (lanes without a DPP source contribute 0)
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  v = fmax(v, dpp_get<0x111, 0xf, 0xf>(v));
+  v = fmax(v, dpp_get<0x112, 0xf, 0xf>(v));
+  v = fmax(v, dpp_get<0x114, 0xf, 0xf>(v));
+  v = fmax(v, dpp_get<0x118, 0xf, 0xf>(v));
+  v = fmax(v, dpp_get<0x142, 0xa, 0xf>(v));
+  v = fmax(v, dpp_get<0x143, 0xc, 0xf>(v));
+  return lane63(v);
+}
+__device__ __forceinline__ int wave_scan_incl_i(int v, int /*lane*/ = 0) {
+  v += dpp_get_i<0x111, 0xf, 0xf>(v);
+  v += dpp_get_i<0x112, 0xf, 0xf>(v);
+  v += dpp_get_i<0x114, 0xf, 0xf>(v);
+  v += dpp_get_i<0x118, 0xf, 0xf>(v);
+  v += dpp_get_i<0x142, 0xa, 0xf>(v);
+  v += dpp_get_i<0x143, 0xc, 0xf>(v);
   return v;
 }
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-// inclusive prefix sum across lanes
-__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-__device__ __forceinline__ int wave_scan_incl_i(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
+__device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_scan_incl_i(v), 63); }
 
 // interp1Q on an LDS array (matlabfunctions.cpp:220-241): y has n entries,
 // delta_y[n-1] := 0.

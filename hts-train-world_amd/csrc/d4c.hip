@@ -8,7 +8,13 @@
 // The std::sort of d4c.cpp:215 only feeds "sum of all but the (boundary+1)
 // largest bins"; here the largest bins are peeled off by repeated wave-wide max
 // and the rest summed directly (no sort).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "batch.hpp"
+#include "bcommon.hpp"
+#include "bfft.hpp"
 #include "common.hpp"
 #include "fft.hpp"
 #include "window.hpp"
@@ -129,12 +135,346 @@ struct D4CTables {
 };
 
 // FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
-template <int FD>
-__global__ __launch_bounds__(64, 2) void d4c_kernel(
+// Variant B: one 256-thread workgroup per frame (bfft.hpp / bcommon.hpp): each thread owns the bins
+// tid + 256 q of every spectrum-domain array and one radix-4 butterfly of every FFT pass.
+template <int FD, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
-    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap) {
+    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap,
+    int dbg) {
+  constexpr int NW = 4, NT = 64 * NW;
+  constexpr int N = FD / 2, H = FD / 2;
+  constexpr int QB = (H + 1 + NT - 1) / NT;        // bins per thread
+  constexpr int QS = FD / NT;                      // time samples per thread
+  constexpr int kA = H + 2;
+  constexpr int kBMax = FD / 16;
+  constexpr int kImg = 2 * (N + 1);
+  constexpr int kMain = kImg > (kA + H + 2 * kBMax + 2) ? kImg : (kA + H + 2 * kBMax + 2);
+  constexpr int kTopMax = 80;                      // >= boundary + 1 (22 at 16 kHz, 65 at 48 kHz)
+  __shared__ __attribute__((aligned(16))) double smem[kMain + (NW + 1) * kTopMax + 2 * NW + 8];
+  double* arr = smem;                         // [H+1] spectrum-domain array
+  double* seg = smem + kA;                    // scan / DC scratch
+  cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image / time-domain frame (aliases both)
+  double* top = smem + kMain;                 // [NW][kTopMax] per-wave largest bins, then [kTopMax] global
+  double* gtop = top + NW * kTopMax;
+  double* red = gtop + kTopMax;               // [NW] reduction scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  BFft<N, NT> bf;
+  bf.init(tid);
+  const int out_bins = out_fft / 2 + 1;
+
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    double* row = ap + frame * (int64_t)out_bins;
+    const double f0v = f0[frame];
+    bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
+    const double cf0 = f0v > kFloorF0D4C ? f0v : kFloorF0D4C;         // d4c.cpp:381
+    // LDS capacity guard for the smoothing scratch (width = f0 is the widest): f0 < fs/16
+    if (run && (int)(cf0 * FD / fs) + 1 > kBMax) run = false;
+    if (!run) {
+      for (int i = tid; i < out_bins; i += NT) row[i] = 1.0 - kSafe;  // d4c.cpp:318-323
+      continue;
+    }
+    const int u = frame_utt[frame];
+    const double* xu = x + x_off[u];
+    const int xl = x_len[u];
+    const double pos = tpos[frame];
+    const int roff = rng_off[frame];
+    const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
+    __syncthreads();
+
+    // All three analysis windows of this frame (two Blackman centroid frames, one Hann power
+    // frame; d4c.cpp:94-95, :152-153) span 4 periods, so they share cos(pi a (i - hw)):
+    // generate it once per frame and keep this thread's QS samples in registers.
+    const int hw = matlab_round(4.0 * fs / cf0 / 2.0);            // d4c.cpp:55-56
+    const int L = 2 * hw + 1;
+    double cw[QS];
+    {
+      CosGen g;
+      g.init(2.0 * cf0 / (4.0 * fs), tid - hw, NT);               // d4c.cpp:36-37
+#pragma unroll
+      for (int q = 0; q < QS; ++q) { cw[q] = g.c; g.next(); }
+    }
+    // windowed, dithered, mean-removed frame of GetWindowedWaveform (d4c.cpp:52-84) into fv[]
+    auto build = [&](auto type_tag, double cpos, int ro, double (&fv)[QS]) {
+      constexpr int TYPE = decltype(type_tag)::value;
+      const int origin = matlab_round(cpos * fs + 0.001);
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        const int i = tid + NT * q;
+        fv[q] = 0.0;
+        if (i < L) {
+          const double w = window_value<TYPE>(cw[q]);
+          fv[q] = xu[imin(xl - 1, imax(0, origin + i - hw))] * w + randn_at(rtab, ro + i) * kSafe;
+          s1 += fv[q];
+          s2 += w;
+        }
+      }
+      BlockOps<NW>::sum2(s1, s2, red, tid);
+      const double coef = s1 / s2;
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        const int i = tid + NT * q;
+        if (i < L) fv[q] -= window_value<TYPE>(cw[q]) * coef;
+      }
+    };
+
+    // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
+    double sc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) sc[q] = 0.0;
+#pragma unroll 1
+    for (int side = 0; side < ((dbg & 1) ? 0 : 2); ++side) {
+      const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+      double fv[QS];
+      build(std::integral_constant<int, kBlackman>{}, cpos, roff + side * Lw, fv);
+      double pwr = 0.0;                                   // d4c.cpp:96-100
+#pragma unroll
+      for (int q = 0; q < QS; ++q) pwr += fv[q] * fv[q];
+      const double nrm = sqrt(BlockOps<NW>::sum(pwr, red, tid));
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        fv[q] /= nrm;
+        smem[tid + NT * q] = fv[q];
+      }
+      bf.rfft_forward(img, tid);
+      cpx s1[QB];
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        s1[q] = k <= H ? img[k] : make_double2(0.0, 0.0);
+      }
+      __syncthreads();
+      // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
+#pragma unroll
+      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fv[q] * (tid + NT * q + 1.0);
+      bf.rfft_forward(img, tid);
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        if (k <= H) {
+          const cpx s2 = img[k];
+          sc[q] += s2.x * s1[q].x + s1[q].y * s2.y;          // d4c.cpp:113-115
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int k = tid + NT * q;
+      if (k <= H) arr[k] = sc[q];
+    }
+    __syncthreads();
+    dc_correction_blk<NT>(arr, cf0, fs, FD, seg, tid);     // d4c.cpp:139
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int k = tid + NT * q;
+      if (k <= H) sc[q] = arr[k];
+    }
+    __syncthreads();
+
+    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
+    if (!(dbg & 2)) {
+      double fv[QS];
+      build(std::integral_constant<int, kHann>{}, pos, roff + 2 * Lw, fv);
+#pragma unroll
+      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fv[q];
+      bf.rfft_forward(img, tid);
+      double p[QB];
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        p[q] = 0.0;
+        if (k <= H) {
+          const cpx s = img[k];
+          p[q] = s.x * s.x + s.y * s.y;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        if (k <= H) arr[k] = p[q];
+      }
+      __syncthreads();
+    }
+    if (!(dbg & 4)) {
+    dc_correction_blk<NT>(arr, cf0, fs, FD, seg, tid);
+    linear_smoothing_blk<NW>(arr, cf0, fs, FD, seg, arr, red, tid);
+    }
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int k = tid + NT * q;
+      if (k <= H) arr[k] = sc[q] / arr[k];
+    }
+    __syncthreads();
+    if (!(dbg & 4)) linear_smoothing_blk<NW>(arr, cf0 / 2.0, fs, FD, seg, arr, red, tid);
+    double gd[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int k = tid + NT * q;
+      gd[q] = k <= H ? arr[k] : 0.0;
+    }
+    __syncthreads();
+    if (!(dbg & 4)) linear_smoothing_blk<NW>(arr, cf0, fs, FD, seg, arr, red, tid);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int k = tid + NT * q;
+      if (k <= H) gd[q] -= arr[k];
+    }
+    __syncthreads();
+
+    // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
+    const int wl = tab.window_length;
+    const int bnd = imin(matlab_round(FD * 8.0 / wl), kTopMax - 1);
+    const int hwl = wl / 2;
+    double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int band = 0; band < ((dbg & 8) ? 0 : tab.nap); ++band) {
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        if (k <= H) arr[k] = gd[q];
+      }
+      __syncthreads();
+      const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
+      double fr[QS];
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        const int i = tid + NT * q;
+        fr[q] = i < wl ? arr[center - hwl + i] * tab.nuttall[i] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fr[q];
+      bf.rfft_forward(img, tid);
+      double p[QB];
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        const int k = tid + NT * q;
+        p[q] = -1.0;
+        if (k <= H) {
+          const cpx s = img[k];
+          p[q] = s.x * s.x + s.y * s.y;
+          tot += p[q];
+        }
+      }
+      tot = BlockOps<NW>::sum(tot, red, tid);
+      // the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220).
+      // Level 1: every wave peels its own bnd + 1 largest; level 2: wave 0 peels the union.
+      {
+        double c[QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) c[q] = p[q];
+#pragma unroll 1
+        for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
+          double mx = c[0];
+#pragma unroll
+          for (int q = 1; q < QB; ++q) mx = fmax(mx, c[q]);
+          const double wmx = wave_max(mx);
+          const unsigned long long vote = __ballot(mx == wmx);
+          const int winner = __ffsll((long long)vote) - 1;
+          if (lane == winner) {
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+              if (!done && c[q] == wmx) { c[q] = -2.0; done = true; }
+            top[wv * kTopMax + it] = wmx;
+          }
+        }
+      }
+      __syncthreads();
+      if (wv == 0) {
+        constexpr int QC = (NW * kTopMax + 63) / 64;
+        double c[QC];
+#pragma unroll
+        for (int q = 0; q < QC; ++q) {
+          const int idx = lane + 64 * q;                  // candidate (wave = idx / (bnd+1), rank = idx % (bnd+1))
+          const int w2 = idx / (bnd + 1), r2 = idx - w2 * (bnd + 1);
+          c[q] = w2 < NW ? top[w2 * kTopMax + r2] : -2.0;
+        }
+#pragma unroll 1
+        for (int it = 0; it <= bnd; ++it) {
+          double mx = c[0];
+#pragma unroll
+          for (int q = 1; q < QC; ++q) mx = fmax(mx, c[q]);
+          const double wmx = wave_max(mx);
+          const unsigned long long vote = __ballot(mx == wmx);
+          const int winner = __ffsll((long long)vote) - 1;
+          if (lane == winner) {
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+              if (!done && c[q] == wmx) { c[q] = -2.0; done = true; }
+            gtop[it] = wmx;
+          }
+        }
+      }
+      __syncthreads();
+      const double tau = gtop[bnd];                       // the (bnd+1)-th largest value
+      int n_gt = 0;
+      for (int it = 0; it <= bnd; ++it) n_gt += gtop[it] > tau ? 1 : 0;
+      const int need_eq = bnd + 1 - n_gt;                 // copies of tau among the removed bins
+      double low = 0.0, eq = 0.0;
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {
+        if (p[q] >= 0.0 && p[q] < tau) low += p[q];
+        if (p[q] == tau) eq += 1.0;
+      }
+      low = BlockOps<NW>::sum(low, red, tid);
+      eq = BlockOps<NW>::sum(eq, red, tid);
+      low += (eq - need_eq) * tau;
+      double c = 10.0 * log10(low / tot);
+      c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
+      c = c < 0.0 ? c : 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
+      __syncthreads();
+    }
+
+    // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
+    const int nk = tab.nap + 2;
+    for (int i = tid; i < out_bins; i += NT) {
+      const double f = (double)i * fs / out_fft;
+      int k = 0;                                            // #{knots <= f}
+      for (int j = 0; j < nk; ++j) {
+        double xj = j <= tab.nap ? j * kFreqInterval : fs / 2.0;
+        k += xj <= f ? 1 : 0;
+      }
+      k = k < 1 ? 1 : (k > nk - 1 ? nk - 1 : k);
+      const double x0 = (k - 1) <= tab.nap ? (k - 1) * kFreqInterval : fs / 2.0;
+      const double x1 = k <= tab.nap ? k * kFreqInterval : fs / 2.0;
+      double y0 = -60.0, y1 = -kSafe;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < tab.nap) {
+          if (k - 1 == j + 1) y0 = coarse[j];
+          if (k == j + 1) y1 = coarse[j];
+        }
+      }
+      const double s = (f - x0) / (x1 - x0);
+      const double yi = y0 + s * (y1 - y0);
+      row[i] = pow(10.0, yi / 20.0);
+    }
+    __syncthreads();
+  }
+}
+
+// FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
+// Variant A: one wavefront per frame (fft.hpp), everything in registers + 18.5 KB of LDS.
+template <int FD, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
+    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap,
+    int dbg) {
   constexpr int N = FD / 2, M = N / 64, H = FD / 2, MB = M + 1;
   constexpr int kA = H + 2;
   constexpr int kBMax = FD / 16;
@@ -173,7 +513,7 @@ __global__ __launch_bounds__(64, 2) void d4c_kernel(
 #pragma unroll
     for (int m = 0; m < MB; ++m) sc[m] = 0.0;
 #pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
+    for (int side = 0; side < ((dbg & 1) ? 0 : 2); ++side) {
       const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
       const int ro = roff + side * Lw;
       cpx v[M];
@@ -218,7 +558,7 @@ __global__ __launch_bounds__(64, 2) void d4c_kernel(
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
     double gd[MB];
-    {
+    if (!(dbg & 2)) {
       cpx v[M];
       windowed_waveform_lds<kHann, false>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
       load_packed<N>(smem, lane, v);
@@ -239,19 +579,21 @@ __global__ __launch_bounds__(64, 2) void d4c_kernel(
       if (lane == 0) arr[N] = p[M];
       __syncthreads();
     }
+    if (!(dbg & 4)) {
     dc_correction_lds(arr, cf0, fs, FD, seg, lane);
     linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+    }
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
     if (lane == 0) arr[N] = sc[M] / arr[N];
     __syncthreads();
-    linear_smoothing_lds(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
+    if (!(dbg & 4)) linear_smoothing_lds(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
     gd[M] = arr[N];
     __syncthreads();
-    linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+    if (!(dbg & 4)) linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[N];
@@ -263,7 +605,7 @@ __global__ __launch_bounds__(64, 2) void d4c_kernel(
     const int hwl = wl / 2;
     double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-    for (int band = 0; band < tab.nap; ++band) {
+    for (int band = 0; band < ((dbg & 8) ? 0 : tab.nap); ++band) {
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
       if (lane == 0) arr[N] = gd[M];
@@ -296,7 +638,7 @@ __global__ __launch_bounds__(64, 2) void d4c_kernel(
       tot = wave_sum(tot);
       // peel the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220)
 #pragma unroll 1
-      for (int it = 0; it <= bnd; ++it) {
+      for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
         double mx = p[0];
 #pragma unroll
         for (int m = 1; m < MB; ++m) mx = fmax(mx, p[m]);
@@ -407,11 +749,22 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
 #undef WM_LT_CASE
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
+  // Variant choice: the one-wavefront kernel executes about half the instructions per FFT
+  // (radix 16/8/8) and wins at fft 1024/2048 even at one wave per SIMD; at fft 4096 it spills and
+  // the workgroup-cooperative kernel takes over.  WORLD_MI355_D4C_VARIANT=wave|block overrides.
+  static const int dbg = getenv("WORLD_MI355_D4C_DBG") ? atoi(getenv("WORLD_MI355_D4C_DBG")) : 0;
+  static const char* var = getenv("WORLD_MI355_D4C_VARIANT");
+  const bool use_block = var ? (var[0] == 'b') : (FD >= 4096);
 #define WM_D4C_CASE(FF)                                                                                   \
   case FF:                                                                                                \
-    hipLaunchKernelGGL(d4c_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,            \
-                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs,        \
-                       b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap);                                   \
+    if (use_block)                                                                                        \
+      hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
+                         b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
+                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
+    else                                                                                                  \
+      hipLaunchKernelGGL((d4c_wave_kernel<FF, 1>), dim3(grid), dim3(64), 0, st, d_x, b.d_x_off,           \
+                         b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
+                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
     break;
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
