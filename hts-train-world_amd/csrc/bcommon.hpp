@@ -33,12 +33,13 @@ __device__ __forceinline__ FrameWindow windowed_waveform_blk(const double* __res
     }
     fw.scale = sqrt(BlockOps<NW>::sum(e, red, tid));
   }
+  const double inv_scale = 1.0 / fw.scale;
   g.init(fw.a, tid - fw.hw, NT);
   double s1 = 0.0, s2 = 0.0;
   for (int i = tid; i < F; i += NT) {
     double val = 0.0;
     if (i < fw.L) {
-      const double w = window_value<TYPE>(g.c) / fw.scale;
+      const double w = NORMALISE ? window_value<TYPE>(g.c) * inv_scale : window_value<TYPE>(g.c);
       val = xu[imin(xl - 1, imax(0, fw.origin + i - fw.hw))] * w + randn_at(rtab, roff + i) * kSafe;
       s1 += val;
       s2 += w;
@@ -51,7 +52,7 @@ __device__ __forceinline__ FrameWindow windowed_waveform_blk(const double* __res
   fw.coef = t1 / t2;
   g.init(fw.a, tid - fw.hw, NT);
   for (int i = tid; i < fw.L; i += NT) {       // own samples only
-    wav[i] -= window_value<TYPE>(g.c) / fw.scale * fw.coef;
+    wav[i] -= (NORMALISE ? window_value<TYPE>(g.c) * inv_scale : window_value<TYPE>(g.c)) * fw.coef;
     g.next();
   }
   __syncthreads();
@@ -61,7 +62,7 @@ __device__ __forceinline__ FrameWindow windowed_waveform_blk(const double* __res
 // second transform of D4C's centroid: the same frame / nrm * (i + 1)  (d4c.cpp:96-112)
 template <int TYPE, int NW>
 __device__ __forceinline__ void rebuild_ramped_blk(const double* __restrict__ xu, int xl, const FrameWindow& fw,
-                                                   const uint32_t* __restrict__ rtab, int roff, double nrm, int tid,
+                                                   const uint32_t* __restrict__ rtab, int roff, double rnrm, int tid,
                                                    double* wav, int F) {
   constexpr int NT = 64 * NW;
   CosGen g;
@@ -69,10 +70,10 @@ __device__ __forceinline__ void rebuild_ramped_blk(const double* __restrict__ xu
   for (int i = tid; i < F; i += NT) {
     double val = 0.0;
     if (i < fw.L) {
-      const double w = window_value<TYPE>(g.c) / fw.scale;
+      const double w = window_value<TYPE>(g.c);
       val = xu[imin(xl - 1, imax(0, fw.origin + i - fw.hw))] * w + randn_at(rtab, roff + i) * kSafe;
       val -= w * fw.coef;
-      val = val / nrm * (i + 1.0);
+      val = val * rnrm * (i + 1.0);
     }
     wav[i] = val;
     g.next();
@@ -101,6 +102,7 @@ __device__ __forceinline__ void linear_smoothing_blk(const double* in, double wi
                                                      double* seg, double* out, double* red, int tid) {
   constexpr int NT = 64 * NW;
   const int half = fft_size / 2;
+  const double inv_fft = 1.0 / fft_size;               // power of two: x * inv_fft == x / fft_size exactly
   const int b = (int)(width * fft_size / fs) + 1;
   const int len = half + 2 * b + 1;
   const int chunk = (len + NT - 1) / NT;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void linear_smoothing_blk(const double* in, double wi
   double run = 0.0;
   for (int i = beg; i < end; ++i) {
     const int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
-    run += in[src] * fs / fft_size;
+    run += in[src] * fs * inv_fft;
     seg[i] = run;
   }
   const int lane = tid & 63, wv = tid >> 6;
@@ -126,7 +128,7 @@ __device__ __forceinline__ void linear_smoothing_blk(const double* in, double wi
   const double origin = -(b - 0.5) * fs / fft_size;
   const double step = (double)fs / fft_size;
   for (int i = tid; i <= half; i += NT) {
-    const double lo_x = (double)i / fft_size * fs - width / 2.0;
+    const double lo_x = (double)i * inv_fft * fs - width / 2.0;
     const double lo = interp1q_lds(origin, step, seg, len, lo_x);
     const double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
     out[i] = (hi - lo) / width;

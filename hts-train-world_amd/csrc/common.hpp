@@ -118,26 +118,29 @@ __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs,
 __device__ __forceinline__ void linear_smoothing_lds(const double* in, double width, int fs, int fft_size,
                                                      double* seg, double* out, int lane) {
   const int half = fft_size / 2;
+  const double inv_fft = 1.0 / fft_size;               // power of two: x * inv_fft == x / fft_size exactly
   const int b = (int)(width * fft_size / fs) + 1;
   const int len = half + 2 * b + 1;
   const int chunk = (len + 63) / 64;
   const int beg = lane * chunk;
   const int end = imin(len, beg + chunk);
   double run = 0.0;
+#pragma unroll 4
   for (int i = beg; i < end; ++i) {
     int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
-    run += in[src] * fs / fft_size;
+    run += in[src] * fs * inv_fft;
     seg[i] = run;
   }
   const double incl = wave_scan_incl(run, lane);
   const double carry = incl - run;
+#pragma unroll 4
   for (int i = beg; i < end; ++i) seg[i] += carry;        // own chunk: no barrier needed before
   __syncthreads();
   const double origin = -(b - 0.5) * fs / fft_size;
   const double step = (double)fs / fft_size;
-#pragma unroll 2
+#pragma unroll 8
   for (int i = lane; i <= half; i += 64) {
-    const double lo_x = (double)i / fft_size * fs - width / 2.0;
+    const double lo_x = (double)i * inv_fft * fs - width / 2.0;
     const double lo = interp1q_lds(origin, step, seg, len, lo_x);
     const double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
     out[i] = (hi - lo) / width;

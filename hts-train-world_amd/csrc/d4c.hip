@@ -8,7 +8,9 @@
 // The std::sort of d4c.cpp:215 only feeds "sum of all but the (boundary+1)
 // largest bins"; here the largest bins are peeled off by repeated wave-wide max
 // and the rest summed directly (no sort).
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -17,6 +19,7 @@
 #include "bfft.hpp"
 #include "common.hpp"
 #include "fft.hpp"
+#include "ilp.hpp"
 #include "window.hpp"
 
 namespace wm {
@@ -127,6 +130,17 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     __syncthreads();
   }
 }
+
+// diagnostic cycle stamps (s_memtime) per phase of d4c_wave_kernel; enabled with dbg bit 32
+__device__ unsigned long long g_d4c_stamps[16];
+#define WM_STAMP(id)                                                                   \
+  do {                                                                                 \
+    if (dbg & 32) {                                                                    \
+      const long long tn_ = clock64();                                                 \
+      if (lane == 0) atomicAdd(&g_d4c_stamps[id], (unsigned long long)(tn_ - tprev_)); \
+      tprev_ = clock64();                                                              \
+    }                                                                                  \
+  } while (0)
 
 struct D4CTables {
   const double* nuttall;    // [window_length] NuttallWindow(window_length) (d4c.cpp:356-359)
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
       }
       const double s = (f - x0) / (x1 - x0);
       const double yi = y0 + s * (y1 - y0);
-      row[i] = pow(10.0, yi / 20.0);
+      row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
     }
     __syncthreads();
   }
@@ -517,23 +531,27 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
       const int ro = roff + side * Lw;
       cpx v[M];
-      const FrameWindow fw = windowed_waveform_lds<kBlackman, false>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
+      const FrameWindow fw = windowed_waveform_lds<kBlackman, false, 8>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
                                                                      smem, FD);
       double pwr = 0.0;                                   // d4c.cpp:96-100
       for (int i = lane; i < fw.L; i += 64) pwr += smem[i] * smem[i];
-      const double nrm = sqrt(wave_sum(pwr));
+      // normalisation by sqrt(power) (d4c.cpp:99-100) applied as a multiplication by its reciprocal
+      const double rnrm = 1.0 / sqrt(wave_sum(pwr));
       load_packed<N>(smem, lane, v);
+      cpx fv[M];                                          // normalised frame, kept for the ramped transform
 #pragma unroll
-      for (int m = 0; m < M; ++m) { v[m].x /= nrm; v[m].y /= nrm; }
+      for (int m = 0; m < M; ++m) { v[m].x *= rnrm; v[m].y *= rnrm; fv[m] = v[m]; }
       rfft_forward<N>(v, img, img, tw, lane);
       cpx s1[MB];
 #pragma unroll
       for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
       s1[M] = img[N];
       // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
-      __syncthreads();
-      rebuild_ramped_lds<kBlackman>(xu, xl, fw, rtab, ro, nrm, lane, smem, FD);
-      load_packed<N>(smem, lane, v);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        v[m] = make_double2(fv[m].x * (i0 + 1.0), fv[m].y * (i0 + 2.0));
+      }
       rfft_forward<N>(v, img, img, tw, lane);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     double gd[MB];
     if (!(dbg & 2)) {
       cpx v[M];
-      windowed_waveform_lds<kHann, false>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
+      windowed_waveform_lds<kHann, false, 8>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
       load_packed<N>(smem, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
@@ -636,21 +654,25 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         tot += p[M];
       }
       tot = wave_sum(tot);
-      // peel the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220)
+      // peel the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220).
+      // Each lane tracks the maximum of its remaining bins; only the winning lane rescans.
+      double cur = p[0];
+#pragma unroll
+      for (int m = 1; m < MB; ++m) cur = fmax(cur, p[m]);
 #pragma unroll 1
       for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
-        double mx = p[0];
-#pragma unroll
-        for (int m = 1; m < MB; ++m) mx = fmax(mx, p[m]);
-        const double wmx = wave_max(mx);
-        const unsigned long long vote = __ballot(mx == wmx);
+        const double wmx = wave_max(cur);
+        const unsigned long long vote = __ballot(cur == wmx);
         const int winner = __ffsll((long long)vote) - 1;
         if (lane == winner) {
           bool done = false;
+          double nc = -1.0;
 #pragma unroll
           for (int m = 0; m < MB; ++m) {
             if (!done && p[m] == wmx) { p[m] = -1.0; done = true; }
+            nc = fmax(nc, p[m]);
           }
+          cur = nc;
         }
       }
       double low = 0.0;
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       }
       const double s = (f - x0) / (x1 - x0);
       const double yi = y0 + s * (y1 - y0);
-      row[i] = pow(10.0, yi / 20.0);
+      row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
     }
     __syncthreads();
   }
@@ -775,6 +797,16 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     }
   }
 #undef WM_D4C_CASE
+  if (dbg & 32) {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_d4c_stamps), sizeof(h));
+    fprintf(stderr, "d4c stamps (Mcycles):");
+    for (int i = 0; i < 11; ++i) fprintf(stderr, " [%d]=%.1f", i, h[i] / 1e6);
+    fprintf(stderr, "\n");
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_d4c_stamps), h, sizeof(h));
+  }
   return wm_check(hipGetLastError());
 }
 

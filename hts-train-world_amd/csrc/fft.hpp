@@ -104,9 +104,22 @@ template <> struct Dft<16> {
   }
 };
 
-// multiply a[r] by w^r, r = 1..R-1.  Two interleaved chains stepping by w^2 keep only three
-// complex values live (register pressure matters more here than the ~R/2 ulp of chain error).
+// multiply a[r] by w^r, r = 1..R-1.
+// WM_FFT_ILP (default): powers from a shallow product tree (depth log2 R) -- more live registers,
+// short dependency chains; the one-wave-per-SIMD kernels are latency bound and want this.
+// Otherwise two interleaved chains stepping by w^2 (three live complex values).
+#ifndef WM_FFT_ILP
+#define WM_FFT_ILP 1
+#endif
 template <int R> __device__ __forceinline__ void apply_twiddle_powers(cpx (&a)[R], cpx w) {
+#if WM_FFT_ILP
+  cpx p[R];
+  p[1] = w;
+#pragma unroll
+  for (int r = 2; r < R; ++r) p[r] = (r & 1) ? cmul(p[r - 1], w) : cmul(p[r / 2], p[r / 2]);
+#pragma unroll
+  for (int r = 1; r < R; ++r) a[r] = cmul(a[r], p[r]);
+#else
   const cpx w2 = cmul(w, w);
   cpx odd = w, even = w2;
   a[1] = cmul(a[1], odd);
@@ -119,6 +132,7 @@ template <int R> __device__ __forceinline__ void apply_twiddle_powers(cpx (&a)[R
     }
     if (r + 2 < R) even = cmul(even, w2);
   }
+#endif
 }
 
 template <int N> struct FftCfg;
@@ -172,7 +186,9 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     const int j = lane + 64 * b;
 #pragma unroll
     for (int r = 0; r < R1; ++r) lds[fft_pad<N>(j * R1 + r)] = a[r];
+#if !WM_FFT_ILP
     __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: bounds the live registers
+#endif
   }
   __syncthreads();
 #pragma unroll
@@ -190,7 +206,9 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     const int base = (j / R1) * (R1 * R2) + (j % R1);
 #pragma unroll
     for (int r = 0; r < R2; ++r) lds[fft_pad<N>(base + r * R1)] = a[r];
+#if !WM_FFT_ILP
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   __syncthreads();
 #pragma unroll
@@ -205,7 +223,9 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     Dft<R3>::run(a);
 #pragma unroll
     for (int r = 0; r < R3; ++r) v[b + r * S3] = a[r];
+#if !WM_FFT_ILP
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
