@@ -40,53 +40,124 @@ __device__ __forceinline__ double coarse_vuv(const double* __restrict__ f0, int 
   return a * 2 - b;
 }
 
-__global__ __launch_bounds__(64) void synth_timebase_kernel(
+// Part 1 of GetTimeBase (synthesis.cpp:287-307): per-sample interpolation of the coarse f0 / vuv
+// contours and the phase increment 2 pi f0 / fs.  Fully parallel over samples.
+__global__ __launch_bounds__(256) void synth_inc_kernel(
     const double* __restrict__ f0, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
-    int fs, double fp, double lowest_f0, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
-    double* __restrict__ vuv_out, int* __restrict__ pulse_cnt) {
-  // The pulse positions of unvoiced stretches sit exactly on phase-wrap ties (500 Hz * 32
-  // samples = one period), so the accumulated phase has to match the reference bit for bit:
-  // no FMA contraction anywhere in this kernel.
+    int fs, double fp, double lowest_f0, double* __restrict__ vuv_out, double* __restrict__ inc_out) {
+  // bit-exact increments are required (see synth_timebase_kernel): no FMA contraction
 #pragma clang fp contract(off)
-  const int u = blockIdx.x, lane = threadIdx.x;
+  const int u = blockIdx.y;
   const double* f0u = f0 + f_off[u];
   const int nf = (int)(f_off[u + 1] - f_off[u]);
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ylen; i += gridDim.x * 256) {
+    // interp1 (matlabfunctions.cpp:136-182) of the (nf+1)-knot coarse contours at t = i / fs
+    const double t = i / (double)fs;
+    int kg = (int)(t / fp) + 1;
+    if (kg > nf + 1) kg = nf + 1;
+    if (kg < 0) kg = 0;
+    while (kg <= nf && kg * fp <= t) ++kg;
+    while (kg > 0 && (kg - 1) * fp > t) --kg;
+    const int k = kg < 1 ? 1 : (kg > nf ? nf : kg);
+    const double x0 = (k - 1) * fp, x1 = k * fp;
+    const double h = x1 - x0;
+    const double s = (t - x0) / h;
+    const double fa = coarse_f0(f0u, nf, k - 1, lowest_f0), fb = coarse_f0(f0u, nf, k, lowest_f0);
+    const double va = coarse_vuv(f0u, nf, k - 1, lowest_f0), vb = coarse_vuv(f0u, nf, k, lowest_f0);
+    double fi = fa + s * (fb - fa);
+    const double vi = va + s * (vb - va);
+    const double vv = vi > 0.5 ? 1.0 : 0.0;                 // synthesis.cpp:303-307
+    fi = vv == 0.0 ? kDefaultF0 : fi;
+    vuv_out[yb + i] = vv;
+    inc_out[yb + i] = 2.0 * kPi * fi / fs;                  // :248-252
+  }
+}
+
+// Part 2 (synthesis.cpp:242-285): one wavefront per utterance accumulates the phase in the
+// reference's strictly sequential order, wraps it and compacts the pulses in order.
+// The pulse positions of unvoiced stretches sit exactly on phase-wrap ties (500 Hz * 32 samples =
+// one period), so the accumulated phase has to match the reference bit for bit: lane l adds
+// increments 0..l one after another (adding 0.0 on the lanes that are done is exact), and
+// fmod(total, 2 pi) is evaluated exactly as total - k * (2 pi) with a single FMA.
+__global__ __launch_bounds__(64) void synth_timebase_kernel(
+    const int64_t* __restrict__ y_off, const double* __restrict__ inc_in, int fs, int* __restrict__ pulse_idx,
+    double* __restrict__ pulse_shift, int* __restrict__ pulse_cnt) {
+#pragma clang fp contract(off)
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const int64_t yb = y_off[u];
+  const int ylen = (int)(y_off[u + 1] - yb);
+  const double two_pi = 2.0 * kPi;
+  const double inv_two_pi = 1.0 / two_pi;
   double carry = 0.0, prev_last = 0.0;
   int count = 0;
+  // Increments travel global -> registers -> LDS -> broadcast reads.  A super-chunk of kSuper
+  // samples is requested from HBM a whole super-chunk (~5 us) before it is needed, parked in
+  // registers, written into one half of an LDS ring, and consumed 16 samples at a time by
+  // uniform-address ds_reads that are issued one block ahead of the chain.
+  constexpr int kSuper = 1024, kPer = kSuper / 64;
+  __shared__ double ring[2 * kSuper];
+  const double* __restrict__ p = inc_in + yb;
+  double stage[kPer];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int idx = s0 + 64 * q + lane;
+      stage[q] = p[imin(idx, ylen - 1)];          // the tail repeats the last increment: never used
+    }
+  };
+  auto park = [&](int half) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) ring[half * kSuper + 64 * q + lane] = stage[q];
+  };
+  request(0);
+  park(0);
+  request(kSuper);
+  __syncthreads();
+  double r[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) r[q] = ring[q];
   for (int c0 = 0; c0 < ylen; c0 += 64) {
     const int i = c0 + lane;
-    double inc = 0.0;
-    if (i < ylen) {
-      // interp1 (matlabfunctions.cpp:136-182) of the (nf+1)-knot coarse contours at t = i / fs
-      const double t = i / (double)fs;
-      int kg = (int)(t / fp) + 1;
-      if (kg > nf + 1) kg = nf + 1;
-      if (kg < 0) kg = 0;
-      while (kg <= nf && kg * fp <= t) ++kg;
-      while (kg > 0 && (kg - 1) * fp > t) --kg;
-      const int k = kg < 1 ? 1 : (kg > nf ? nf : kg);
-      const double x0 = (k - 1) * fp, x1 = k * fp;
-      const double h = x1 - x0;
-      const double s = (t - x0) / h;
-      const double fa = coarse_f0(f0u, nf, k - 1, lowest_f0), fb = coarse_f0(f0u, nf, k, lowest_f0);
-      const double va = coarse_vuv(f0u, nf, k - 1, lowest_f0), vb = coarse_vuv(f0u, nf, k, lowest_f0);
-      double fi = fa + s * (fb - fa);
-      const double vi = va + s * (vb - va);
-      const double vv = vi > 0.5 ? 1.0 : 0.0;                 // synthesis.cpp:303-307
-      fi = vv == 0.0 ? kDefaultF0 : fi;
-      vuv_out[yb + i] = vv;
-      inc = 2.0 * kPi * fi / fs;                              // :248-252
+    if ((c0 & (kSuper - 1)) == 0) {
+      // entering super-chunk k: park k+1 (requested one super-chunk ago) and request k+2
+      park(((c0 / kSuper) + 1) & 1);
+      request(c0 + 2 * kSuper);
+      __syncthreads();
     }
-    // total_phase[i] = total_phase[i-1] + inc[i], strictly in order (:250-252)
+    // total_phase[i] = total_phase[i-1] + inc[i], strictly in order (:250-252): sample j is added
+    // under exec = lanes >= j, so lane l ends with the prefix up to l and one sample costs one
+    // v_add_f64 on the dependency chain plus one scalar shift of exec.
     double t = carry;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const double sj = __shfl(inc, j, 64);
-      if (lane >= j) t += sj;
+    for (int g = 0; g < 4; ++g) {
+      double n[16];
+      const int nb = (c0 + 16 * (g + 1)) & (2 * kSuper - 1);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) n[q] = ring[nb + q];
+#define WM_STEP(R) "v_add_f64 %[t], %[t], %[" #R "]\n\ts_lshl_b64 exec, exec, 1\n\t"
+      asm volatile(
+          "s_lshl_b64 exec, -1, %[sh]\n\t"
+          WM_STEP(b0) WM_STEP(b1) WM_STEP(b2) WM_STEP(b3) WM_STEP(b4) WM_STEP(b5) WM_STEP(b6) WM_STEP(b7)
+          WM_STEP(b8) WM_STEP(b9) WM_STEP(b10) WM_STEP(b11) WM_STEP(b12) WM_STEP(b13) WM_STEP(b14)
+          "v_add_f64 %[t], %[t], %[b15]\n\t"
+          "s_mov_b64 exec, -1"
+          : [t] "+v"(t)
+          : [sh] "n"(16 * g), [b0] "v"(r[0]), [b1] "v"(r[1]), [b2] "v"(r[2]), [b3] "v"(r[3]), [b4] "v"(r[4]),
+            [b5] "v"(r[5]), [b6] "v"(r[6]), [b7] "v"(r[7]), [b8] "v"(r[8]), [b9] "v"(r[9]), [b10] "v"(r[10]),
+            [b11] "v"(r[11]), [b12] "v"(r[12]), [b13] "v"(r[13]), [b14] "v"(r[14]), [b15] "v"(r[15])
+          : "scc");
+#undef WM_STEP
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] = n[q];
     }
-    const double wrap = fmod(t, 2.0 * kPi);                   // :249, :253
+    // wrap = fmod(t, 2 pi) (:249, :253): the remainder is exactly representable, so one fused
+    // multiply-add from the unrounded t gives it once k is right
+    double kq = floor(t * inv_two_pi);
+    double wrap = __fma_rn(-kq, two_pi, t);
+    if (wrap < 0.0) { kq -= 1.0; wrap = __fma_rn(-kq, two_pi, t); }
+    if (wrap >= two_pi) { kq += 1.0; wrap = __fma_rn(-kq, two_pi, t); }
     double prev = __shfl_up(wrap, 1, 64);
     if (lane == 0) prev = prev_last;
     // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
@@ -375,6 +446,7 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     al((void**)&b.d_pulse_idx, sizeof(int) * (size_t)b.total_y);
     al((void**)&b.d_pulse_shift, sizeof(double) * (size_t)b.total_y);
     al((void**)&b.d_vuv, sizeof(double) * (size_t)b.total_y);
+    al((void**)&b.d_phase, sizeof(double) * (size_t)b.total_y);
     al((void**)&b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt);
     al((void**)&b.d_pulse_off, sizeof(int64_t) * ((size_t)b.n_utt + 1));
     al((void**)&b.d_dc_remover, sizeof(double) * (size_t)F);
@@ -388,9 +460,15 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
   if (rc) return rc;
   {
-  TimedScope ts_(b.ctx, "synth_timebase_kernel");
-  hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, d_f0, b.d_f_off, b.d_y_off, fs, fp,
-                     lowest_f0, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_pulse_cnt);
+    const int tiles = imin(64, (b.max_y_len + 255) / 256);
+    {
+      TimedScope ts_(b.ctx, "synth_inc_kernel");
+      hipLaunchKernelGGL(synth_inc_kernel, dim3(tiles, b.n_utt), dim3(256), 0, st, d_f0, b.d_f_off, b.d_y_off, fs,
+                         fp, lowest_f0, b.d_vuv, b.d_phase);
+    }
+    TimedScope ts_(b.ctx, "synth_timebase_kernel");
+    hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, b.d_y_off, b.d_phase, fs,
+                       b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
   }
   rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
                                hipMemcpyDeviceToHost, st));

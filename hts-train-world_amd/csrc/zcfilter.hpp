@@ -12,10 +12,11 @@ constexpr int kBandK = 8;                       // outputs per thread
 constexpr int kBandTile = 256 * kBandK;         // samples per tile
 
 // LDS doubles needed by filter_and_events() for filters of up to ntap_max taps
+__host__ __device__ inline int zc_pad8(int n) { return (n + 7) & ~7; }
 __host__ __device__ inline int zc_lds_doubles(int ntap_max) {
-  const int zspan = kBandTile + ntap_max;
+  const int zspan = kBandTile + zc_pad8(ntap_max) + 8;
   const int stride = (zspan + kBandK - 1) / kBandK + 1;
-  return kBandK * stride + ntap_max + kBandTile;
+  return kBandK * stride + zc_pad8(ntap_max) + kBandTile;
 }
 
 // filtered[n] = sum_{k < ntap} taps[k] * sig[n + bias - k], n in [0, ylen), where sig[m] is read for
@@ -26,49 +27,66 @@ __device__ __forceinline__ void filter_and_events(const double* __restrict__ sig
                                                   const double* __restrict__ taps, int ntap, int bias,
                                                   double* __restrict__ ev, int cap, int* __restrict__ ev_cnt4,
                                                   double* lds) {
-  // LDS: transposed signal tile (element e at [(e % K) * stride + e / K]), taps, filtered tile
-  const int zspan = kBandTile + ntap;                           // elements needed per tile
+  // LDS: transposed signal tile (element e at [(e % K) * stride + e / K]), taps (zero-padded to a
+  // multiple of 8), filtered tile.  The tile carries 8 extra leading elements so that the 8-tap
+  // register rotation below never indexes below zero.
+  const int ntp = zc_pad8(ntap);
+  const int zspan = kBandTile + ntp + 8;                        // elements needed per tile
   const int stride = (zspan + kBandK - 1) / kBandK + 1;
   double* zt = lds;                                             // [K * stride]
-  double* w = zt + kBandK * stride;                             // [ntap]
-  double* s = w + ntap;                                         // [kBandTile] filtered samples
+  double* w = zt + kBandK * stride;                             // [ntp]
+  double* s = w + ntp;                                          // [kBandTile] filtered samples
   __shared__ int wave_cnt[4][4];                                // [kind][wave]
   __shared__ int run_cnt[4];
-  for (int j = threadIdx.x; j < ntap; j += 256) w[j] = taps[j];
+  for (int j = threadIdx.x; j < ntp; j += 256) w[j] = j < ntap ? taps[j] : 0.0;
   if (threadIdx.x < 4) run_cnt[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int step = kBandTile - 2;                               // tiles overlap by 2 (s[i+1], s[i+2] look-ahead)
 
   for (int n0 = 0; n0 < ylen; n0 += step) {
     __syncthreads();
-    // tile element e <-> signal index zbase + e with zbase = n0 + bias - (ntap - 1)
-    const int zbase = n0 + bias - (ntap - 1);
+    // tile element e <-> signal index zbase + e with zbase = n0 + bias - (ntp - 1) - 8
+    const int zbase = n0 + bias - (ntp - 1) - 8;
     for (int e = threadIdx.x; e < zspan; e += 256) {
       const int m = zbase + e;
       const double val = (m >= lo && m < hi) ? sig[m] : 0.0;
       zt[(e % kBandK) * stride + e / kBandK] = val;
     }
     __syncthreads();
-    // thread t: outputs n0 + t*K + q, q < K; output q at tap k reads element e = t*K + q + (ntap-1) - k
+    // thread t: outputs n0 + t*K + q, q < K; output q at tap k reads element
+    // e = t*K + q + (ntp - 1) + 8 - k.  Taps are consumed 8 at a time: the 8 window registers
+    // r[q] (elements for tap k) and 8 freshly loaded lower elements nw[] cover all 64 products of
+    // the group with static register indices, so the window slides without register moves.
     {
       double acc[kBandK];
 #pragma unroll
       for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
       const int t = threadIdx.x;
-      double r[kBandK];                                          // sliding register window
+      const int ebase = t * kBandK + (ntp - 1) + 8;             // element of output 0 at tap 0
+      double r[kBandK];
 #pragma unroll
       for (int q = 0; q < kBandK; ++q) {
-        const int e = t * kBandK + q + (ntap - 1);
+        const int e = ebase + q;
         r[q] = zt[(e % kBandK) * stride + e / kBandK];
       }
-      for (int k = 0; k < ntap; ++k) {
-        const double wk = w[k];
+      for (int k = 0; k < ntp; k += 8) {
+        double nw[8], wk[8];
 #pragma unroll
-        for (int q = 0; q < kBandK; ++q) acc[q] += wk * r[q];
+        for (int i = 0; i < 8; ++i) {
+          const int e = ebase - k - 1 - i;                      // >= 0 thanks to the 8 leading elements
+          nw[i] = zt[(e % kBandK) * stride + e / kBandK];
+          wk[i] = w[k + i];
+        }
 #pragma unroll
-        for (int q = kBandK - 1; q > 0; --q) r[q] = r[q - 1];
-        const int e = t * kBandK + (ntap - 1) - (k + 1);
-        r[0] = e >= 0 ? zt[(e % kBandK) * stride + e / kBandK] : 0.0;
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int q = 0; q < kBandK; ++q) {
+            const double el = (q - j >= 0) ? r[(q - j) & 7] : nw[(j - q - 1) & 7];
+            acc[q] += wk[j] * el;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kBandK; ++q) r[q] = nw[7 - q];
       }
 #pragma unroll
       for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
