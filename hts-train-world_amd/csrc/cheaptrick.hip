@@ -67,12 +67,14 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
   double* work = smem + (H + 2);                               // frame | FFT image | spectrum | scan scratch
   cpx* img = reinterpret_cast<cpx*>(work);
 
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
   FftTw<N> tw;
-  tw.init(lane);
+  tw.init(lane0);
   const double f0_floor = 3.0 * fs / (F - 3.0);                // cheaptrick.cpp:196-198
 
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
+    tw.fence();
     const int u = frame_utt[frame];
     const double f0v = f0[frame];
     const double cf0 = f0v <= f0_floor ? kDefaultF0 : f0v;     // cheaptrick.cpp:217

@@ -31,6 +31,13 @@ __device__ __forceinline__ double randn_at(const uint32_t* __restrict__ tab, int
   return (double)tab[k] / 268435456.0 - 6.0;
 }
 
+// Compiler fence for the lane index inside persistent frame loops (see FftTw::fence): address
+// arithmetic derived from the returned value cannot be hoisted out of the loop and spilled.
+__device__ __forceinline__ int opaque_lane(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
 // ---- wavefront collectives (64 lanes) ----------------------------------------
 // Built on DPP row shifts / row broadcasts (gfx9 family) instead of ds_bpermute shuffles: six
 // dependent VALU steps with no LDS round trip.  The six steps are a complete inclusive scan over
@@ -95,16 +102,29 @@ __device__ __forceinline__ double interp1q_lds(double x0, double dx, const doubl
   return y0 + dy * frac;
 }
 
+// same with the reciprocal of the knot spacing supplied (the quotient may differ from the division's
+// by one ulp; the interpolant is continuous across knots, so the value moves by ~1e-16 relative)
+__device__ __forceinline__ double interp1q_lds_r(double x0, double inv_dx, const double* y, int n, double xi) {
+  const double q = (xi - x0) * inv_dx;
+  const int b = (int)q;
+  const double frac = q - b;
+  const double y0 = y[b];
+  const double dy = (b == n - 1) ? 0.0 : y[b + 1] - y0;
+  return y0 + dy * frac;
+}
+
 // DCCorrection (common.cpp:56-75) in place on pw[0..half] (LDS).  One wavefront.
 // `scratch` (LDS, >= upper doubles) holds the replica so that every read of pw
 // happens before any write, as in the reference.
 __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs, int fft_size,
                                                   double* scratch, int lane) {
+  const double inv_fft = 1.0 / fft_size;               // power of two: exact
   const int upper = 2 + (int)(f0 * fft_size / fs);
   const int nrep = upper - 1;
+  const double inv_dx = -(double)fft_size / fs;
   for (int i = lane; i < nrep; i += 64) {
-    double axis = (double)i * fs / fft_size;
-    scratch[i] = interp1q_lds(f0, -(double)fs / fft_size, pw, upper + 1, axis);
+    const double axis = (double)i * fs * inv_fft;
+    scratch[i] = interp1q_lds_r(f0, inv_dx, pw, upper + 1, axis);
   }
   __syncthreads();
   for (int i = lane; i < nrep; i += 64) pw[i] += scratch[i];
@@ -112,38 +132,61 @@ __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs,
 }
 
 // LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[0..half] (LDS; may alias in).
-// seg is an LDS scratch of >= half + 2*b + 1 doubles (b = int(width*fft_size/fs)+1).  The
-// cumulative sum is blocked per lane and stitched by a wave scan (the reference's is sequential,
-// common.cpp:38-41).  Ends with a barrier.
+// seg is an LDS scratch of >= half + 2*b + 1 doubles (b = int(width*fft_size/fs)+1).
+// The cumulative sum of the mirrored spectrum (the reference's is sequential, common.cpp:38-41) is
+// taken row-wise: lane l owns elements l, l+64, ...; each row of 64 is scanned across the wave and
+// the rows are chained through a uniform running total.  Rows and output bins go in groups of 8
+// with all LDS reads of a group in flight together.  Ends with a barrier.
 __device__ __forceinline__ void linear_smoothing_lds(const double* in, double width, int fs, int fft_size,
                                                      double* seg, double* out, int lane) {
+  constexpr int G = 8;
   const int half = fft_size / 2;
   const double inv_fft = 1.0 / fft_size;               // power of two: x * inv_fft == x / fft_size exactly
   const int b = (int)(width * fft_size / fs) + 1;
   const int len = half + 2 * b + 1;
-  const int chunk = (len + 63) / 64;
-  const int beg = lane * chunk;
-  const int end = imin(len, beg + chunk);
-  double run = 0.0;
-#pragma unroll 4
-  for (int i = beg; i < end; ++i) {
-    int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
-    run += in[src] * fs * inv_fft;
-    seg[i] = run;
+  const int rows = (len + 63) >> 6;
+  double base = 0.0;
+  for (int r0 = 0; r0 < rows; r0 += G) {
+    double v[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int i = (r0 + q) * 64 + lane;
+      int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
+      src = imax(0, imin(half, src));
+      v[q] = in[src];
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int i = (r0 + q) * 64 + lane;
+      v[q] = wave_scan_incl(i < len ? v[q] * fs * inv_fft : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int i = (r0 + q) * 64 + lane;
+      if (i < len) seg[i] = v[q] + base;
+      base += lane63(v[q]);
+    }
   }
-  const double incl = wave_scan_incl(run, lane);
-  const double carry = incl - run;
-#pragma unroll 4
-  for (int i = beg; i < end; ++i) seg[i] += carry;        // own chunk: no barrier needed before
   __syncthreads();
-  const double origin = -(b - 0.5) * fs / fft_size;
-  const double step = (double)fs / fft_size;
-#pragma unroll 8
-  for (int i = lane; i <= half; i += 64) {
-    const double lo_x = (double)i * inv_fft * fs - width / 2.0;
-    const double lo = interp1q_lds(origin, step, seg, len, lo_x);
-    const double hi = interp1q_lds(origin, step, seg, len, lo_x + width);
-    out[i] = (hi - lo) / width;
+  const double step = (double)fs * inv_fft;
+  const double inv_step = (double)fft_size / fs;
+  const double origin = -(b - 0.5) * step;
+  const double inv_width = 1.0 / width;
+  constexpr int GI = 4;
+  for (int i0 = 0; i0 <= half; i0 += 64 * GI) {
+    double lo[GI], hi[GI];
+#pragma unroll
+    for (int q = 0; q < GI; ++q) {
+      const int i = imin(half, i0 + 64 * q + lane);
+      const double lo_x = (double)i * inv_fft * fs - width / 2.0;
+      lo[q] = interp1q_lds_r(origin, inv_step, seg, len, lo_x);
+      hi[q] = interp1q_lds_r(origin, inv_step, seg, len, lo_x + width);
+    }
+#pragma unroll
+    for (int q = 0; q < GI; ++q) {
+      const int i = i0 + 64 * q + lane;
+      if (i <= half) out[i] = (hi[q] - lo[q]) * inv_width;
+    }
   }
   __syncthreads();
 }

@@ -92,11 +92,12 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
   constexpr int N = FL / 2, M = N / 64;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems];
   cpx* img = reinterpret_cast<cpx*>(smem);
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
   FftTw<N> tw;
-  tw.init(lane);
+  tw.init(lane0);
   const int b0 = (int)ceil(100.0 * FL / fs), b1 = (int)ceil(4000.0 * FL / fs), b2 = (int)ceil(7900.0 * FL / fs);
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
     const double f0v = f0[frame];
     if (f0v == 0.0) {
       if (lane == 0) ap0[frame] = 0.0;
@@ -499,12 +500,13 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
   double* seg = smem + kA;                    // scan / DC scratch
   cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image (aliases both)
 
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
   FftTw<N> tw;
-  tw.init(lane);
+  tw.init(lane0);
   const int out_bins = out_fft / 2 + 1;
 
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];
     bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     const double pos = tpos[frame];
     const int roff = rng_off[frame];
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
+    long long tprev_ = clock64();
 
     // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
     double sc[MB];
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       cpx v[M];
       const FrameWindow fw = windowed_waveform_lds<kBlackman, false, 8>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
                                                                      smem, FD);
+    WM_STAMP(1);
       double pwr = 0.0;                                   // d4c.cpp:96-100
       for (int i = lane; i < fw.L; i += 64) pwr += smem[i] * smem[i];
       // normalisation by sqrt(power) (d4c.cpp:99-100) applied as a multiplication by its reciprocal
@@ -541,7 +545,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       cpx fv[M];                                          // normalised frame, kept for the ramped transform
 #pragma unroll
       for (int m = 0; m < M; ++m) { v[m].x *= rnrm; v[m].y *= rnrm; fv[m] = v[m]; }
+      WM_STAMP(2);
       rfft_forward<N>(v, img, img, tw, lane);
+      WM_STAMP(3);
       cpx s1[MB];
 #pragma unroll
       for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
@@ -553,6 +559,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         v[m] = make_double2(fv[m].x * (i0 + 1.0), fv[m].y * (i0 + 2.0));
       }
       rfft_forward<N>(v, img, img, tw, lane);
+      WM_STAMP(4);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         cpx s2 = img[lane + 64 * m];
@@ -563,6 +570,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         sc[M] += s2.x * s1[M].x + s1[M].y * s2.y;
       }
       __syncthreads();
+      WM_STAMP(5);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m];
@@ -573,12 +581,14 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
     sc[M] = arr[N];
     __syncthreads();
+    WM_STAMP(6);
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
     double gd[MB];
     if (!(dbg & 2)) {
       cpx v[M];
       windowed_waveform_lds<kHann, false, 8>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
+      WM_STAMP(7);
       load_packed<N>(smem, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
@@ -596,11 +606,13 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
       if (lane == 0) arr[N] = p[M];
       __syncthreads();
+      WM_STAMP(8);
     }
     if (!(dbg & 4)) {
     dc_correction_lds(arr, cf0, fs, FD, seg, lane);
     linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
     }
+    WM_STAMP(9);
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[N];
     __syncthreads();
+    WM_STAMP(10);
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
     const int wl = tab.window_length;
@@ -638,7 +651,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         if (i0 + 1 < wl) a1 = arr[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
         v[m] = make_double2(a0, a1);
       }
+      WM_STAMP(11);
       rfft_forward<N>(v, img, img, tw, lane);
+      WM_STAMP(12);
       double p[MB];
       double tot = 0.0;
 #pragma unroll
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       for (int j = 0; j < 6; ++j)
         if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
       __syncthreads();
+      WM_STAMP(13);
     }
 
     // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
@@ -713,6 +729,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
     }
     __syncthreads();
+    WM_STAMP(14);
   }
 }
 
@@ -802,7 +819,7 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     (void)hipStreamSynchronize(st);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_d4c_stamps), sizeof(h));
     fprintf(stderr, "d4c stamps (Mcycles):");
-    for (int i = 0; i < 11; ++i) fprintf(stderr, " [%d]=%.1f", i, h[i] / 1e6);
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%.1f", i, h[i] / 1e6);
     fprintf(stderr, "\n");
     memset(h, 0, sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_d4c_stamps), h, sizeof(h));

@@ -160,6 +160,15 @@ template <int N> struct FftTw {
     wsplit = cis_neg2pi((double)lane / (double)(2 * N));
     wstep = cis_neg2pi(64.0 / (double)(2 * N));
   }
+  // Compiler fence for persistent (grid-stride) kernels: called at the top of every frame, it makes
+  // the twiddle bases opaque so that nothing derived from them (powers, products) is hoisted out of
+  // the frame loop -- LICM otherwise precomputes dozens of twiddle powers and LDS addresses once per
+  // kernel and then spills them, which costs far more than recomputing a few FMAs per transform.
+  __device__ __forceinline__ void fence() {
+    asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(wsplit.x), "+v"(wsplit.y), "+v"(wstep.x), "+v"(wstep.y));
+#pragma unroll
+    for (int b = 0; b < S3; ++b) asm volatile("" : "+v"(w3[b].x), "+v"(w3[b].y));
+  }
 };
 
 template <int N> __device__ __forceinline__ int fft_pad(int i) { return i + i / FftCfg<N>::R1; }
@@ -170,6 +179,10 @@ template <int N> __device__ __forceinline__ int fft_pad(int i) { return i + i / 
 template <int N>
 __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
   constexpr int M = N / 64;
+  // per-call fences: every transform derives its own LDS addresses and twiddle powers (a few
+  // integer ops / FMAs) instead of sharing hoisted copies that the register allocator then spills
+  asm volatile("" : "+v"(lane));
+  const_cast<FftTw<N>&>(tw).fence();
   constexpr int R1 = FftCfg<N>::R1, R2 = FftCfg<N>::R2, R3 = FftCfg<N>::R3;
   constexpr int S1 = M / R1, S2 = M / R2, S3 = M / R3;
   static_assert(S1 >= 1 && S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
@@ -248,6 +261,7 @@ __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* sp
                                              int lane) {
   constexpr int M = N / 64;
   fft_forward<N>(v, lds, tw, lane);
+  asm volatile("" : "+v"(lane));
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < M; ++m) lds[lane + 64 * m] = v[m];     // Z, plain layout
@@ -282,6 +296,8 @@ template <int N>
 __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw,
                                               int lane) {
   constexpr int M = N / 64;
+  asm volatile("" : "+v"(lane));
+  const_cast<FftTw<N>&>(tw).fence();
   cpx w = cconj(tw.wsplit);                                  // e^{+j pi k / N}
   const cpx wst = cconj(tw.wstep);
   __syncthreads();

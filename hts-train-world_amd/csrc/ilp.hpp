@@ -33,19 +33,20 @@ __device__ __forceinline__ void frame_cos(double a, int hw, int lane, cpx (&cw)[
 }
 
 // GetWindowedWaveform (d4c.cpp:52-84, unnormalised windows) into registers, packed order.
-// All x / randn loads are issued up front.
-template <int TYPE, int M>
-__device__ __forceinline__ void build_frame_regs(const double* __restrict__ xu, int xl, int origin, int hw, int L,
-                                                 const uint32_t* __restrict__ rtab, int roff, int lane,
-                                                 const cpx (&cw)[M], cpx (&fv)[M]) {
-  double xs[2 * M];
-  uint32_t rs[2 * M];
+// All x / randn loads of the frame are issued up front (one memory round trip per frame instead of
+// one per 64 samples); slots m >= MU are beyond the window and stay zero.
+template <int TYPE, int M, int MU>
+__device__ __forceinline__ void build_frame_regs_t(const double* __restrict__ xu, int xl, int origin, int hw, int L,
+                                                   const uint32_t* __restrict__ rtab, int roff, int lane,
+                                                   const cpx (&cw)[M], cpx (&fv)[M]) {
+  double xs[2 * MU];
+  uint32_t rs[2 * MU];
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < MU; ++m) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int i = 2 * (lane + 64 * m) + c;
-      const int ic = i < L ? i : 0;                                // keep the address valid; value unused
+      const int ic = i < L ? i : L - 1;                            // keep the address inside the frame's draws
       xs[2 * m + c] = xu[imin(xl - 1, imax(0, origin + ic - hw))];
       rs[2 * m + c] = rtab[roff + ic];
     }
@@ -53,22 +54,36 @@ __device__ __forceinline__ void build_frame_regs(const double* __restrict__ xu, 
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    const int i0 = 2 * (lane + 64 * m);
-    const double w0 = i0 < L ? window_value<TYPE>(cw[m].x) : 0.0;
-    const double w1 = i0 + 1 < L ? window_value<TYPE>(cw[m].y) : 0.0;
-    const double a0 = i0 < L ? xs[2 * m] * w0 + ((double)rs[2 * m] / 268435456.0 - 6.0) * kSafe : 0.0;
-    const double a1 = i0 + 1 < L ? xs[2 * m + 1] * w1 + ((double)rs[2 * m + 1] / 268435456.0 - 6.0) * kSafe : 0.0;
-    fv[m] = make_double2(a0, a1);
-    s1 += a0 + a1;
-    s2 += w0 + w1;
+    if (m < MU) {
+      const int i0 = 2 * (lane + 64 * m);
+      const double w0 = i0 < L ? window_value<TYPE>(cw[m].x) : 0.0;
+      const double w1 = i0 + 1 < L ? window_value<TYPE>(cw[m].y) : 0.0;
+      const double a0 = i0 < L ? xs[2 * m] * w0 + ((double)rs[2 * m] / 268435456.0 - 6.0) * kSafe : 0.0;
+      const double a1 = i0 + 1 < L ? xs[2 * m + 1] * w1 + ((double)rs[2 * m + 1] / 268435456.0 - 6.0) * kSafe : 0.0;
+      fv[m] = make_double2(a0, a1);
+      s1 += a0 + a1;
+      s2 += w0 + w1;
+    } else {
+      fv[m] = make_double2(0.0, 0.0);
+    }
   }
   const double coef = wave_sum(s1) / wave_sum(s2);
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < MU; ++m) {
     const int i0 = 2 * (lane + 64 * m);
     if (i0 < L) fv[m].x -= window_value<TYPE>(cw[m].x) * coef;
     if (i0 + 1 < L) fv[m].y -= window_value<TYPE>(cw[m].y) * coef;
   }
+}
+
+// tier dispatch on the window length: a quarter / half / all of the M register slots
+template <int TYPE, int M>
+__device__ __forceinline__ void build_frame_regs(const double* __restrict__ xu, int xl, int origin, int hw, int L,
+                                                 const uint32_t* __restrict__ rtab, int roff, int lane,
+                                                 const cpx (&cw)[M], cpx (&fv)[M]) {
+  if (L <= 32 * M) build_frame_regs_t<TYPE, M, M / 4>(xu, xl, origin, hw, L, rtab, roff, lane, cw, fv);
+  else if (L <= 64 * M) build_frame_regs_t<TYPE, M, M / 2>(xu, xl, origin, hw, L, rtab, roff, lane, cw, fv);
+  else build_frame_regs_t<TYPE, M, M>(xu, xl, origin, hw, L, rtab, roff, lane, cw, fv);
 }
 
 // DCCorrection (common.cpp:56-75) in place on pw[0..half] (LDS), replica of at most 64*REP bins.
