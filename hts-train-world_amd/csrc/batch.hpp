@@ -106,6 +106,8 @@ struct Batch {
   int* d_pulse_cnt = nullptr;        // [n_utt]
   int64_t* d_pulse_off = nullptr;    // [n_utt+1]
   int* h_pulse_cnt = nullptr;        // pinned
+  void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
+  int64_t pulse_rec_cap = 0;
   double* d_dc_remover = nullptr;    // [fft_size]
 
   int64_t rng_bound_cheaptrick() const;

@@ -705,28 +705,32 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     }
 
     // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
-    const int nk = tab.nap + 2;
-    for (int i = lane; i < out_bins; i += 64) {
-      const double f = (double)i * fs / out_fft;
-      int k = 0;                                            // #{knots <= f}
-      for (int j = 0; j < nk; ++j) {
-        double xj = j <= tab.nap ? j * kFreqInterval : fs / 2.0;
-        k += xj <= f ? 1 : 0;
-      }
-      k = k < 1 ? 1 : (k > nk - 1 ? nk - 1 : k);
-      const double x0 = (k - 1) <= tab.nap ? (k - 1) * kFreqInterval : fs / 2.0;
-      const double x1 = k <= tab.nap ? k * kFreqInterval : fs / 2.0;
-      double y0 = -60.0, y1 = -kSafe;
+    // knot values {-60, coarse..., -kSafe} go through LDS (the FFT image is free here) so that the
+    // segment of every output bin is one indexed read; the segment index is floor(f / 3000) taken
+    // with a reciprocal: on an exact knot it may pick the segment to the left with s = 1, which is
+    // the same point of the (continuous) interpolant.
+    if (lane <= tab.nap + 1) {
+      double kv = lane == 0 ? -60.0 : -kSafe;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (j < tab.nap) {
-          if (k - 1 == j + 1) y0 = coarse[j];
-          if (k == j + 1) y1 = coarse[j];
-        }
+      for (int j = 0; j < 6; ++j)
+        if (lane == j + 1 && j < tab.nap) kv = coarse[j];
+      smem[lane] = kv;
+    }
+    __syncthreads();
+    {
+      const double bin_hz = (double)fs / out_fft;
+      const double last_w = fs / 2.0 - tab.nap * kFreqInterval;
+      const double inv_last = 1.0 / last_w;
+      for (int i = lane; i < ((dbg & 64) ? 0 : out_bins); i += 64) {
+        const double f = (double)i * bin_hz;
+        int kk = (int)(f * (1.0 / kFreqInterval));
+        kk = kk > tab.nap ? tab.nap : kk;
+        const double x0 = kk * kFreqInterval;
+        const double sfr = (f - x0) * (kk == tab.nap ? inv_last : 1.0 / kFreqInterval);
+        const double y0 = smem[kk], y1 = smem[kk + 1];
+        const double yi = y0 + sfr * (y1 - y0);
+        row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
       }
-      const double s = (f - x0) / (x1 - x0);
-      const double yi = y0 + s * (y1 - y0);
-      row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
     }
     __syncthreads();
     WM_STAMP(14);
@@ -801,7 +805,7 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
                          b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
                          c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
     else                                                                                                  \
-      hipLaunchKernelGGL((d4c_wave_kernel<FF, 1>), dim3(grid), dim3(64), 0, st, d_x, b.d_x_off,           \
+      hipLaunchKernelGGL((d4c_wave_kernel<FF, 2>), dim3(grid), dim3(64), 0, st, d_x, b.d_x_off,           \
                          b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
                          c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
     break;

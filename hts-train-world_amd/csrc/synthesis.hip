@@ -228,56 +228,79 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
     const cpx s = img[k];
     const double amp = exp(s.x / F);                              // :210-218
     double sn, cs;
-    sincos(s.y / F, &sn, &cs);
+    sincospi(s.y * (1.0 / (kPi * F)), &sn, &cs);                  // phase in half-turns: no Payne-Hanek path
     mp[m] = make_double2(amp * cs, amp * sn);
+    __builtin_amdgcn_sched_barrier(0);                            // one bin at a time: keeps the VGPR peak low
   }
   __syncthreads();
 }
 
+// Everything a pulse needs that is not spectral data, gathered by a fully parallel kernel so that
+// the per-pulse kernel starts with ONE (scalar) load instead of a binary search over the pulse
+// offsets followed by four levels of dependent loads.
+struct PulseRec {
+  int64_t fbase;      // first frame of the utterance
+  int nf;             // frames of the utterance
+  int idx;            // pulse sample index (pulse_locations_index)
+  int roff;           // idx - idx of the utterance's first pulse: randn table offset (:341, :369)
+  int noise_size;     // idx of the next pulse - idx (:369; 0 for the last pulse)
+  double shift;       // pulse_locations_time_shift
+  double cvuv;        // interpolated vuv at the pulse
+};
+
+__global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
+    const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
+    const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift, const double* __restrict__ vuv,
+    PulseRec* __restrict__ rec) {
+  const int u = blockIdx.y;
+  const int64_t pb = p_off[u];
+  const int np = (int)(p_off[u + 1] - pb);
+  const int64_t yb = y_off[u];
+  for (int pi = blockIdx.x * 256 + threadIdx.x; pi < np; pi += gridDim.x * 256) {
+    PulseRec r;
+    r.fbase = f_off[u];
+    r.nf = (int)(f_off[u + 1] - f_off[u]);
+    r.idx = pulse_idx[yb + pi];
+    r.roff = r.idx - pulse_idx[yb];
+    r.noise_size = pulse_idx[yb + imin(np - 1, pi + 1)] - r.idx;
+    r.shift = pulse_shift[yb + pi];
+    r.cvuv = vuv[yb + r.idx];
+    rec[pb + pi] = r;
+  }
+}
+
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64) void synth_pulse_kernel(
-    const double* __restrict__ f0, const double* __restrict__ sp, const double* __restrict__ ap,
-    const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
-    int n_utt, const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift,
-    const double* __restrict__ vuv, const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs,
-    double fp, int64_t p_begin, int64_t p_end, double* __restrict__ resp) {
+__global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
+    const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
+    const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
+    int64_t p_end, double* __restrict__ resp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + H + 2];
   cpx* img = reinterpret_cast<cpx*>(smem);
   double* ls = smem + 2 * FftLds<N>::kElems;
-  const int lane = threadIdx.x;
+  const int lane0 = threadIdx.x;
   FftTw<N> tw;
-  tw.init(lane);
+  tw.init(lane0);
 
   for (int64_t p = p_begin + blockIdx.x; p < p_end; p += gridDim.x) {
-    // utterance of this pulse: last u with p_off[u] <= p
-    int lo = 0, hi = n_utt;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (p_off[mid] <= p) lo = mid; else hi = mid;
-    }
-    const int u = lo;
-    const int pi = (int)(p - p_off[u]);
-    const int np = (int)(p_off[u + 1] - p_off[u]);
-    const int64_t yb = y_off[u];
-    const int nf = (int)(f_off[u + 1] - f_off[u]);
-    const int idx = pulse_idx[yb + pi];
-    const int idx0 = pulse_idx[yb];
-    const int idx_next = pulse_idx[yb + imin(np - 1, pi + 1)];
-    const int noise_size = idx_next - idx;                          // synthesis.cpp:369
-    const double cvuv = vuv[yb + idx];
+    const int lane = opaque_lane(lane0);
+    const PulseRec r = rec[p];                                      // wave-uniform
+    const int nf = r.nf;
+    const int idx = r.idx;
+    const int noise_size = r.noise_size;                            // synthesis.cpp:369
+    const double cvuv = r.cvuv;
     const double ctime = idx / (double)fs;                          // pulse_locations = time_axis[i]
-    const double shift = pulse_shift[yb + pi];
+    const double shift = r.shift;
 
     // ---- GetSpectralEnvelope / GetAperiodicRatio (:140-178) ----
     const int ff = imin(nf - 1, (int)floor(ctime / fp));
     const int fc = imin(nf - 1, (int)ceil(ctime / fp));
     const double wgt = ctime / fp - ff;
-    const double* s0 = sp + (f_off[u] + ff) * (int64_t)(H + 1);
-    const double* s1 = sp + (f_off[u] + fc) * (int64_t)(H + 1);
-    const double* a0 = ap + (f_off[u] + ff) * (int64_t)(H + 1);
-    const double* a1 = ap + (f_off[u] + fc) * (int64_t)(H + 1);
+    const double* s0 = sp + (r.fbase + ff) * (int64_t)(H + 1);
+    const double* s1 = sp + (r.fbase + fc) * (int64_t)(H + 1);
+    const double* a0 = ap + (r.fbase + ff) * (int64_t)(H + 1);
+    const double* a1 = ap + (r.fbase + fc) * (int64_t)(H + 1);
     double env[MB], rat[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -303,7 +326,10 @@ __global__ __launch_bounds__(64) void synth_pulse_kernel(
     if (periodic) {
       __syncthreads();
 #pragma unroll
-      for (int m = 0; m < M; ++m) ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+      for (int m = 0; m < M; ++m) {
+        ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
       __syncthreads();
       cpx mp[MB];
@@ -316,6 +342,7 @@ __global__ __launch_bounds__(64) void synth_pulse_kernel(
         const double im2 = sqrt(1.0 - re2 * re2);
         const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
         if (m < M || lane == 0) img[k] = s;
+        __builtin_amdgcn_sched_barrier(0);
       }
       cpx v[M];
       rfft_backward<N>(img, v, img, tw, lane);
@@ -335,8 +362,9 @@ __global__ __launch_bounds__(64) void synth_pulse_kernel(
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       const int k = m < M ? lane + 64 * m : H;
-      const double val = cvuv != 0.0 ? log(env[m] * rat[m]) / 2.0 : log(env[m]) / 2.0;
+      const double val = log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
       if (m < M || lane == 0) ls[k] = val;
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     cpx mp[MB];
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(64) void synth_pulse_kernel(
     // GetNoiseSpectrum (:19-33)
     cpx v[M];
     {
-      const int roff = idx - idx0;
+      const int roff = r.roff;
       double sum = 0.0;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -490,6 +518,21 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   if (chunk > total_p) chunk = total_p;
   rc = c.ensure_scratch(chunk * F);
   if (rc) return rc;
+  if (total_p > b.pulse_rec_cap) {
+    if (b.d_pulse_rec) (void)hipFree(b.d_pulse_rec);
+    b.d_pulse_rec = nullptr;
+    b.pulse_rec_cap = 0;
+    rc = wm_check(hipMalloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)(total_p + total_p / 8 + 64)));
+    if (rc) return rc;
+    b.pulse_rec_cap = total_p + total_p / 8 + 64;
+  }
+  {
+    int max_np = 0;
+    for (int u = 0; u < b.n_utt; ++u) max_np = b.h_pulse_cnt[u] > max_np ? b.h_pulse_cnt[u] : max_np;
+    hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (max_np + 255) / 256), b.n_utt), dim3(256), 0, st,
+                       b.d_f_off, b.d_y_off, b.d_pulse_off, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,
+                       (PulseRec*)b.d_pulse_rec);
+  }
   const int ola_tiles = (b.max_y_len + 255) / 256;
   for (int64_t p0 = 0; p0 < total_p; p0 += chunk) {
     const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
@@ -497,9 +540,8 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
 #define WM_SY_CASE(FF)                                                                                          \
   case FF:                                                                                                      \
-    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(grid), dim3(64), 0, st, d_f0, d_sp, d_ap, b.d_f_off,         \
-                       b.d_y_off, b.d_pulse_off, b.n_utt, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,              \
-                       b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);                                   \
+    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(grid), dim3(64), 0, st, d_sp, d_ap,                          \
+                       (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);    \
     break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
