@@ -38,6 +38,16 @@ struct Context {
   void timing_clear();
 };
 
+// Grid of a persistent (grid-stride) kernel: exactly the workgroups that are resident at once, so
+// that every wave slot gets the same share of frames and there is no half-empty second round.
+template <class K> inline int persistent_grid(const Context& c, K kernel, int block, int64_t items) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  const int64_t g = (int64_t)c.num_cu * per_cu;
+  return (int)(items < g ? items : g);
+}
+
 // RAII bracket: records a start/stop event pair around the launches in its scope.
 struct TimedScope {
   Context* c;
@@ -95,6 +105,9 @@ struct Batch {
   int64_t* d_dio_ev_off = nullptr;   // per utterance base into events (in doubles)
   std::vector<int64_t> dio_ev_off;
   int* d_dio_ev_cnt = nullptr;       // [utt][band][4]
+  int* d_dio_tile_cnt = nullptr;     // [utt][band][tile + 1][4] per-tile event counts, then offsets
+  double* d_dio_slots = nullptr;     // staged events, [utt][band][4][tiles(utt)][kZcSlot]
+  int64_t* d_dio_slot_off = nullptr; // per utterance base into d_dio_slots
   double* d_dio_cand = nullptr;      // [band][total_f]
   double* d_dio_score = nullptr;     // [band][total_f]
   void* harvest_ws = nullptr;        // HarvestWs (harvest.hip)

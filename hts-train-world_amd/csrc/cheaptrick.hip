@@ -145,10 +145,12 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
   const int grid = (int)(tf < (int64_t)b.ctx->frame_grid ? tf : (int64_t)b.ctx->frame_grid);
   if (grid <= 0) return 0;
 #define WM_CT_CASE(FF)                                                                                   \
-  case FF:                                                                                               \
-    hipLaunchKernelGGL(cheaptrick_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,    \
-                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng, b.p.fs, b.p.q1, tf, d_sp);  \
-    break;
+  case FF: {                                                                                             \
+    static const int per_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF>, 64, (int64_t)1 << 40);        \
+    hipLaunchKernelGGL(cheaptrick_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,   \
+                       b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng, b.p.fs, b.p.q1,   \
+                       tf, d_sp);                                                                        \
+  } break;
   {
   TimedScope ts_(b.ctx, "cheaptrick_kernel");
   switch (F) {

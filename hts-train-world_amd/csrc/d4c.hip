@@ -777,10 +777,11 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   hipLaunchKernelGGL(d4c_offsets_kernel<0>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)nullptr,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off2);
 #define WM_LT_CASE(FF)                                                                                     \
-  case FF:                                                                                                 \
-    hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(grid), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,   \
-                       b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, b.d_ap0);                  \
-    break;
+  case FF: {                                                                                               \
+    static const int per_ = persistent_grid(c, d4c_lovetrain_kernel<FF>, 64, (int64_t)1 << 40);            \
+    hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,  \
+                       b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, b.d_ap0);       \
+  } break;
   {
     TimedScope ts_(b.ctx, "d4c_lovetrain_kernel");
     switch (FL) {
@@ -800,14 +801,16 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   const bool use_block = var ? (var[0] == 'b') : (FD >= 4096);
 #define WM_D4C_CASE(FF)                                                                                   \
   case FF:                                                                                                \
-    if (use_block)                                                                                        \
+    if (use_block) {                                                                                      \
       hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
                          b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
                          c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
-    else                                                                                                  \
-      hipLaunchKernelGGL((d4c_wave_kernel<FF, 2>), dim3(grid), dim3(64), 0, st, d_x, b.d_x_off,           \
-                         b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
-                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
+    } else {                                                                                              \
+      static const int per_ = persistent_grid(c, d4c_wave_kernel<FF, 2>, 64, (int64_t)1 << 40);           \
+      hipLaunchKernelGGL((d4c_wave_kernel<FF, 2>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,          \
+                         b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,          \
+                         b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);  \
+    }                                                                                                     \
     break;
   {
     TimedScope ts_(b.ctx, "d4c_kernel");

@@ -100,22 +100,50 @@ __global__ __launch_bounds__(256) void dio_lowcut_kernel(
   }
 }
 
-// One workgroup per (utterance, band): Nuttall FIR over the low-cut signal + the four
+// One workgroup per (tile, band, utterance): Nuttall FIR over the low-cut signal + the four
 // ZeroCrossingEngine passes (dio.cpp:296-435), see zcfilter.hpp.
-// events layout per (utt, band): 4 lists of `cap` fine edges.
+// events / staging layout per (utt, band): 4 lists of `cap` fine edges / 4 x tiles x kZcSlot slots.
+template <int STRIDE>
 __global__ __launch_bounds__(256) void dio_band_kernel(
     const int* __restrict__ ylen_a, const int64_t* __restrict__ z_off, const double* __restrict__ z,
-    const double* __restrict__ win, DioMeta meta, const int64_t* __restrict__ ev_off,
-    double* __restrict__ events, int* __restrict__ ev_cnt) {
+    const double* __restrict__ win, DioMeta meta, int tiles_max, int* __restrict__ tile_cnt,
+    const int64_t* __restrict__ slot_off, double* __restrict__ slots) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int u = blockIdx.z, band = blockIdx.y, tile = blockIdx.x;
+  const int ylen = ylen_a[u];
+  const int nt = zc_tiles(ylen);
+  if (tile >= nt) return;
+  const int hal = meta.hal[band];
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+  // filtered[n] = sum_{k < 4 hal} w[k] z[n + 2 hal - k]  (dio.cpp:310-337)
+  filter_tile_events<STRIDE>(z + z_off[u] + meta.pad, -meta.pad, ylen + meta.pad, ylen, win + meta.win_off[band],
+                             4 * hal, 2 * hal, tile,
+                             tile_cnt + (((int64_t)u * meta.nb + band) * (tiles_max + 1) + tile) * 4,
+                             slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, lds);
+}
+
+__global__ __launch_bounds__(64) void dio_band_scan_kernel(const int* __restrict__ ylen_a, DioMeta meta,
+                                                           int tiles_max, int* __restrict__ tile_cnt,
+                                                           int* __restrict__ ev_cnt) {
   const int u = blockIdx.y, band = blockIdx.x;
   const int ylen = ylen_a[u];
-  const int hal = meta.hal[band];
+  zc_scan_tiles(tile_cnt + ((int64_t)u * meta.nb + band) * (tiles_max + 1) * 4, zc_tiles(ylen), ylen / 2 + 2,
+                ev_cnt + ((int64_t)u * meta.nb + band) * 4, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void dio_band_compact_kernel(
+    const int* __restrict__ ylen_a, DioMeta meta, int tiles_max, const int* __restrict__ tile_cnt,
+    const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ ev_off,
+    double* __restrict__ events) {
+  const int u = blockIdx.z, band = blockIdx.y, tile = blockIdx.x;
+  const int ylen = ylen_a[u];
+  const int nt = zc_tiles(ylen);
+  if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
-  // filtered[n] = sum_{k < 4 hal} w[k] z[n + 2 hal - k]  (dio.cpp:310-337)
-  filter_and_events(z + z_off[u] + meta.pad, -meta.pad, ylen + meta.pad, ylen, win + meta.win_off[band], 4 * hal,
-                    2 * hal, events + ev_off[u] + (int64_t)band * 4 * cap, cap,
-                    ev_cnt + ((int64_t)u * meta.nb + band) * 4, lds);
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+  const int* off = tile_cnt + (((int64_t)u * meta.nb + band) * (tiles_max + 1) + tile) * 4;
+  zc_compact_tile(slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, tile, off, off + 4,
+                  events + ev_off[u] + (int64_t)band * 4 * cap, cap);
 }
 
 __global__ __launch_bounds__(256) void dio_candidate_kernel(
@@ -352,6 +380,15 @@ static int dio_setup(Batch& b) {
   al((void**)&b.d_dio_z, sizeof(double) * (size_t)b.dio_z_off[(size_t)b.n_utt]);
   al((void**)&b.d_dio_events, sizeof(double) * (size_t)b.dio_ev_off[(size_t)b.n_utt]);
   al((void**)&b.d_dio_ev_cnt, sizeof(int) * (size_t)b.n_utt * m.nb * 4);
+  al((void**)&b.d_dio_tile_cnt,
+     sizeof(int) * (size_t)b.n_utt * m.nb * 4 * ((size_t)zc_tiles(b.max_x_len / m.ratio + 1) + 1));
+  {
+    std::vector<int64_t> soff((size_t)b.n_utt + 1, 0);
+    for (int u = 0; u < b.n_utt; ++u)
+      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nb * 4 * zc_tiles(ylens[(size_t)u]) * kZcSlot;
+    up((void**)&b.d_dio_slot_off, soff.data(), sizeof(int64_t) * soff.size());
+    al((void**)&b.d_dio_slots, sizeof(double) * (size_t)soff[(size_t)b.n_utt]);
+  }
   al((void**)&b.d_dio_cand, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_score, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_ws, sizeof(double) * 3 * (size_t)b.total_f);
@@ -395,10 +432,27 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
   }
   {
-    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles(4 * m.hal[0]);
+    // row stride of the LDS tile by the longest filter: 16 kHz fits the small one, 48 kHz needs the large
+    const int ntap_max = 4 * m.hal[0];
+    const bool small = ntap_max <= zc_max_taps<kZcStrideDio>();
+    if (!small && ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(double) * (size_t)(small ? zc_lds_doubles<kZcStrideDio>(ntap_max)
+                                                       : zc_lds_doubles<kZcStrideHarvest>(ntap_max));
+    const int tiles_max = zc_tiles(b.max_x_len / m.ratio + 1);
     TimedScope ts_(b.ctx, "dio_band_kernel");
-    hipLaunchKernelGGL(dio_band_kernel, dim3(m.nb, b.n_utt), dim3(256), lds, st, b.d_dio_ylen, b.d_dio_z_off,
-                       b.d_dio_z, b.d_dio_win, m, b.d_dio_ev_off, b.d_dio_events, b.d_dio_ev_cnt);
+    if (small)
+      hipLaunchKernelGGL((dio_band_kernel<kZcStrideDio>), dim3(tiles_max, m.nb, b.n_utt), dim3(256), lds, st,
+                         b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, b.d_dio_win, m, tiles_max, b.d_dio_tile_cnt,
+                         b.d_dio_slot_off, b.d_dio_slots);
+    else
+      hipLaunchKernelGGL((dio_band_kernel<kZcStrideHarvest>), dim3(tiles_max, m.nb, b.n_utt), dim3(256), lds, st,
+                         b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, b.d_dio_win, m, tiles_max, b.d_dio_tile_cnt,
+                         b.d_dio_slot_off, b.d_dio_slots);
+    hipLaunchKernelGGL(dio_band_scan_kernel, dim3(m.nb, b.n_utt), dim3(64), 0, st, b.d_dio_ylen, m, tiles_max,
+                       b.d_dio_tile_cnt, b.d_dio_ev_cnt);
+    hipLaunchKernelGGL(dio_band_compact_kernel, dim3(tiles_max, m.nb, b.n_utt), dim3(256), 0, st, b.d_dio_ylen, m,
+                       tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off, b.d_dio_slots, b.d_dio_ev_off,
+                       b.d_dio_events);
   }
   {
     const int gx = (int)((b.total_f + 255) / 256);

@@ -55,6 +55,8 @@ struct HarvestWs {
   double* d_bf = nullptr; int* d_half = nullptr; int* d_tapoff = nullptr; double* d_taps = nullptr;
   double* d_y = nullptr; double* d_tmp = nullptr;
   double* d_events = nullptr; int* d_evcnt = nullptr;
+  int* d_tile_cnt = nullptr; int tiles_max = 0;
+  double* d_slots = nullptr; int64_t* d_slot_off = nullptr;
   double* d_raw = nullptr; double* d_offc = nullptr; int* d_cnt = nullptr; int* d_ncand1 = nullptr;
   double *d_rc = nullptr, *d_rs = nullptr, *d_rc2 = nullptr, *d_rs2 = nullptr;
   double* d_work = nullptr;                    // [8][tot_b] contour work arrays
@@ -91,20 +93,49 @@ __global__ __launch_bounds__(256) void hv_mean_kernel(const int64_t* __restrict_
 }
 
 // ---- filterbank + events --------------------------------------------------------------------
+// One workgroup per (tile, channel, utterance); events are staged per tile, then scanned and
+// compacted into the ordered lists (zcfilter.hpp).
 __global__ __launch_bounds__(256) void hv_band_kernel(const int64_t* __restrict__ yoff,
                                                       const int* __restrict__ ylen_a, const double* __restrict__ y,
                                                       const double* __restrict__ taps,
                                                       const int* __restrict__ tapoff, const int* __restrict__ half,
-                                                      int nch, const int64_t* __restrict__ evoff,
-                                                      double* __restrict__ events, int* __restrict__ evcnt) {
+                                                      int nch, int tiles_max, int* __restrict__ tile_cnt,
+                                                      const int64_t* __restrict__ slot_off,
+                                                      double* __restrict__ slots) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int u = blockIdx.z, ch = blockIdx.y, tile = blockIdx.x;
+  const int ylen = ylen_a[u];
+  const int nt = zc_tiles(ylen);
+  if (tile >= nt) return;
+  const int hf = half[ch];
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+  // filtered[n] = sum_k bp[k] y[n + (half + 1) - k], k < 2 half + 1 (harvest.cpp:101-142)
+  filter_tile_events<kZcStrideHarvest>(y + yoff[u], 0, ylen, ylen, taps + tapoff[ch], 2 * hf + 1, hf + 1, tile,
+                                       tile_cnt + (((int64_t)u * nch + ch) * (tiles_max + 1) + tile) * 4,
+                                       slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, lds);
+}
+
+__global__ __launch_bounds__(64) void hv_band_scan_kernel(const int* __restrict__ ylen_a, int nch, int tiles_max,
+                                                          int* __restrict__ tile_cnt, int* __restrict__ evcnt) {
   const int u = blockIdx.y, ch = blockIdx.x;
   const int ylen = ylen_a[u];
+  zc_scan_tiles(tile_cnt + ((int64_t)u * nch + ch) * (tiles_max + 1) * 4, zc_tiles(ylen), ylen / 2 + 2,
+                evcnt + ((int64_t)u * nch + ch) * 4, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void hv_band_compact_kernel(
+    const int* __restrict__ ylen_a, int nch, int tiles_max, const int* __restrict__ tile_cnt,
+    const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ evoff,
+    double* __restrict__ events) {
+  const int u = blockIdx.z, ch = blockIdx.y, tile = blockIdx.x;
+  const int ylen = ylen_a[u];
+  const int nt = zc_tiles(ylen);
+  if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
-  const int hf = half[ch];
-  // filtered[n] = sum_k bp[k] y[n + (half + 1) - k], k < 2 half + 1 (harvest.cpp:101-142)
-  filter_and_events(y + yoff[u], 0, ylen, ylen, taps + tapoff[ch], 2 * hf + 1, hf + 1,
-                    events + evoff[u] + (int64_t)ch * 4 * cap, cap, evcnt + ((int64_t)u * nch + ch) * 4, lds);
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+  const int* off = tile_cnt + (((int64_t)u * nch + ch) * (tiles_max + 1) + tile) * 4;
+  zc_compact_tile(slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, tile, off, off + 4,
+                  events + evoff[u] + (int64_t)ch * 4 * cap, cap);
 }
 
 // raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
@@ -684,6 +715,19 @@ static int hv_setup(Batch& b) {
   if (m.r > 1) al((void**)&W->d_tmp, sizeof(double) * (size_t)W->tot_t);
   al((void**)&W->d_events, sizeof(double) * (size_t)W->tot_ev);
   al((void**)&W->d_evcnt, sizeof(int) * (size_t)n_utt * m.nch * 4);
+  {
+    int ymax = 1;
+    for (int u = 0; u < n_utt; ++u) ymax = imax(ymax, W->ylen[(size_t)u]);
+    W->tiles_max = zc_tiles(ymax);
+  }
+  al((void**)&W->d_tile_cnt, sizeof(int) * (size_t)n_utt * m.nch * 4 * ((size_t)W->tiles_max + 1));
+  {
+    std::vector<int64_t> soff((size_t)n_utt + 1, 0);
+    for (int u = 0; u < n_utt; ++u)
+      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nch * 4 * zc_tiles(W->ylen[(size_t)u]) * kZcSlot;
+    up((void**)&W->d_slot_off, soff.data(), sizeof(int64_t) * soff.size());
+    al((void**)&W->d_slots, sizeof(double) * (size_t)soff[(size_t)n_utt]);
+  }
   al((void**)&W->d_raw, sizeof(double) * (size_t)W->tot_b * m.nch);
   al((void**)&W->d_offc, sizeof(double) * (size_t)W->tot_b * m.cpf);
   al((void**)&W->d_cnt, sizeof(int) * (size_t)W->tot_b);
@@ -732,9 +776,15 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   hipLaunchKernelGGL(hv_mean_kernel, dim3(n_utt), dim3(256), 0, st, W.d_yoff, W.d_ylen, W.d_y);
   {
     TimedScope ts_(b.ctx, "hv_band_kernel");
-    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles(m.ntap_max);
-    hipLaunchKernelGGL(hv_band_kernel, dim3(m.nch, n_utt), dim3(256), lds, st, W.d_yoff, W.d_ylen, W.d_y, W.d_taps,
-                       W.d_tapoff, W.d_half, m.nch, W.d_evoff, W.d_events, W.d_evcnt);
+    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles<kZcStrideHarvest>(m.ntap_max);
+    if (m.ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(hv_band_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), lds, st, W.d_yoff, W.d_ylen,
+                       W.d_y, W.d_taps, W.d_tapoff, W.d_half, m.nch, W.tiles_max, W.d_tile_cnt, W.d_slot_off,
+                       W.d_slots);
+    hipLaunchKernelGGL(hv_band_scan_kernel, dim3(m.nch, n_utt), dim3(64), 0, st, W.d_ylen, m.nch, W.tiles_max,
+                       W.d_tile_cnt, W.d_evcnt);
+    hipLaunchKernelGGL(hv_band_compact_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
+                       W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
   }
   const int gx = (int)((W.tot_b + 255) / 256);
   {

@@ -539,10 +539,11 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     const int64_t np = p1 - p0;
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
 #define WM_SY_CASE(FF)                                                                                          \
-  case FF:                                                                                                      \
-    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(grid), dim3(64), 0, st, d_sp, d_ap,                          \
+  case FF: {                                                                                                    \
+    static const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
+    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
                        (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);    \
-    break;
+  } break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
       switch (F) {

@@ -1,8 +1,16 @@
 // zcfilter.hpp -- FIR filtering fused with the four zero-crossing event passes, shared by DIO and
 // Harvest (externs/WORLD_v2/src/dio.cpp:296-435 and harvest.cpp:99-238 are the same construction
-// with different filters).  One 256-thread workgroup filters one (utterance, band) signal tile by
-// tile and appends the fine zero-crossing positions of each of the four event kinds to ordered
-// lists (ballot + popcount compaction keeps the reference's sample order).
+// with different filters).
+//
+// The ordered event lists need a running count along the signal; walking the tiles of one signal one
+// after another makes that walk (tens of tiles, thousands of FMAs per thread each) the critical
+// path of the whole launch.  Here every tile of every (utterance, band) signal is its own 256-thread
+// workgroup and the ordering is restored afterwards:
+//   filter_tile_events   filter the tile, write its events (in order) into the tile's own slot of a
+//                        staging array and its four counts
+//   zc_scan_tiles        per-tile counts -> exclusive offsets, list lengths
+//   zc_compact_tile      move the tile's events from the slot to offset + rank of the ordered lists
+// Only actual events travel twice; the FIR runs once.
 #pragma once
 #include "common.hpp"
 
@@ -10,136 +18,216 @@ namespace wm {
 
 constexpr int kBandK = 8;                       // outputs per thread
 constexpr int kBandTile = 256 * kBandK;         // samples per tile
+constexpr int kZcStep = kBandTile - 2;          // tiles overlap by 2 (s[i+1], s[i+2] look-ahead)
+constexpr int kZcSlot = 1024;                   // staging slots per tile and event kind
+// Row stride (doubles) of the transposed signal tile; the two users pick the smallest that holds their
+// longest filter.  stride % 32 == 24 spreads the 8 rows over distinct LDS bank groups.
+constexpr int kZcStrideDio = 312;               // taps <= 8 * 311 - 2056 = 432
+constexpr int kZcStrideHarvest = 408;           // taps <= 8 * 407 - 2056 = 1200
 
-// LDS doubles needed by filter_and_events() for filters of up to ntap_max taps
-__host__ __device__ inline int zc_pad8(int n) { return (n + 7) & ~7; }
-__host__ __device__ inline int zc_lds_doubles(int ntap_max) {
-  const int zspan = kBandTile + zc_pad8(ntap_max) + 8;
-  const int stride = (zspan + kBandK - 1) / kBandK + 1;
-  return kBandK * stride + zc_pad8(ntap_max) + kBandTile;
+__host__ __device__ inline int zc_pad16(int n) { return (n + 15) & ~15; }
+__host__ __device__ inline int zc_tiles(int ylen) { return (ylen + kZcStep - 1) / kZcStep; }
+template <int STRIDE> __host__ __device__ inline int zc_max_taps() { return 8 * (STRIDE - 1) - kBandTile - 8; }
+// LDS doubles needed for filters of up to ntap_max taps
+template <int STRIDE> __host__ __device__ inline int zc_lds_doubles(int ntap_max) {
+  return kBandK * STRIDE + zc_pad16(ntap_max) + kBandTile;
 }
 
 // filtered[n] = sum_{k < ntap} taps[k] * sig[n + bias - k], n in [0, ylen), where sig[m] is read for
 // m in [lo, hi) and is zero elsewhere.  Events (ZeroCrossingEngine, dio.cpp:357-393) of the four
-// kinds go to ev[kind * cap + i] in order; ev_cnt4[kind] receives the number of edges.
-// Kinds (dio.cpp:402-435): 0 negative-going, 1 positive-going, 2 peaks, 3 dips.
-__device__ __forceinline__ void filter_and_events(const double* __restrict__ sig, int lo, int hi, int ylen,
-                                                  const double* __restrict__ taps, int ntap, int bias,
-                                                  double* __restrict__ ev, int cap, int* __restrict__ ev_cnt4,
-                                                  double* lds) {
-  // LDS: transposed signal tile (element e at [(e % K) * stride + e / K]), taps (zero-padded to a
-  // multiple of 8), filtered tile.  The tile carries 8 extra leading elements so that the 8-tap
-  // register rotation below never indexes below zero.
-  const int ntp = zc_pad8(ntap);
-  const int zspan = kBandTile + ntp + 8;                        // elements needed per tile
-  const int stride = (zspan + kBandK - 1) / kBandK + 1;
-  double* zt = lds;                                             // [K * stride]
-  double* w = zt + kBandK * stride;                             // [ntp]
+// kinds go to ev[kind * cap + i] in order.  Kinds (dio.cpp:402-435): 0 negative-going,
+// 1 positive-going, 2 peaks, 3 dips.
+// The tile's events of kind K go to slot[K * slot_cap + tile * kZcSlot + rank] in sample order and
+// tile_cnt4[K] receives their number (an event kind cannot fire on two consecutive samples, so a
+// tile of 2046 samples holds at most 1023 of a kind).
+//
+// Layout.  Tile element e (signal index zbase + e) sits at zt[(e % 8) * STRIDE + e / 8], so that the
+// eight consecutive outputs of a thread and their sliding window are eight conflict-free rows.
+// Thread t produces outputs n0 + 8t + q; at tap k output q reads element 8t + ntp + 7 + q - k.
+// Taps go 16 per trip in two groups of 8.  A group holds the 8 window elements of its first tap
+// in registers and loads the 8 elements below them; all 64 products of the group then use static
+// register indices.  The second group takes the first group's loads as its window and loads into
+// the registers of the old window, so the window slides without a single register move, and with
+// STRIDE a compile-time constant every LDS address is one moving column plus an immediate.
+// Wave w owns the 512 consecutive samples [512 w, 512 w + 512) of the tile, as 8 rows of 64.
+template <int STRIDE>
+__device__ __forceinline__ void filter_tile_events(const double* __restrict__ sig, int lo, int hi, int ylen,
+                                                   const double* __restrict__ taps, int ntap, int bias, int tile,
+                                                   int* __restrict__ tile_cnt4, double* __restrict__ slot,
+                                                   int64_t slot_cap, double* lds) {
+  const int ntp = zc_pad16(ntap);
+  const int zspan = kBandTile + ntp + 8;
+  double* zt = lds;                                             // [8 * STRIDE]
+  double* w = zt + kBandK * STRIDE;                             // [ntp], zero-padded taps
   double* s = w + ntp;                                          // [kBandTile] filtered samples
   __shared__ int wave_cnt[4][4];                                // [kind][wave]
-  __shared__ int run_cnt[4];
-  for (int j = threadIdx.x; j < ntp; j += 256) w[j] = j < ntap ? taps[j] : 0.0;
-  if (threadIdx.x < 4) run_cnt[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int step = kBandTile - 2;                               // tiles overlap by 2 (s[i+1], s[i+2] look-ahead)
-
-  for (int n0 = 0; n0 < ylen; n0 += step) {
-    __syncthreads();
-    // tile element e <-> signal index zbase + e with zbase = n0 + bias - (ntp - 1) - 8
+  const int n0 = tile * kZcStep;
+  for (int j = threadIdx.x; j < ntp; j += 256) w[j] = j < ntap ? taps[j] : 0.0;
+  {
+    // 8 extra leading elements keep the lowest load of the last group inside the tile
     const int zbase = n0 + bias - (ntp - 1) - 8;
     for (int e = threadIdx.x; e < zspan; e += 256) {
       const int m = zbase + e;
-      const double val = (m >= lo && m < hi) ? sig[m] : 0.0;
-      zt[(e % kBandK) * stride + e / kBandK] = val;
-    }
-    __syncthreads();
-    // thread t: outputs n0 + t*K + q, q < K; output q at tap k reads element
-    // e = t*K + q + (ntp - 1) + 8 - k.  Taps are consumed 8 at a time: the 8 window registers
-    // r[q] (elements for tap k) and 8 freshly loaded lower elements nw[] cover all 64 products of
-    // the group with static register indices, so the window slides without register moves.
-    {
-      double acc[kBandK];
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
-      const int t = threadIdx.x;
-      const int ebase = t * kBandK + (ntp - 1) + 8;             // element of output 0 at tap 0
-      double r[kBandK];
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) {
-        const int e = ebase + q;
-        r[q] = zt[(e % kBandK) * stride + e / kBandK];
-      }
-      for (int k = 0; k < ntp; k += 8) {
-        double nw[8], wk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = ebase - k - 1 - i;                      // >= 0 thanks to the 8 leading elements
-          nw[i] = zt[(e % kBandK) * stride + e / kBandK];
-          wk[i] = w[k + i];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-          for (int q = 0; q < kBandK; ++q) {
-            const double el = (q - j >= 0) ? r[(q - j) & 7] : nw[(j - q - 1) & 7];
-            acc[q] += wk[j] * el;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < kBandK; ++q) r[q] = nw[7 - q];
-      }
-#pragma unroll
-      for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
-    }
-    __syncthreads();
-    // ---- zero crossings over samples i in [n0, n0 + step) ----
-    for (int rowb = 0; rowb < step; rowb += 256) {
-      const int li = rowb + threadIdx.x;          // local index
-      const int i = n0 + li;
-      bool f[4] = {false, false, false, false};
-      double fine[4] = {0.0, 0.0, 0.0, 0.0};
-      if (li < step && i < ylen - 1) {
-        const double a = s[li], b = s[li + 1];
-        // kind 0: positive -> non-positive (dio.cpp:361-363); kind 1 on the negated signal (:419-422)
-        f[0] = 0.0 < a && b <= 0.0;
-        f[1] = 0.0 < -a && -b <= 0.0;
-        if (f[0] || f[1]) fine[f[0] ? 0 : 1] = (i + 1) - a / (b - a);          // :378-382
-        if (i < ylen - 2) {
-          const double c = s[li + 2];
-          const double p0 = b - a, p1 = c - b;     // (-s[i]) - (-s[i+1]) (:424-425)
-          f[2] = 0.0 < p0 && p1 <= 0.0;
-          f[3] = 0.0 < -p0 && -p1 <= 0.0;
-          if (f[2] || f[3]) fine[f[2] ? 2 : 3] = (i + 1) - p0 / (p1 - p0);
-        }
-      }
-      unsigned long long bal[4];
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        bal[ty] = __ballot(f[ty]);
-        if (lane == 0) wave_cnt[ty][wv] = __popcll(bal[ty]);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        int base = run_cnt[ty];
-        for (int q = 0; q < wv; ++q) base += wave_cnt[ty][q];
-        if (f[ty]) {
-          const int rank = __popcll(bal[ty] & ((1ull << lane) - 1ull));
-          const int dst = base + rank;
-          if (dst < cap) ev[(int64_t)ty * cap + dst] = fine[ty];
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < 4) {
-        int tot = 0;
-        for (int q = 0; q < 4; ++q) tot += wave_cnt[threadIdx.x][q];
-        run_cnt[threadIdx.x] += tot;
-      }
-      __syncthreads();
+      const double val = sig[imin(hi - 1, imax(lo, m))];        // clamped address, no branch around the load
+      zt[(e & 7) * STRIDE + (e >> 3)] = (m >= lo && m < hi) ? val : 0.0;
     }
   }
   __syncthreads();
-  if (threadIdx.x < 4) ev_cnt4[threadIdx.x] = imin(run_cnt[threadIdx.x], cap);
+  {
+    double acc[kBandK];
+#pragma unroll
+    for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
+    const int t = threadIdx.x;
+    // window at tap 0: elements 8t + ntp + 7 + q -> q = 0: row 7, column t + ntp/8; q >= 1: row q - 1, one further
+    const double* zc = zt + t + ntp / 8;                        // column of the current group's loads
+    double a[8], b[8];
+    a[0] = zc[7 * STRIDE];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) a[q] = zc[(q - 1) * STRIDE + 1];
+    const double2* w2 = reinterpret_cast<const double2*>(w);
+    for (int k = 0; k < ntp; k += 16) {
+      // group 1: window a[], loads b[i] = element 8t + ntp + 6 - k - i
+      double wk[8];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) b[i] = zc[(6 - i) * STRIDE];
+      b[7] = zc[7 * STRIDE - 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double2 p = w2[k / 2 + i];
+        wk[2 * i] = p.x;
+        wk[2 * i + 1] = p.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int q = 0; q < kBandK; ++q) acc[q] += wk[j] * ((q - j >= 0) ? a[(q - j) & 7] : b[(j - q - 1) & 7]);
+      }
+      // group 2: window is b[] reversed (b[7 - q]), loads go into a[] reversed (a[7 - i])
+#pragma unroll
+      for (int i = 0; i < 7; ++i) a[7 - i] = zc[(6 - i) * STRIDE - 1];
+      a[0] = zc[7 * STRIDE - 2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double2 p = w2[k / 2 + 4 + i];
+        wk[2 * i] = p.x;
+        wk[2 * i + 1] = p.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int q = 0; q < kBandK; ++q)
+          acc[q] += wk[j] * ((q - j >= 0) ? b[(7 - (q - j)) & 7] : a[(7 - (j - q - 1)) & 7]);
+      }
+      zc -= 2;
+    }
+#pragma unroll
+    for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
+  }
+  __syncthreads();
+  // ---- zero crossings (ZeroCrossingEngine, dio.cpp:357-393; kinds :402-435) ----
+  int cnt[4] = {0, 0, 0, 0};
+  unsigned fbits = 0;
+#pragma unroll
+  for (int row = 0; row < 8; ++row) {
+    const int li = wv * 512 + row * 64 + lane;
+    const int i = n0 + li;
+    bool f[4] = {false, false, false, false};
+    if (li < kZcStep && i < ylen - 1) {
+      const double x0 = s[li], x1 = s[li + 1];
+      f[0] = 0.0 < x0 && x1 <= 0.0;                             // positive -> non-positive (:361-363)
+      f[1] = 0.0 < -x0 && -x1 <= 0.0;                           // same on the negated signal (:419-422)
+      if (i < ylen - 2) {
+        const double x2 = s[li + 2];
+        const double p0 = x1 - x0, p1 = x2 - x1;                // (:424-425)
+        f[2] = 0.0 < p0 && p1 <= 0.0;
+        f[3] = 0.0 < -p0 && -p1 <= 0.0;
+      }
+    }
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      cnt[ty] += __popcll(__ballot(f[ty]));
+      fbits |= (f[ty] ? 1u : 0u) << (4 * row + ty);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) wave_cnt[ty][wv] = cnt[ty];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    tile_cnt4[threadIdx.x] = wave_cnt[threadIdx.x][0] + wave_cnt[threadIdx.x][1] + wave_cnt[threadIdx.x][2] +
+                             wave_cnt[threadIdx.x][3];
+  int base[4];
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    base[ty] = tile * kZcSlot;
+    for (int q = 0; q < wv; ++q) base[ty] += wave_cnt[ty][q];
+  }
+#pragma unroll
+  for (int row = 0; row < 8; ++row) {
+    const int li = wv * 512 + row * 64 + lane;
+    const int i = n0 + li;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      const bool f = (fbits >> (4 * row + ty)) & 1u;
+      const unsigned long long bal = __ballot(f);
+      if (f) {
+        const double x0 = s[li], x1 = s[li + 1];
+        double fine;
+        if (ty < 2) {
+          fine = (i + 1) - x0 / (x1 - x0);                      // :378-382
+        } else {
+          const double x2 = s[li + 2];
+          const double p0 = x1 - x0, p1 = x2 - x1;
+          fine = (i + 1) - p0 / (p1 - p0);
+        }
+        const int dst = base[ty] + __popcll(bal & ((1ull << lane) - 1ull));
+        slot[(int64_t)ty * slot_cap + dst] = fine;
+      }
+      base[ty] += __popcll(bal);
+    }
+  }
+}
+
+// per-tile event counts -> exclusive offsets (in place; entry ntiles receives the total) and the list
+// lengths; one wavefront per signal.  tile_cnt has 4 * (ntiles + 1) entries.
+__device__ __forceinline__ void zc_scan_tiles(int* __restrict__ tile_cnt, int ntiles, int cap,
+                                              int* __restrict__ ev_cnt4, int lane) {
+  int run[4] = {0, 0, 0, 0};
+  for (int t0 = 0; t0 < ntiles; t0 += 64) {
+    const int t = t0 + lane;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      const int c = t < ntiles ? tile_cnt[4 * t + ty] : 0;
+      const int incl = wave_scan_incl_i(c);
+      if (t < ntiles) tile_cnt[4 * t + ty] = run[ty] + incl - c;
+      run[ty] += __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+  if (lane < 4) {
+    int v = run[0];
+    if (lane == 1) v = run[1];
+    if (lane == 2) v = run[2];
+    if (lane == 3) v = run[3];
+    ev_cnt4[lane] = imin(v, cap);
+    tile_cnt[4 * ntiles + lane] = v;                            // end offset of the last tile
+  }
+}
+
+// move one tile's staged events to their place in the ordered lists: off4 / end4 are the tile's and
+// the next tile's entries of the scanned offsets
+__device__ __forceinline__ void zc_compact_tile(const double* __restrict__ slot, int64_t slot_cap, int tile,
+                                                const int* __restrict__ off4, const int* __restrict__ end4,
+                                                double* __restrict__ ev, int cap) {
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    const int off = off4[ty];
+    const int n = end4[ty] - off;
+    const double* src = slot + (int64_t)ty * slot_cap + (int64_t)tile * kZcSlot;
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+      if (off + j < cap) ev[(int64_t)ty * cap + off + j] = src[j];
+  }
 }
 
 // interp1 (matlabfunctions.cpp:136-182) over a zero-crossing track given by its fine edges:
