@@ -65,7 +65,9 @@ __device__ __forceinline__ double dio_y(const double* __restrict__ xu, int n, in
 }
 
 // z[m] = sum_lag h(lag) y[(m - lag) mod fft], m in [-pad, ylen + pad); stored at z[m + pad].
-constexpr int kLcTile = 1024;
+// Tiles of 2048 outputs, 8 per thread, on the register-rotation FIR core of zcfilter.hpp
+// (h is symmetric in the lag, so h[j] with j = lag + cut serves as the tap sequence directly).
+template <int STRIDE>
 __global__ __launch_bounds__(256) void dio_lowcut_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ ylen_a, const double* __restrict__ mean, const int* __restrict__ fft_sizes,
@@ -75,27 +77,27 @@ __global__ __launch_bounds__(256) void dio_lowcut_kernel(
   const int n = x_len[u], ylen = ylen_a[u], fftn = fft_sizes[u];
   const int cut = meta.cut, ntap = 2 * cut + 1;
   const int total = ylen + 2 * meta.pad;
-  const int m0 = blockIdx.x * kLcTile;              // tile start in z-storage coordinates
+  const int m0 = blockIdx.x * kBandTile;            // tile start in z-storage coordinates
   if (m0 >= total) return;
-  double* ytile = lds;                              // [kLcTile + 2 cut]
-  double* h = lds + (kLcTile + 2 * cut);            // [ntap], h[j] = filter at lag (j - cut)
+  const int ntp = zc_pad16(ntap);
+  const int zspan = kBandTile + ntp + 8;
+  double* zt = lds;                                 // [8 * STRIDE] transposed tile
+  double* w = lds + kBandK * STRIDE;                // [ntp] taps: w[k] = h(lag = k - cut)
   const double* xu = x + x_off[u];
   const double mu = mean[u];
-  for (int j = threadIdx.x; j < ntap; j += 256) h[j] = lowcut[j];
-  for (int j = threadIdx.x; j < kLcTile + 2 * cut; j += 256)
-    ytile[j] = dio_y(xu, n, ylen, fftn, mu, m0 - meta.pad - cut + j);
+  for (int j = threadIdx.x; j < ntp; j += 256) w[j] = j < ntap ? lowcut[j] : 0.0;
+  // output m (storage index m0 + 8t + q) = sum_k w[k] y[(m0 + 8t + q) - pad - (k - cut)]: tile element e is
+  // y[m0 - pad + cut - (ntp - 1) - 8 + e]
+  const int ybase = m0 - meta.pad + cut - (ntp - 1) - 8;
+  for (int e = threadIdx.x; e < zspan; e += 256)
+    zt[(e & 7) * STRIDE + (e >> 3)] = dio_y(xu, n, ylen, fftn, mu, ybase + e);
   __syncthreads();
-  // each thread: 4 outputs, strided by 256 (conflict-free LDS reads)
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int j = 0; j < ntap; ++j) {                  // lag = j - cut; y index = m - lag
-    const double hj = h[j];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] += hj * ytile[threadIdx.x + 256 * q + 2 * cut - j];
-  }
+  double acc[kBandK];
+  fir_tile_accumulate<STRIDE>(zt, w, ntp, threadIdx.x, acc);
   double* zu = z + z_off[u];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int m = m0 + threadIdx.x + 256 * q;
+  for (int q = 0; q < kBandK; ++q) {
+    const int m = m0 + threadIdx.x * kBandK + q;
     if (m < total) zu[m] = acc[q];
   }
 }
@@ -182,31 +184,42 @@ __global__ __launch_bounds__(256) void dio_candidate_kernel(
   score[(int64_t)band * total_frames + frame] = sc / (c + kSafe);                        // :564-565
 }
 
-// SelectBestF0, dio.cpp:190-209
-__device__ __forceinline__ double dio_select(double cur, double past, const double* __restrict__ cand,
-                                             int64_t total_frames, int64_t gidx, int nb, double allowed) {
+// SelectBestF0 (dio.cpp:190-209) with the bands spread over the lanes of a wavefront: lane b < nb
+// holds candidate b of the frame.  The reference keeps the FIRST band with a strictly smaller error,
+// i.e. the lowest band among the minima.  cur / past / the result are wave-uniform.
+__device__ __forceinline__ double dio_select_wave(double cur, double past, double cv, int nb, int lane,
+                                                  double allowed) {
   const double ref = (cur * 3.0 - past) / 2.0;
-  double best = cand[gidx];
-  double err = fabs(ref - best);
-  for (int b = 1; b < nb; ++b) {
-    const double cv = cand[(int64_t)b * total_frames + gidx];
-    const double e = fabs(ref - cv);
-    if (e < err) { err = e; best = cv; }
-  }
+  const double err = lane < nb ? fabs(ref - cv) : HUGE_VAL;
+  double m = err;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) m = fmin(m, __shfl_xor(m, sh, 64));
+  const unsigned long long at = __ballot(err == m);
+  const int who = at ? __ffsll((long long)at) - 1 : 0;
+  const double best = __shfl(cv, who, 64);
   if (fabs(1.0 - best / ref) > allowed) return 0.0;
   return best;
 }
 
 // GetBestF0Contour (dio.cpp:112-126) + FixF0Contour / FixStep1-4 (:132-289), one workgroup per
-// utterance.  Steps 1-2 are per-frame parallel; steps 3-4 are sequential along time and run on one
-// lane.  ws holds 3 work arrays of the utterance's frame count.
+// utterance.  Steps 1-2 and the copies are per-frame parallel.  Steps 3-4 are sequential along time
+// by construction (each extension step feeds the next); they run on wavefront 0 with everything that
+// does not depend on the chain taken off it: the rising / falling edges of step 2's contour are
+// compacted into LDS lists up front, the chain state (current and previous f0) lives in registers,
+// the candidates of the next 16 frames are fetched in one round trip with the bands spread over
+// lanes, and results are stored without waiting.
+// ws holds 3 work arrays of the utterance's frame count; dynamic LDS: 2 * (max_nf / 2 + 2) ints.
+constexpr int kFixBlk = 16;
 __global__ __launch_bounds__(256) void dio_fix_kernel(const int64_t* __restrict__ f_off,
                                                       const double* __restrict__ cand,
                                                       const double* __restrict__ score, int nb,
                                                       double frame_period, double f0_floor, double allowed,
-                                                      int64_t total_frames, double* __restrict__ ws,
+                                                      int64_t total_frames, int edge_cap, double* __restrict__ ws,
                                                       double* __restrict__ tpos, double* __restrict__ f0) {
+  extern __shared__ int edges[];                      // [2][edge_cap]: falling (negative), rising (positive)
+  __shared__ int n_edges[2];
   const int u = blockIdx.x;
+  const int lane = threadIdx.x & 63;
   const int64_t base = f_off[u];
   const int nf = (int)(f_off[u + 1] - base);
   double* best = ws + base;
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256) void dio_fix_kernel(const int64_t* __restrict_
     s1[i] = r;
   }
   __syncthreads();
-  // step 2 (dio.cpp:156-169)
+  // step 2 (dio.cpp:156-169); s1 becomes the copy step 3 works on
   const int c = (vrm - 1) / 2;
   for (int i = threadIdx.x; i < nf; i += 256) {
     double r = s1[i];
@@ -248,40 +261,83 @@ __global__ __launch_bounds__(256) void dio_fix_kernel(const int64_t* __restrict_
     s2[i] = r;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  // step 3 (dio.cpp:215-231): forward from each falling edge of s2; result into s1
-  for (int i = 0; i < nf; ++i) s1[i] = s2[i];
-  {
-    int i = 1;
-    while (i < nf) {
-      if (s2[i] == 0 && s2[i - 1] != 0) {                       // negative_index = i - 1
-        const int start = i - 1;
-        int limit = nf - 1;                                     // next negative index, or f0_length - 1
-        for (int q = i + 1; q < nf; ++q)
-          if (s2[q] == 0 && s2[q - 1] != 0) { limit = q - 1; break; }
-        for (int j = start; j < limit; ++j) {
-          s1[j + 1] = dio_select(s1[j], s1[j - 1], cand, total_frames, base + j + 1, nb, allowed);
-          if (s1[j + 1] == 0) break;
+  for (int i = threadIdx.x; i < nf; i += 256) s1[i] = s2[i];
+  // edge lists of s2, in ascending order: falling at i (s2[i] == 0, s2[i-1] != 0), rising at i
+  // (s2[i-1] == 0, s2[i] != 0)
+  if (threadIdx.x < 64) {
+    int cnt0 = 0, cnt1 = 0;
+    for (int i0 = 1; i0 < nf; i0 += 64) {
+      const int i = i0 + lane;
+      const double a = i < nf ? s2[i - 1] : 0.0, bq = i < nf ? s2[i] : 0.0;
+      const bool fall = i < nf && bq == 0 && a != 0;
+      const bool rise = i < nf && a == 0 && bq != 0;
+      const unsigned long long bf = __ballot(fall), br = __ballot(rise);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (fall) edges[cnt0 + __popcll(bf & below)] = i;
+      if (rise) edges[edge_cap + cnt1 + __popcll(br & below)] = i;
+      cnt0 += __popcll(bf);
+      cnt1 += __popcll(br);
+    }
+    if (lane == 0) { n_edges[0] = cnt0; n_edges[1] = cnt1; }
+  }
+  __syncthreads();
+  const int n_fall = n_edges[0], n_rise = n_edges[1];
+  const double* cu = cand + base + (int64_t)(lane < nb ? lane : 0) * total_frames;   // this lane's band
+  // step 3 (dio.cpp:215-231): forward from each falling edge; result in s1
+  if (threadIdx.x < 64) {
+    for (int k = 0; k < n_fall; ++k) {
+      const int start = edges[k] - 1;                           // negative_index
+      const int limit = k + 1 < n_fall ? edges[k + 1] - 1 : nf - 1;
+      __threadfence_block();                                    // an earlier extension may have written these
+      double cur = s1[start], past = s1[start - 1];
+      int j = start;
+      bool stop = false;
+      while (j < limit && !stop) {
+        double blk[kFixBlk];
+#pragma unroll
+        for (int r = 0; r < kFixBlk; ++r) blk[r] = cu[imin(nf - 1, j + 1 + r)];
+#pragma unroll
+        for (int r = 0; r < kFixBlk; ++r) {
+          if (!stop && j < limit) {
+            const double sel = dio_select_wave(cur, past, blk[r], nb, lane, allowed);
+            if (lane == 0) s1[j + 1] = sel;
+            stop = sel == 0;
+            past = cur;
+            cur = sel;
+            ++j;
+          }
         }
       }
-      ++i;
     }
   }
-  // step 4 (dio.cpp:237-253): backward from each rising edge of s2 (positive_index), last first
-  for (int i = 0; i < nf; ++i) out[i] = s1[i];
-  {
-    int i = nf - 1;
-    while (i >= 1) {
-      if (s2[i - 1] == 0 && s2[i] != 0) {                       // positive_index = i
-        int limit = 1;                                          // previous positive index, or 1
-        for (int q = i - 1; q >= 1; --q)
-          if (s2[q - 1] == 0 && s2[q] != 0) { limit = q; break; }
-        for (int j = i; j > limit; --j) {
-          out[j - 1] = dio_select(out[j], out[j + 1], cand, total_frames, base + j - 1, nb, allowed);
-          if (out[j - 1] == 0) break;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nf; i += 256) out[i] = s1[i];
+  __syncthreads();
+  // step 4 (dio.cpp:237-253): backward from each rising edge, last edge first
+  if (threadIdx.x < 64) {
+    for (int k = n_rise - 1; k >= 0; --k) {
+      const int start = edges[edge_cap + k];                    // positive_index
+      const int limit = k > 0 ? edges[edge_cap + k - 1] : 1;
+      __threadfence_block();
+      double cur = out[start], past = out[start + 1];
+      int j = start;
+      bool stop = false;
+      while (j > limit && !stop) {
+        double blk[kFixBlk];
+#pragma unroll
+        for (int r = 0; r < kFixBlk; ++r) blk[r] = cu[imax(0, j - 1 - r)];
+#pragma unroll
+        for (int r = 0; r < kFixBlk; ++r) {
+          if (!stop && j > limit) {
+            const double sel = dio_select_wave(cur, past, blk[r], nb, lane, allowed);
+            if (lane == 0) out[j - 1] = sel;
+            stop = sel == 0;
+            past = cur;
+            cur = sel;
+            --j;
+          }
         }
       }
-      --i;
     }
   }
 }
@@ -425,11 +481,20 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                      b.d_dio_mean);
   {
     const int total_max = b.max_x_len / m.ratio + 1 + 2 * m.pad;
-    const int tiles = (total_max + kLcTile - 1) / kLcTile;
-    const size_t lds = sizeof(double) * (size_t)(kLcTile + 2 * m.cut + 2 * m.cut + 1);
+    const int tiles = (total_max + kBandTile - 1) / kBandTile;
+    const int ntap = 2 * m.cut + 1;
+    const bool small = ntap <= zc_max_taps<kZcStrideHarvest>();
+    if (!small && ntap > zc_max_taps<kZcStrideLong>()) return WM_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(double) * (size_t)((small ? kZcStrideHarvest : kZcStrideLong) * kBandK + zc_pad16(ntap));
     TimedScope ts_(b.ctx, "dio_lowcut_kernel");
-    hipLaunchKernelGGL(dio_lowcut_kernel, dim3(tiles, b.n_utt), dim3(256), lds, st, src, src_off, src_len,
-                       b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off, b.d_dio_z);
+    if (small)
+      hipLaunchKernelGGL(dio_lowcut_kernel<kZcStrideHarvest>, dim3(tiles, b.n_utt), dim3(256), lds, st, src, src_off,
+                         src_len, b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off,
+                         b.d_dio_z);
+    else
+      hipLaunchKernelGGL(dio_lowcut_kernel<kZcStrideLong>, dim3(tiles, b.n_utt), dim3(256), lds, st, src, src_off,
+                         src_len, b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off,
+                         b.d_dio_z);
   }
   {
     // row stride of the LDS tile by the longest filter: 16 kHz fits the small one, 48 kHz needs the large
@@ -463,8 +528,10 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   }
   {
   TimedScope ts_(b.ctx, "dio_fix_kernel");
-  hipLaunchKernelGGL(dio_fix_kernel, dim3(b.n_utt), dim3(256), 0, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,
-                     m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f, b.d_dio_ws, d_t, d_f0);
+  const int edge_cap = b.max_f0_len / 2 + 2;
+  hipLaunchKernelGGL(dio_fix_kernel, dim3(b.n_utt), dim3(256), sizeof(int) * 2 * (size_t)edge_cap, st, b.d_f_off,
+                     b.d_dio_cand, b.d_dio_score, m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f,
+                     edge_cap, b.d_dio_ws, d_t, d_f0);
   }
   return wm_check(hipGetLastError());
 }

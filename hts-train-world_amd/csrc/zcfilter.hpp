@@ -24,6 +24,7 @@ constexpr int kZcSlot = 1024;                   // staging slots per tile and ev
 // longest filter.  stride % 32 == 24 spreads the 8 rows over distinct LDS bank groups.
 constexpr int kZcStrideDio = 312;               // taps <= 8 * 311 - 2056 = 432
 constexpr int kZcStrideHarvest = 408;           // taps <= 8 * 407 - 2056 = 1200
+constexpr int kZcStrideLong = 520;              // taps <= 8 * 519 - 2056 = 2096 (DIO low-cut at 48 kHz)
 
 __host__ __device__ inline int zc_pad16(int n) { return (n + 15) & ~15; }
 __host__ __device__ inline int zc_tiles(int ylen) { return (ylen + kZcStep - 1) / kZcStep; }
@@ -31,6 +32,57 @@ template <int STRIDE> __host__ __device__ inline int zc_max_taps() { return 8 * 
 // LDS doubles needed for filters of up to ntap_max taps
 template <int STRIDE> __host__ __device__ inline int zc_lds_doubles(int ntap_max) {
   return kBandK * STRIDE + zc_pad16(ntap_max) + kBandTile;
+}
+
+// acc[q] = sum_{k < ntp} w[k] * element(8 t + ntp + 7 + q - k) of the transposed tile zt (see
+// filter_tile_events for the layout); ntp is a multiple of 16 and w is zero-padded to it.
+template <int STRIDE>
+__device__ __forceinline__ void fir_tile_accumulate(const double* zt, const double* w, int ntp, int t,
+                                                    double (&acc)[kBandK]) {
+#pragma unroll
+  for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
+  // window at tap 0: elements 8t + ntp + 7 + q -> q = 0: row 7, column t + ntp/8; q >= 1: row q - 1, one further
+  const double* zc = zt + t + ntp / 8;                          // column of the current group's loads
+  double a[8], b[8];
+  a[0] = zc[7 * STRIDE];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) a[q] = zc[(q - 1) * STRIDE + 1];
+  const double2* w2 = reinterpret_cast<const double2*>(w);
+  for (int k = 0; k < ntp; k += 16) {
+    // group 1: window a[], loads b[i] = element 8t + ntp + 6 - k - i
+    double wk[8];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) b[i] = zc[(6 - i) * STRIDE];
+    b[7] = zc[7 * STRIDE - 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double2 p = w2[k / 2 + i];
+      wk[2 * i] = p.x;
+      wk[2 * i + 1] = p.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int q = 0; q < kBandK; ++q) acc[q] += wk[j] * ((q - j >= 0) ? a[(q - j) & 7] : b[(j - q - 1) & 7]);
+    }
+    // group 2: window is b[] reversed (b[7 - q]), loads go into a[] reversed (a[7 - i])
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a[7 - i] = zc[(6 - i) * STRIDE - 1];
+    a[0] = zc[7 * STRIDE - 2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double2 p = w2[k / 2 + 4 + i];
+      wk[2 * i] = p.x;
+      wk[2 * i + 1] = p.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int q = 0; q < kBandK; ++q)
+        acc[q] += wk[j] * ((q - j >= 0) ? b[(7 - (q - j)) & 7] : a[(7 - (j - q - 1)) & 7]);
+    }
+    zc -= 2;
+  }
 }
 
 // filtered[n] = sum_{k < ntap} taps[k] * sig[n + bias - k], n in [0, ylen), where sig[m] is read for
@@ -76,53 +128,9 @@ __device__ __forceinline__ void filter_tile_events(const double* __restrict__ si
   __syncthreads();
   {
     double acc[kBandK];
+    fir_tile_accumulate<STRIDE>(zt, w, ntp, threadIdx.x, acc);
 #pragma unroll
-    for (int q = 0; q < kBandK; ++q) acc[q] = 0.0;
-    const int t = threadIdx.x;
-    // window at tap 0: elements 8t + ntp + 7 + q -> q = 0: row 7, column t + ntp/8; q >= 1: row q - 1, one further
-    const double* zc = zt + t + ntp / 8;                        // column of the current group's loads
-    double a[8], b[8];
-    a[0] = zc[7 * STRIDE];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) a[q] = zc[(q - 1) * STRIDE + 1];
-    const double2* w2 = reinterpret_cast<const double2*>(w);
-    for (int k = 0; k < ntp; k += 16) {
-      // group 1: window a[], loads b[i] = element 8t + ntp + 6 - k - i
-      double wk[8];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) b[i] = zc[(6 - i) * STRIDE];
-      b[7] = zc[7 * STRIDE - 1];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const double2 p = w2[k / 2 + i];
-        wk[2 * i] = p.x;
-        wk[2 * i + 1] = p.y;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int q = 0; q < kBandK; ++q) acc[q] += wk[j] * ((q - j >= 0) ? a[(q - j) & 7] : b[(j - q - 1) & 7]);
-      }
-      // group 2: window is b[] reversed (b[7 - q]), loads go into a[] reversed (a[7 - i])
-#pragma unroll
-      for (int i = 0; i < 7; ++i) a[7 - i] = zc[(6 - i) * STRIDE - 1];
-      a[0] = zc[7 * STRIDE - 2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const double2 p = w2[k / 2 + 4 + i];
-        wk[2 * i] = p.x;
-        wk[2 * i + 1] = p.y;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int q = 0; q < kBandK; ++q)
-          acc[q] += wk[j] * ((q - j >= 0) ? b[(7 - (q - j)) & 7] : a[(7 - (j - q - 1)) & 7]);
-      }
-      zc -= 2;
-    }
-#pragma unroll
-    for (int q = 0; q < kBandK; ++q) s[t * kBandK + q] = acc[q];
+    for (int q = 0; q < kBandK; ++q) s[threadIdx.x * kBandK + q] = acc[q];
   }
   __syncthreads();
   // ---- zero crossings (ZeroCrossingEngine, dio.cpp:357-393; kinds :402-435) ----
