@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
 
 // RemoveUnreliableCandidates (harvest.cpp:652-688): one thread per (frame, slot); neighbours are
 // read from the unmodified table.  Rows 0 and T-1 of the reference's scratch are uninitialised
-// memory; they read as zero here (as in the oracle).
+// memory; they read as zero here.
 __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ bframe_utt,
                                                         const int64_t* __restrict__ boff,
                                                         const int* __restrict__ nb1_a, HvMeta m,

@@ -14,28 +14,46 @@ namespace wm {
 
 constexpr double kFloorF0StoneMask = 40.0;   // constantnumbers.h
 
-// Sum_i a_i e^{-j 2 pi k i / n} for NB bins k[], both windows at once.
-template <int NB>
-__device__ __forceinline__ void sm_bins(const double* __restrict__ xu, int xl, const double* mw, int L,
-                                        double pos, int hw, int fs, const int (&bin)[NB], int fftn, int lane,
-                                        double (&pw)[NB], double (&num)[NB]) {
+// Sum_i a_i e^{-j 2 pi k i / n} for NB bins k[], both windows at once.  The windowed samples
+// am[i] = x_i * main_window[i], ad[i] = x_i * diff_window[i] are read from LDS (FIRST = false) or
+// produced on the way from the window mw[] and the samples xs[] and left in their place (FIRST).
+template <int NB, bool FIRST>
+__device__ __forceinline__ void sm_bins(double* ad_mw, double* am_xs, int L, const int (&bin)[NB], int fftn,
+                                        int lane, double (&pw)[NB], double (&num)[NB]) {
   cpx mainv[NB], diffv[NB], w[NB], st[NB];
+  const double inv_fftn = 1.0 / fftn;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     mainv[b] = make_double2(0.0, 0.0);
     diffv[b] = make_double2(0.0, 0.0);
-    w[b] = cis_neg2pi((double)(((long long)bin[b] * lane) % fftn) / (double)fftn);
-    st[b] = cis_neg2pi((double)(((long long)bin[b] * 64) % fftn) / (double)fftn);
+    // fftn is a power of two: the modulo is a mask and the division an exact multiplication
+    w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
+    st[b] = cis_neg2pi((double)((bin[b] * 64) & (fftn - 1)) * inv_fftn);
   }
-  for (int i = lane; i < L; i += 64) {
-    const int raw = matlab_round((pos + (double)(-hw + i) / fs) * fs);   // GetBaseIndex, stonemask.cpp:24-28
-    const double xi = xu[imax(0, imin(xl - 1, raw - 1))];           // :67-68
-    const double m = mw[i];
-    double d;                                                       // stonemask.cpp:49-55
-    if (i == 0) d = -mw[1] / 2.0;
-    else if (i == L - 1) d = mw[L - 2] / 2.0;
-    else d = -(mw[i + 1] - mw[i - 1]) / 2.0;
-    const double am = xi * m, ad = xi * d;
+  double carry = 0.0;                                 // mw of the previous trip's last lane
+  for (int i = lane; i < ((L + 63) & ~63); i += 64) {
+    double am = 0.0, ad = 0.0;
+    if (FIRST) {
+      // differential window, stonemask.cpp:49-55; each lane overwrites only its own element and the
+      // left neighbour of lane 0 travels in a register, so two LDS arrays are enough
+      const bool in = i < L;
+      const double m = in ? ad_mw[i] : 0.0;
+      double left = (in && i > 0) ? ad_mw[i - 1] : 0.0;
+      const double right = (i + 1 < L) ? ad_mw[i + 1] : 0.0;
+      if (lane == 0) left = carry;
+      carry = __shfl(m, 63, 64);
+      const double xi = in ? am_xs[i] : 0.0;
+      double d;
+      if (i == 0) d = -right / 2.0;
+      else if (i == L - 1) d = left / 2.0;
+      else d = -(right - left) / 2.0;
+      am = xi * m;
+      ad = in ? xi * d : 0.0;
+      if (in) { am_xs[i] = am; ad_mw[i] = ad; }
+    } else if (i < L) {
+      am = am_xs[i];
+      ad = ad_mw[i];
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       mainv[b].x += am * w[b].x; mainv[b].y += am * w[b].y;
@@ -57,12 +75,14 @@ template <int NB>
 __device__ __forceinline__ double sm_fix(const double (&pw)[NB], const double (&num)[NB], const int (&bin)[NB],
                                          int fftn, int fs) {
   double numer = 0.0, denom = 0.0;
+  const double inv_fftn = 1.0 / fftn;                 // power of two: exact
+  const double fs_over_2pi = fs / 2.0 / kPi;
 #pragma unroll
   for (int h = 0; h < NB; ++h) {
     // bins above fftn/2 are an out-of-bounds read in the reference; they count as zero power here
     const bool ok = bin[h] <= fftn / 2;
     const double p = ok ? pw[h] : 0.0;
-    const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs / fftn + num[h] / p * fs / 2.0 / kPi;
+    const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * inv_fftn + num[h] / p * fs_over_2pi;
     const double amp = sqrt(p);
     numer += amp * inst;
     denom += amp * (h + 1);
@@ -73,10 +93,14 @@ __device__ __forceinline__ double sm_fix(const double (&pw)[NB], const double (&
 __global__ __launch_bounds__(64) void stonemask_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0, int fs,
-    int64_t total_frames, double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) double mw[];
-  const int lane = threadIdx.x;
+    int lmax, int64_t total_frames, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double sm_lds[];
+  double* mw = sm_lds;                      // [lmax + 2] main window, then x * diff window
+  double* xs = sm_lds + lmax + 2;           // [lmax + 2] samples, then x * main window
+  const int lane0 = threadIdx.x;
+  const double inv_fs = 1.0 / fs;
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
     const double f = f0[frame];
     if (f <= kFloorF0StoneMask || f > fs / 12.0) {                 // stonemask.cpp:186-187
       if (lane == 0) out[frame] = 0.0;
@@ -89,14 +113,31 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const int hw = (int)(1.5 * fs / f + 1.0);                      // :189
     const int L = 2 * hw + 1;
     const double wlen = (2.0 * hw + 1.0) / fs;                     // :190
+    const double inv_wlen = 1.0 / wlen;
     // :194-195; a power of two by shift (device pow() is not guaranteed exact for 2^n)
     const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
     __syncthreads();
-    for (int i = lane; i < L; i += 64) {
-      const double bt = (double)(-hw + i) / fs;
-      const int raw = matlab_round((pos + bt) * fs);               // GetBaseIndex :24-28
-      const double tm = (raw - 1.0) / fs - pos;                    // GetMainWindow :33-43
-      mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * tm / wlen) + 0.08 * cos(4.0 * kPi * tm / wlen);
+    // main window (GetMainWindow :33-43) and the samples under it (:67-68), four trips at a time so
+    // that the x loads of a group are in flight together and hide behind the window arithmetic
+    for (int i0 = 0; i0 < L; i0 += 256) {
+      int raw[4];
+      double xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = imin(L - 1, i0 + 64 * q + lane);
+        raw[q] = matlab_round((pos + (double)(-hw + i) * inv_fs) * fs);   // GetBaseIndex :24-28
+        xv[q] = xu[imax(0, imin(xl - 1, raw[q] - 1))];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 64 * q + lane;
+        const double tm = (raw[q] - 1.0) * inv_fs - pos;
+        const double c1 = cospi(2.0 * tm * inv_wlen);               // cos(2 pi tm / wlen)
+        if (i < L) {
+          mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);   // + 0.08 cos(4 pi tm / wlen)
+          xs[i] = xv[q];
+        }
+      }
     }
     __syncthreads();
 
@@ -104,7 +145,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     double pw2[2], num2[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) bin2[h] = matlab_round(f * fftn / fs * (h + 1));   // :102
-    sm_bins<2>(xu, xl, mw, L, pos, hw, fs, bin2, fftn, lane, pw2, num2);
+    sm_bins<2, true>(mw, xs, L, bin2, fftn, lane, pw2, num2);
     const double tent = sm_fix<2>(pw2, num2, bin2, fftn, fs);      // GetTentativeF0 :122-131
     double mean = 0.0;
     if (!(tent <= 0.0 || tent > f * 2)) {
@@ -112,7 +153,8 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
       double pw6[6], num6[6];
 #pragma unroll
       for (int h = 0; h < 6; ++h) bin6[h] = matlab_round(tent * fftn / fs * (h + 1));
-      sm_bins<6>(xu, xl, mw, L, pos, hw, fs, bin6, fftn, lane, pw6, num6);
+      __syncthreads();
+      sm_bins<6, false>(mw, xs, L, bin6, fftn, lane, pw6, num6);
       mean = sm_fix<6>(pw6, num6, bin6, fftn, fs);
     }
     if (fabs(mean - f) / f > 0.2) mean = f;                        // :202
@@ -124,14 +166,19 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   Context& c = *b.ctx;
   const int fs = b.p.fs;
   const int lmax = 2 * (int)(1.5 * fs / kFloorF0StoneMask + 1.0) + 1;
-  const size_t lds = sizeof(double) * (size_t)(lmax + 2);
+  const size_t lds = sizeof(double) * 2 * (size_t)(lmax + 2);
   if (lds > 64 * 1024) return WM_ERR_UNSUPPORTED;
   const int64_t tf = b.total_f;
-  const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
-  if (grid <= 0) return WM_OK;
+  if (tf <= 0) return WM_OK;
+  hipFuncSetAttribute((const void*)stonemask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stonemask_kernel, 64, lds) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  const int64_t resident = (int64_t)c.num_cu * per_cu;
+  const int grid = (int)(tf < resident ? tf : resident);
   TimedScope ts_(b.ctx, "stonemask_kernel");
   hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, fs, tf, d_out);
+                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, d_out);
   return wm_check(hipGetLastError());
 }
 
