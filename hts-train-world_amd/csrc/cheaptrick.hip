@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
   const int nf = (int)(f_off[u + 1] - base);
   const double f0_floor = 3.0 * fs / (fft_size - 3.0);
   if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
+  wave_sync();
   for (int start = 0; start < nf; start += 256) {
     const int i = start + threadIdx.x;
     int c = 0;
@@ -37,18 +37,18 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
       c = 2 * matlab_round(1.5 * fs / cf0) + 1 + fft_size / 2 + 1;
     }
     part[threadIdx.x] = c;
-    __syncthreads();
+    wave_sync();
     for (int o = 1; o < 256; o <<= 1) {
       int tv = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-      __syncthreads();
+      wave_sync();
       part[threadIdx.x] += tv;
-      __syncthreads();
+      wave_sync();
     }
     const int carry = carry_s;
     if (i < nf) rng_off[base + i] = carry + part[threadIdx.x] - c;
-    __syncthreads();
+    wave_sync();
     if (threadIdx.x == 255) carry_s = carry + part[255];
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
       const cpx s = img[k];
       pw[k] = s.x * s.x + s.y * s.y;
     }
-    __syncthreads();
+    wave_sync();
     dc_correction_lds(pw, cf0, fs, F, work, lane);
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
     linear_smoothing_lds(pw, cf0 * 2.0 / 3.0, fs, F, work, pw, lane);
     for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fw.L + i)) * kEps);
-    __syncthreads();
+    wave_sync();
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
 #pragma unroll
@@ -124,13 +124,13 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
       }
     }
     rfft_backward<N>(img, v, img, tw, lane);
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int m = 0; m < M; ++m) img[lane + 64 * m] = v[m];       // x[2n], x[2n+1] -> work[0..F)
-    __syncthreads();
+    wave_sync();
     double* row = sp + frame * (int64_t)(H + 1);
     for (int i = lane; i <= H; i += 64) row[i] = exp(work[i]);
-    __syncthreads();
+    wave_sync();
   }
 }
 

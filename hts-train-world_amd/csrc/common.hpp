@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "wavesync.hpp"
+
 namespace wm {
 
 constexpr double kPi = 3.1415926535897932384;
@@ -126,9 +128,9 @@ __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs,
     const double axis = (double)i * fs * inv_fft;
     scratch[i] = interp1q_lds_r(f0, inv_dx, pw, upper + 1, axis);
   }
-  __syncthreads();
+  wave_sync();
   for (int i = lane; i < nrep; i += 64) pw[i] += scratch[i];
-  __syncthreads();
+  wave_sync();
 }
 
 // LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[0..half] (LDS; may alias in).
@@ -167,7 +169,7 @@ __device__ __forceinline__ void linear_smoothing_lds(const double* in, double wi
       base += lane63(v[q]);
     }
   }
-  __syncthreads();
+  wave_sync();
   const double step = (double)fs * inv_fft;
   const double inv_step = (double)fft_size / fs;
   const double origin = -(b - 0.5) * step;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void linear_smoothing_lds(const double* in, double wi
       if (i <= half) out[i] = (hi[q] - lo[q]) * inv_width;
     }
   }
-  __syncthreads();
+  wave_sync();
 }
 
 }  // namespace wm

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) ap0[frame] = s1 / s2;
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -569,18 +569,18 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         cpx s2 = img[N];
         sc[M] += s2.x * s1[M].x + s1[M].y * s2.y;
       }
-      __syncthreads();
+      wave_sync();
       WM_STAMP(5);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m];
     if (lane == 0) arr[N] = sc[M];
-    __syncthreads();
+    wave_sync();
     dc_correction_lds(arr, cf0, fs, FD, seg, lane);        // d4c.cpp:139
 #pragma unroll
     for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
     sc[M] = arr[N];
-    __syncthreads();
+    wave_sync();
     WM_STAMP(6);
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
@@ -601,11 +601,11 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         cpx s = img[N];
         p[M] = s.x * s.x + s.y * s.y;
       }
-      __syncthreads();
+      wave_sync();
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
       if (lane == 0) arr[N] = p[M];
-      __syncthreads();
+      wave_sync();
       WM_STAMP(8);
     }
     if (!(dbg & 4)) {
@@ -617,17 +617,17 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
     if (lane == 0) arr[N] = sc[M] / arr[N];
-    __syncthreads();
+    wave_sync();
     if (!(dbg & 4)) linear_smoothing_lds(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
     gd[M] = arr[N];
-    __syncthreads();
+    wave_sync();
     if (!(dbg & 4)) linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[N];
-    __syncthreads();
+    wave_sync();
     WM_STAMP(10);
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
       if (lane == 0) arr[N] = gd[M];
-      __syncthreads();
+      wave_sync();
       const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
       cpx v[M];
 #pragma unroll
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
-      __syncthreads();
+      wave_sync();
       WM_STAMP(13);
     }
 
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         if (lane == j + 1 && j < tab.nap) kv = coarse[j];
       smem[lane] = kv;
     }
-    __syncthreads();
+    wave_sync();
     {
       const double bin_hz = (double)fs / out_fft;
       const double last_w = fs / 2.0 - tab.nap * kFreqInterval;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
       }
     }
-    __syncthreads();
+    wave_sync();
     WM_STAMP(14);
   }
 }

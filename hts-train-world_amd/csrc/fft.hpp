@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "wavesync.hpp"
+
 namespace wm {
 
 typedef double2 cpx;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
   static_assert(S1 >= 1 && S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
   static_assert(R1 * R2 * R3 == N, "radix plan");
 
-  __syncthreads();
+  wave_sync();
   // ---- pass 1: radix R1, Ns = 1, no twiddles; store to out[j*R1 + r]
 #pragma unroll
   for (int b = 0; b < S1; ++b) {
@@ -203,10 +205,10 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: bounds the live registers
 #endif
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>(lane + 64 * m)];
-  __syncthreads();
+  wave_sync();
   // ---- pass 2: radix R2, Ns = R1; twiddle W_{R1 R2}^{k r}, k = j % R1 = lane % R1
 #pragma unroll
   for (int b = 0; b < S2; ++b) {
@@ -223,7 +225,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     __builtin_amdgcn_sched_barrier(0);
 #endif
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>(lane + 64 * m)];
   // ---- pass 3: radix R3, Ns = N / R3; twiddle W_N^{j r}; output lands in the register layout
@@ -262,10 +264,10 @@ __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* sp
   constexpr int M = N / 64;
   fft_forward<N>(v, lds, tw, lane);
   asm volatile("" : "+v"(lane));
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) lds[lane + 64 * m] = v[m];     // Z, plain layout
-  __syncthreads();
+  wave_sync();
   cpx xk[M];
   cpx w = tw.wsplit;
 #pragma unroll
@@ -280,14 +282,14 @@ __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* sp
     w = cmul(w, tw.wstep);
   }
   cpx z0 = lds[0];
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) spec[lane + 64 * m] = xk[m];
   if (lane == 0) {
     spec[0] = make_double2(z0.x + z0.y, 0.0);
     spec[N] = make_double2(z0.x - z0.y, 0.0);
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // c2r (unnormalised; fft.cpp:27-35 semantics): X[0..N] in `spec` (LDS, plain).
@@ -300,7 +302,7 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
   const_cast<FftTw<N>&>(tw).fence();
   cpx w = cconj(tw.wsplit);                                  // e^{+j pi k / N}
   const cpx wst = cconj(tw.wstep);
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const double inv_wlen = 1.0 / wlen;
     // :194-195; a power of two by shift (device pow() is not guaranteed exact for 2^n)
     const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
-    __syncthreads();
+    wave_sync();
     // main window (GetMainWindow :33-43) and the samples under it (:67-68), four trips at a time so
     // that the x loads of a group are in flight together and hide behind the window arithmetic
     for (int i0 = 0; i0 < L; i0 += 256) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
         }
       }
     }
-    __syncthreads();
+    wave_sync();
 
     int bin2[2];
     double pw2[2], num2[2];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
       double pw6[6], num6[6];
 #pragma unroll
       for (int h = 0; h < 6; ++h) bin6[h] = matlab_round(tent * fftn / fs * (h + 1));
-      __syncthreads();
+      wave_sync();
       sm_bins<6, false>(mw, xs, L, bin6, fftn, lane, pw6, num6);
       mean = sm_fix<6>(pw6, num6, bin6, fftn, fs);
     }

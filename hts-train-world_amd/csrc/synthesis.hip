@@ -232,7 +232,7 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
     mp[m] = make_double2(amp * cs, amp * sn);
     __builtin_amdgcn_sched_barrier(0);                            // one bin at a time: keeps the VGPR peak low
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // Everything a pulse needs that is not spectral data, gathered by a fully parallel kernel so that
@@ -324,14 +324,14 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
 #pragma unroll
     for (int m = 0; m < M; ++m) xp[m] = 0.0;
     if (periodic) {
-      __syncthreads();
+      wave_sync();
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
         __builtin_amdgcn_sched_barrier(0);
       }
       if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
-      __syncthreads();
+      wave_sync();
       cpx mp[MB];
       minimum_phase<N>(ls, img, tw, lane, mp);
       const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
@@ -354,11 +354,11 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
         dc += v[m].x + v[m].y;
       }
       dc = wave_sum(dc);
-      __syncthreads();
+      wave_sync();
     }
 
     // ---- GetAperiodicResponse (:38-68) ----
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       const int k = m < M ? lane + 64 * m : H;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
       if (m < M || lane == 0) ls[k] = val;
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    wave_sync();
     cpx mp[MB];
     minimum_phase<N>(ls, img, tw, lane, mp);
     // GetNoiseSpectrum (:19-33)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
         out[i0 + 1 - H] = r1;
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
