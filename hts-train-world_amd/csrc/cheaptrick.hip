@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
     int64_t total_frames, double* __restrict__ sp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2;
   constexpr int kImg = 2 * FftLds<N>::kElems;                 // doubles
-  constexpr int kSeg = H + 2 * (F / 3 + 1) + 2;               // worst-case smoothing scratch
+  constexpr int kCh = ((H + 2 * (F / 3 + 1) + 1 + 63) / 64) | 1;   // odd per-lane chunk of the smoothing scan
+  constexpr int kSeg = 64 * kCh;                                // worst-case smoothing scratch
   constexpr int kWork = kImg > kSeg ? kImg : kSeg;
   __shared__ __attribute__((aligned(16))) double smem[(H + 2) + kWork];
   double* pw = smem;                                           // [H+1] power / log spectrum
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
     dc_correction_lds(pw, cf0, fs, F, work, lane);
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
-    linear_smoothing_lds(pw, cf0 * 2.0 / 3.0, fs, F, work, pw, lane);
+    linear_smoothing_lds<kCh>(pw, cf0 * 2.0 / 3.0, fs, F, work, pw, lane);
     for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fw.L + i)) * kEps);
     wave_sync();
 

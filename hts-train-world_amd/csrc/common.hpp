@@ -134,60 +134,64 @@ __device__ __forceinline__ void dc_correction_lds(double* pw, double f0, int fs,
 }
 
 // LinearSmoothing (common.cpp:77-111).  in[0..half] (LDS) -> out[0..half] (LDS; may alias in).
-// seg is an LDS scratch of >= half + 2*b + 1 doubles (b = int(width*fft_size/fs)+1).
-// The cumulative sum of the mirrored spectrum (the reference's is sequential, common.cpp:38-41) is
-// taken row-wise: lane l owns elements l, l+64, ...; each row of 64 is scanned across the wave and
-// the rows are chained through a uniform running total.  Rows and output bins go in groups of 8
-// with all LDS reads of a group in flight together.  Ends with a barrier.
+// seg is an LDS scratch of >= 64 * CH doubles; CH is an ODD compile-time bound on ceil(len / 64),
+// len = half + 2 b + 1, b = int(width * fft_size / fs) + 1.
+//
+// Cumulative sum of the mirrored spectrum (the reference's is sequential, common.cpp:38-41): lane l
+// sums its own CH consecutive elements in registers (an odd lane stride makes these LDS accesses
+// conflict-free), one wave scan stitches the 64 partial sums.
+// Interpolation (interp1Q at x -/+ width/2, common.cpp:99-108): on the uniform grid the query of bin i
+// is knot i + c exactly, with c = b - 0.5 -/+ width / (2 step) the same for every bin, so the knot
+// offset and the fraction are computed once per frame; the reference's per-bin quotient differs from
+// i + c by rounding only, and the interpolant is continuous across knots.
+// Ends with a barrier.
+template <int CH>
 __device__ __forceinline__ void linear_smoothing_lds(const double* in, double width, int fs, int fft_size,
                                                      double* seg, double* out, int lane) {
-  constexpr int G = 8;
+  static_assert(CH % 2 == 1, "odd per-lane chunk keeps the strided LDS accesses conflict-free");
   const int half = fft_size / 2;
   const double inv_fft = 1.0 / fft_size;               // power of two: x * inv_fft == x / fft_size exactly
-  const int b = (int)(width * fft_size / fs) + 1;
+  const double wq = width * fft_size / fs;             // width in bins
+  const int b = (int)wq + 1;
   const int len = half + 2 * b + 1;
-  const int rows = (len + 63) >> 6;
-  double base = 0.0;
-  for (int r0 = 0; r0 < rows; r0 += G) {
-    double v[G];
+  const int beg = lane * CH;
+  double v[CH];
 #pragma unroll
-    for (int q = 0; q < G; ++q) {
-      const int i = (r0 + q) * 64 + lane;
-      int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
-      src = imax(0, imin(half, src));
-      v[q] = in[src];
-    }
-#pragma unroll
-    for (int q = 0; q < G; ++q) {
-      const int i = (r0 + q) * 64 + lane;
-      v[q] = wave_scan_incl(i < len ? v[q] * fs * inv_fft : 0.0);
-    }
-#pragma unroll
-    for (int q = 0; q < G; ++q) {
-      const int i = (r0 + q) * 64 + lane;
-      if (i < len) seg[i] = v[q] + base;
-      base += lane63(v[q]);
-    }
+  for (int q = 0; q < CH; ++q) {
+    const int i = beg + q;
+    int src = i < b ? b - i : (i < half + b ? i - b : half - (i - (half + b)));
+    src = imax(0, imin(half, src));
+    v[q] = in[src];
   }
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const double term = (beg + q < len) ? v[q] * fs * inv_fft : 0.0;
+    v[q] = q == 0 ? term : v[q - 1] + term;
+  }
+  const double carry = wave_scan_incl(v[CH - 1]) - v[CH - 1];
+#pragma unroll
+  for (int q = 0; q < CH; ++q)
+    if (beg + q < len) seg[beg + q] = v[q] + carry;
   wave_sync();
-  const double step = (double)fs * inv_fft;
-  const double inv_step = (double)fft_size / fs;
-  const double origin = -(b - 0.5) * step;
+  const double c_lo = (b - 0.5) - 0.5 * wq, c_hi = c_lo + wq;
+  const int bl = (int)c_lo, bh = (int)c_hi;
+  const double fl = c_lo - bl, fh = c_hi - bh;
   const double inv_width = 1.0 / width;
-  constexpr int GI = 4;
+  constexpr int GI = 8;
   for (int i0 = 0; i0 <= half; i0 += 64 * GI) {
-    double lo[GI], hi[GI];
+    double lo0[GI], lo1[GI], hi0[GI], hi1[GI];
 #pragma unroll
     for (int q = 0; q < GI; ++q) {
       const int i = imin(half, i0 + 64 * q + lane);
-      const double lo_x = (double)i * inv_fft * fs - width / 2.0;
-      lo[q] = interp1q_lds_r(origin, inv_step, seg, len, lo_x);
-      hi[q] = interp1q_lds_r(origin, inv_step, seg, len, lo_x + width);
+      lo0[q] = seg[i + bl]; lo1[q] = seg[i + bl + 1];
+      hi0[q] = seg[i + bh]; hi1[q] = seg[i + bh + 1];
     }
 #pragma unroll
     for (int q = 0; q < GI; ++q) {
       const int i = i0 + 64 * q + lane;
-      if (i <= half) out[i] = (hi[q] - lo[q]) * inv_width;
+      const double lo = lo0[q] + (lo1[q] - lo0[q]) * fl;
+      const double hi = hi0[q] + (hi1[q] - hi0[q]) * fh;
+      if (i <= half) out[i] = (hi - lo) * inv_width;
     }
   }
   wave_sync();

@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
   constexpr int kA = H + 2;
   constexpr int kBMax = FD / 16;
   constexpr int kImg = 2 * FftLds<N>::kElems;
-  constexpr int kTot = kImg > (kA + H + 2 * kBMax + 2) ? kImg : (kA + H + 2 * kBMax + 2);
+  constexpr int kCh = ((H + 2 * kBMax + 1 + 63) / 64) | 1;   // odd per-lane chunk of the smoothing scan
+  constexpr int kTot = kImg > (kA + 64 * kCh) ? kImg : (kA + 64 * kCh);
   __shared__ __attribute__((aligned(16))) double smem[kTot];
   double* arr = smem;                         // [H+1] spectrum-domain array
   double* seg = smem + kA;                    // scan / DC scratch
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     }
     if (!(dbg & 4)) {
     dc_correction_lds(arr, cf0, fs, FD, seg, lane);
-    linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+    linear_smoothing_lds<kCh>(arr, cf0, fs, FD, seg, arr, lane);
     }
     WM_STAMP(9);
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
@@ -618,12 +619,12 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
     if (lane == 0) arr[N] = sc[M] / arr[N];
     wave_sync();
-    if (!(dbg & 4)) linear_smoothing_lds(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
+    if (!(dbg & 4)) linear_smoothing_lds<kCh>(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
     gd[M] = arr[N];
     wave_sync();
-    if (!(dbg & 4)) linear_smoothing_lds(arr, cf0, fs, FD, seg, arr, lane);
+    if (!(dbg & 4)) linear_smoothing_lds<kCh>(arr, cf0, fs, FD, seg, arr, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[N];
