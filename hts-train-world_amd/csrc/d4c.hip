@@ -143,6 +143,29 @@ __device__ unsigned long long g_d4c_stamps[16];
     }                                                                                  \
   } while (0)
 
+// Descending sort of a[0..NS) in registers, NS a power of two: Batcher's odd-even merge sort.  All
+// loop bounds are compile-time, so after unrolling every compare-exchange has static register indices.
+template <int NS>
+__device__ __forceinline__ void sort_desc(double (&a)[NS + 1]) {
+#pragma unroll
+  for (int p = 1; p < NS; p <<= 1) {
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1) {
+#pragma unroll
+      for (int j = k % p; j + k < NS; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          if (i + j + k < NS && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const double hi = fmax(a[i + j], a[i + j + k]), lo = fmin(a[i + j], a[i + j + k]);
+            a[i + j] = hi;
+            a[i + j + k] = lo;
+          }
+        }
+      }
+    }
+  }
+}
+
 struct D4CTables {
   const double* nuttall;    // [window_length] NuttallWindow(window_length) (d4c.cpp:356-359)
   int window_length;
@@ -670,30 +693,38 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         tot += p[M];
       }
       tot = wave_sum(tot);
-      // peel the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220).
-      // Each lane tracks the maximum of its remaining bins; only the winning lane rescans.
-      double cur = p[0];
+      // Sum of all but the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest
+      // (d4c.cpp:215-220).  Each lane sorts its own bins once (Batcher network, static indices) and
+      // parks the sorted column in LDS (the FFT image is free again); the largest bins are then
+      // peeled by repeated wave-wide max over the lanes' current heads, and the winning lane
+      // advances its head with one LDS read.
+      wave_sync();
+      sort_desc<M>(p);
 #pragma unroll
-      for (int m = 1; m < MB; ++m) cur = fmax(cur, p[m]);
+      for (int i = M - 1; i >= 0; --i) {                    // Nyquist bin (lane 0 only, -1 elsewhere) into place
+        const double hi = fmax(p[i], p[i + 1]), lo = fmin(p[i], p[i + 1]);
+        p[i] = hi;
+        p[i + 1] = lo;
+      }
+      double* heads = smem;                                   // [MB + 1][64]
+#pragma unroll
+      for (int m = 0; m < MB; ++m) heads[m * 64 + lane] = p[m];
+      heads[MB * 64 + lane] = -1.0;                           // exhausted
+      int taken = 0;
+      double cur = p[0];
 #pragma unroll 1
       for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
         const double wmx = wave_max(cur);
         const unsigned long long vote = __ballot(cur == wmx);
         const int winner = __ffsll((long long)vote) - 1;
         if (lane == winner) {
-          bool done = false;
-          double nc = -1.0;
-#pragma unroll
-          for (int m = 0; m < MB; ++m) {
-            if (!done && p[m] == wmx) { p[m] = -1.0; done = true; }
-            nc = fmax(nc, p[m]);
-          }
-          cur = nc;
+          ++taken;
+          cur = heads[taken * 64 + lane];
         }
       }
       double low = 0.0;
 #pragma unroll
-      for (int m = 0; m < MB; ++m) low += p[m] >= 0.0 ? p[m] : 0.0;
+      for (int m = 0; m < MB; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;
       low = wave_sum(low);
       double c = 10.0 * log10(low / tot);
       c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
