@@ -121,7 +121,7 @@ def main():
     kernel_ms = {}
     for k in ("dio_lowcut_kernel", "dio_band_kernel", "dio_candidate_kernel", "dio_fix_kernel", "stonemask_kernel",
               "cheaptrick_kernel", "d4c_lovetrain_kernel", "d4c_kernel", "synth_inc_kernel",
-              "synth_timebase_kernel", "synth_pulse_kernel", "synth_ola_kernel"):
+              "synth_timebase_kernel", "synth_search_kernel", "synth_pulse_kernel", "synth_ola_kernel"):
         ms, n = ctx.timing_query(k)
         kernel_ms[k] = (ms, n)
     ctx.timing_enable(False)
@@ -208,7 +208,7 @@ def side_workload(args, torch, dist, W, sd, rank, world):
     else:
         t, f0, sp, ap = batch.analyze(x)
         y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
-        names = ("synth_inc_kernel", "synth_timebase_kernel", "synth_pulse_kernel", "synth_ola_kernel")
+        names = ("synth_inc_kernel", "synth_timebase_kernel", "synth_search_kernel", "synth_pulse_kernel", "synth_ola_kernel")
         step = lambda: batch.synthesize(f0, sp, ap, out=y)
 
     def barrier():

@@ -81,24 +81,19 @@ __global__ __launch_bounds__(256) void synth_inc_kernel(
 // one period), so the accumulated phase has to match the reference bit for bit: lane l adds
 // increments 0..l one after another (adding 0.0 on the lanes that are done is exact), and
 // fmod(total, 2 pi) is evaluated exactly as total - k * (2 pi) with a single FMA.
-__global__ __launch_bounds__(64) void synth_timebase_kernel(
-    const int64_t* __restrict__ y_off, const double* __restrict__ inc_in, int fs, int* __restrict__ pulse_idx,
-    double* __restrict__ pulse_shift, int* __restrict__ pulse_cnt) {
+__global__ __launch_bounds__(64) void synth_timebase_kernel(const int64_t* __restrict__ y_off, double* phase) {
 #pragma clang fp contract(off)
   const int u = blockIdx.x, lane = threadIdx.x;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
-  const double two_pi = 2.0 * kPi;
-  const double inv_two_pi = 1.0 / two_pi;
-  double carry = 0.0, prev_last = 0.0;
-  int count = 0;
+  double carry = 0.0;
   // Increments travel global -> registers -> LDS -> broadcast reads.  A super-chunk of kSuper
   // samples is requested from HBM a whole super-chunk (~5 us) before it is needed, parked in
   // registers, written into one half of an LDS ring, and consumed 16 samples at a time by
   // uniform-address ds_reads that are issued one block ahead of the chain.
   constexpr int kSuper = 1024, kPer = kSuper / 64;
   __shared__ double ring[2 * kSuper];
-  const double* __restrict__ p = inc_in + yb;
+  const double* p = phase + yb;
   double stage[kPer];
   auto request = [&](int s0) {
 #pragma unroll
@@ -152,29 +147,78 @@ __global__ __launch_bounds__(64) void synth_timebase_kernel(
 #pragma unroll
       for (int q = 0; q < 16; ++q) r[q] = n[q];
     }
-    // wrap = fmod(t, 2 pi) (:249, :253): the remainder is exactly representable, so one fused
-    // multiply-add from the unrounded t gives it once k is right
-    double kq = floor(t * inv_two_pi);
-    double wrap = __fma_rn(-kq, two_pi, t);
-    if (wrap < 0.0) { kq -= 1.0; wrap = __fma_rn(-kq, two_pi, t); }
-    if (wrap >= two_pi) { kq += 1.0; wrap = __fma_rn(-kq, two_pi, t); }
-    double prev = __shfl_up(wrap, 1, 64);
-    if (lane == 0) prev = prev_last;
-    // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
-    const bool hit = i >= 1 && i < ylen && fabs(wrap - prev) > kPi;
-    const unsigned long long bal = __ballot(hit);
-    if (hit) {
-      const int dst = count + __popcll(bal & ((1ull << lane) - 1ull));
-      const double y1 = prev - 2.0 * kPi, y2 = wrap;          // :271-274
-      const double xx = -y1 / (y2 - y1);
-      pulse_idx[yb + dst] = i - 1;
-      pulse_shift[yb + dst] = xx / fs;
-    }
-    count += __popcll(bal);
+    // the running phase replaces the increment it came from (the ring read it long ago); wrapping
+    // and the pulse search are per-sample work and live in synth_pulse_search_kernel
+    if (i < ylen) phase[yb + i] = t;
     carry = __shfl(t, 63, 64);
-    prev_last = __shfl(wrap, 63, 64);
   }
-  if (lane == 0) pulse_cnt[u] = count;
+}
+
+// wrap = fmod(total, 2 pi) (synthesis.cpp:249, :253): the remainder is exactly representable, so one
+// fused multiply-add from the unrounded total gives it once k is right
+__device__ __forceinline__ double wrap_two_pi(double t) {
+  const double two_pi = 2.0 * kPi;
+  double kq = floor(t * (1.0 / two_pi));
+  double w = __fma_rn(-kq, two_pi, t);
+  if (w < 0.0) { kq -= 1.0; w = __fma_rn(-kq, two_pi, t); }
+  if (w >= two_pi) { kq += 1.0; w = __fma_rn(-kq, two_pi, t); }
+  return w;
+}
+
+// Part 3 (synthesis.cpp:253-285): pulses where the wrapped phase jumps by more than pi, compacted in
+// order.  One 256-thread workgroup per utterance walks it in tiles with a running count.
+__global__ __launch_bounds__(256) void synth_pulse_search_kernel(
+    const int64_t* __restrict__ y_off, const double* __restrict__ phase, int fs, int* __restrict__ pulse_idx,
+    double* __restrict__ pulse_shift, int* __restrict__ pulse_cnt) {
+#pragma clang fp contract(off)
+  constexpr int kSub = 8;                                   // sub-tiles of 256 samples per trip
+  __shared__ int wave_cnt[kSub][4];
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t yb = y_off[u];
+  const int ylen = (int)(y_off[u + 1] - yb);
+  int count = 0;
+  for (int i0 = 0; i0 < ylen; i0 += 256 * kSub) {
+    // all loads of the trip first: one memory round trip per 2048 samples
+    double tc[kSub], tp[kSub];
+#pragma unroll
+    for (int q = 0; q < kSub; ++q) {
+      const int i = i0 + 256 * q + threadIdx.x;
+      const bool in = i >= 1 && i < ylen;
+      tc[q] = phase[yb + (in ? i : 0)];
+      tp[q] = phase[yb + (in ? i - 1 : 0)];
+    }
+    bool hit[kSub];
+    double wrap[kSub], prev[kSub];
+    unsigned long long bal[kSub];
+#pragma unroll
+    for (int q = 0; q < kSub; ++q) {
+      const int i = i0 + 256 * q + threadIdx.x;
+      wrap[q] = wrap_two_pi(tc[q]);
+      prev[q] = wrap_two_pi(tp[q]);
+      // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
+      hit[q] = i >= 1 && i < ylen && fabs(wrap[q] - prev[q]) > kPi;
+      bal[q] = __ballot(hit[q]);
+      if (lane == 0) wave_cnt[q][wv] = __popcll(bal[q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSub; ++q) {
+      const int i = i0 + 256 * q + threadIdx.x;
+      int base = count;
+      for (int w = 0; w < wv; ++w) base += wave_cnt[q][w];
+      if (hit[q]) {
+        const int dst = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
+        const double y1 = prev[q] - 2.0 * kPi, y2 = wrap[q];  // :271-274
+        const double xx = -y1 / (y2 - y1);
+        pulse_idx[yb + dst] = i - 1;
+        pulse_shift[yb + dst] = xx / fs;
+      }
+      count += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pulse_cnt[u] = count;
 }
 
 __global__ void synth_dc_remover_kernel(int fft_size, double* __restrict__ dcr) {   // GetDCRemover :322-334
@@ -495,7 +539,11 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
                          fp, lowest_f0, b.d_vuv, b.d_phase);
     }
     TimedScope ts_(b.ctx, "synth_timebase_kernel");
-    hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, b.d_y_off, b.d_phase, fs,
+    hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, b.d_y_off, b.d_phase);
+  }
+  {
+    TimedScope ts_(b.ctx, "synth_search_kernel");
+    hipLaunchKernelGGL(synth_pulse_search_kernel, dim3(b.n_utt), dim3(256), 0, st, b.d_y_off, b.d_phase, fs,
                        b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
   }
   rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
