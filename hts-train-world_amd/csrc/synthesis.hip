@@ -379,10 +379,21 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
       cpx mp[MB];
       minimum_phase<N>(ls, img, tw, lane, mp);
       const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
+      // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
+      // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
+      double rc, rs, dc64, ds64;
+      sincos(coef * lane, &rs, &rc);
+      sincos(coef * 64.0, &ds64, &dc64);
+      const double reH = cos(coef * H);
 #pragma unroll
       for (int m = 0; m < MB; ++m) {                                // :88-100
         const int k = m < M ? lane + 64 * m : H;
-        const double re2 = cos(coef * k);
+        const double re2 = m < M ? rc : reH;
+        {
+          const double nc = rc * dc64 - rs * ds64;
+          rs = rs * dc64 + rc * ds64;
+          rc = nc;
+        }
         const double im2 = sqrt(1.0 - re2 * re2);
         const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
         if (m < M || lane == 0) img[k] = s;
