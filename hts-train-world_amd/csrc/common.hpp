@@ -72,6 +72,41 @@ __device__ __forceinline__ double wave_scan_incl(double v, int /*lane*/ = 0) {
   return v;
 }
 __device__ __forceinline__ double wave_sum(double v) { return lane63(wave_scan_incl(v)); }
+// Four wave-wide sums at once (gfx950 v_permlane32_swap / v_permlane16_swap): swapping halves of
+// two registers and adding reduces BOTH by one level with a single add, so the four values cost two
+// levels of swaps (9 instructions), four row-rotate steps on one register and four broadcasts --
+// about a third of four separate scans.  The summation tree differs from wave_sum()'s.
+__device__ __forceinline__ double permswap_add32(double a, double b) {
+  // vdst' = [a(0:31), b(0:31)], src' = [a(32:63), b(32:63)]
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double permswap_add16(double a, double b) {
+  // vdst' = rows [a0, b0, a2, b2], src' = rows [a1, b1, a3, b3]
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, double& d) {
+  const double ab = permswap_add32(a, b);        // lanes 0-31: partials of a, 32-63: of b
+  const double cd = permswap_add32(c, d);
+  double r = permswap_add16(ab, cd);             // rows: a, c, b, d (16 partials each)
+  r += dpp_get<0x128, 0xf, 0xf>(r);              // row_ror:8
+  r += dpp_get<0x124, 0xf, 0xf>(r);              // row_ror:4
+  r += dpp_get<0x122, 0xf, 0xf>(r);              // row_ror:2
+  r += dpp_get<0x121, 0xf, 0xf>(r);              // row_ror:1
+  a = readlane_d(r, 0);
+  c = readlane_d(r, 16);
+  b = readlane_d(r, 32);
+  d = readlane_d(r, 48);
+}
+
 // maximum of NON-NEGATIVE values (lanes without a DPP source contribute 0)
 __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_get<0x111, 0xf, 0xf>(v));

@@ -215,34 +215,47 @@ __device__ __forceinline__ void hv_dft_bins(const double* __restrict__ ys, int y
                                             int basic, const int (&bin)[NB], int nh, int fftn, int lane,
                                             double (&pw)[NB], double (&num)[NB]) {
   cpx mainv[NB], diffv[NB], w[NB], st[NB];
+  const double inv_fftn = 1.0 / fftn;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     mainv[b] = make_double2(0.0, 0.0);
     diffv[b] = make_double2(0.0, 0.0);
-    w[b] = cis_neg2pi((double)(((long long)bin[b] * lane) % fftn) / (double)fftn);
-    st[b] = cis_neg2pi((double)(((long long)bin[b] * 64) % fftn) / (double)fftn);
+    // fftn is a power of two: the modulo is a mask and the division an exact multiplication
+    w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
+    st[b] = cis_neg2pi((double)((bin[b] * 64) & (fftn - 1)) * inv_fftn);
   }
-  for (int i = lane; i < L; i += 64) {
-    const double xi = ys[imax(0, imin(ylen - 1, basic + i - 1))];   // :481-484
-    const double mm = mw[i];
-    double d;                                                       // :462-468
-    if (i == 0) d = -mw[1] / 2.0;
-    else if (i == L - 1) d = mw[L - 2] / 2.0;
-    else d = -(mw[i + 1] - mw[i - 1]) / 2.0;
-    const double am = xi * mm, ad = xi * d;
+  // four trips at a time: the samples of a group are requested together (one memory round trip)
+  for (int i0 = 0; i0 < L; i0 += 256) {
+    double xv[4];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < nh) {
-        mainv[b].x += am * w[b].x; mainv[b].y += am * w[b].y;
-        diffv[b].x += ad * w[b].x; diffv[b].y += ad * w[b].y;
-        w[b] = cmul(w[b], st[b]);
+    for (int q = 0; q < 4; ++q) xv[q] = ys[imax(0, imin(ylen - 1, basic + imin(L - 1, i0 + 64 * q + lane) - 1))];   // :481-484
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + 64 * q + lane;
+      if (i0 + 64 * q < L) {                                          // uniform
+        const bool in = i < L;
+        const int ic = in ? i : L - 1;
+        const double mm = mw[ic];
+        double d;                                                     // :462-468
+        if (ic == 0) d = -mw[1] / 2.0;
+        else if (ic == L - 1) d = mw[L - 2] / 2.0;
+        else d = -(mw[ic + 1] - mw[ic - 1]) / 2.0;
+        const double am = in ? xv[q] * mm : 0.0, ad = in ? xv[q] * d : 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b < nh) {
+            mainv[b].x += am * w[b].x; mainv[b].y += am * w[b].y;
+            diffv[b].x += ad * w[b].x; diffv[b].y += ad * w[b].y;
+            w[b] = cmul(w[b], st[b]);
+          }
+        }
       }
     }
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const double mr = wave_sum(mainv[b].x), mi = wave_sum(mainv[b].y);
-    const double dr = wave_sum(diffv[b].x), di = wave_sum(diffv[b].y);
+    double mr = mainv[b].x, mi = mainv[b].y, dr = diffv[b].x, di = diffv[b].y;
+    wave_sum4(mr, mi, dr, di);
     num[b] = mr * di - mi * dr;                                     // :565-566
     pw[b] = mr * mr + mi * mi;                                      // :567-568
   }
@@ -268,13 +281,29 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
     const int ylen = ylen_a[u];
     const double pos = k * 1 / 1000.0;
     const double fs = m.afs;
-    for (int s = 0; s < nc1 * kHvOverlap; ++s) {
-      const int blk = s / nc1, j = s - blk * nc1;
-      const int src = blk == 0 ? k : (blk <= 3 ? k - blk : k + (blk - 3));
-      double f0 = 0.0;
-      if (src >= 0 && src < nb1) f0 = offc[(boff[u] + src) * m.cpf + j];
+    // the candidates of all slots are fetched side by side (lane = slot); empty slots are answered at
+    // once and only the occupied ones are walked
+    const int ns = nc1 * kHvOverlap;
+    for (int s0 = 0; s0 < ns; s0 += 64) {
+      const int sl_ = s0 + lane;
+      double f0s = 0.0;
+      if (sl_ < ns) {
+        const int blk = sl_ / nc1, j = sl_ - blk * nc1;
+        const int src = blk == 0 ? k : (blk <= 3 ? k - blk : k + (blk - 3));
+        if (src >= 0 && src < nb1) f0s = offc[(boff[u] + src) * m.cpf + j];
+        if (!(f0s > 0.0)) {
+          rc[fr * m.maxc + sl_] = 0.0;
+          rs[fr * m.maxc + sl_] = 0.0;
+        }
+      }
+      unsigned long long todo = __ballot(f0s > 0.0);
+      while (todo) {
+      const int pick = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int s = s0 + pick;
+      const double f0 = __shfl(f0s, pick, 64);
       double rf0 = 0.0, rscore = 0.0;
-      if (f0 > 0.0) {                                              // GetRefinedF0 :589-617
+      {                                                            // GetRefinedF0 :589-617
         const int hw = (int)(1.5 * fs / f0 + 1.0);
         const int L = 2 * hw + 1;
         const double wlen = (2.0 * hw + 1.0) / fs;
@@ -282,9 +311,11 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
         const double bt0 = (-hw + 0) / fs;
         const int basic = matlab_round((pos + bt0) * fs + 0.001);  // GetBaseIndex :434-441
         __syncthreads();
+        const double inv_fs = 1.0 / fs, inv_wlen = 1.0 / wlen;
         for (int i = lane; i < L; i += 64) {                       // GetMainWindow :446-456
-          const double tm = ((basic + i) - 1.0) / fs - pos;
-          mw[i] = 0.42 + 0.5 * cos(2.0 * kPi * tm / wlen) + 0.08 * cos(4.0 * kPi * tm / wlen);
+          const double tm = ((basic + i) - 1.0) * inv_fs - pos;
+          const double c1 = cospi(2.0 * tm * inv_wlen);             // cos(2 pi tm / wlen); cos(4 pi ..) = 2 c^2 - 1
+          mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
         }
         __syncthreads();
         const int nh = imin((int)(fs / 2.0 / f0), 6);              // :571-572
@@ -298,7 +329,7 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
         for (int h = 0; h < 6; ++h) {
           if (h < nh) {
             const double p = bin[h] <= fftn / 2 ? pw[h] : 0.0;
-            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs / fftn + num[h] / p * fs / 2.0 / kPi;
+            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * (1.0 / fftn) + num[h] / p * fs / 2.0 / kPi;
             const double amp = sqrt(p);
             numer += amp * inst;
             denom += amp * (h + 1.0);
@@ -312,6 +343,7 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
       if (lane == 0) {
         rc[fr * m.maxc + s] = rf0;
         rs[fr * m.maxc + s] = rscore;
+      }
       }
     }
   }

@@ -63,8 +63,8 @@ __device__ __forceinline__ void sm_bins(double* ad_mw, double* am_xs, int L, con
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const double mr = wave_sum(mainv[b].x), mi = wave_sum(mainv[b].y);
-    const double dr = wave_sum(diffv[b].x), di = wave_sum(diffv[b].y);
+    double mr = mainv[b].x, mi = mainv[b].y, dr = diffv[b].x, di = diffv[b].y;
+    wave_sum4(mr, mi, dr, di);
     num[b] = mr * di - mi * dr;                                     // stonemask.cpp:159-160
     pw[b] = mr * mr + mi * mi;                                      // :161-162
   }
