@@ -459,6 +459,134 @@ __device__ __forceinline__ double hv_search_score(double f0, const double* c, co
   return score;
 }
 
+// ---- workgroup-wide (256 threads, uniform control flow) forms of the contour helpers --------------
+// Boundaries of a 0/1 sequence (GetBoundaryList, harvest.cpp:727-743): transitions of
+// v(i) = (i == n-1) ? 0 : voiced(i), i in [1, n), against v(i-1) (0 before the first), written in
+// order as list[p] = i - (p & 1).  Ordered compaction by ballots; returns the count to every thread.
+template <class F>
+__device__ __forceinline__ int hv_boundaries_wg(F voiced, int n, int* __restrict__ list, int* sh4) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int cnt = 0;
+  for (int i0 = 1; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    bool flag = false;
+    if (i < n) {
+      const int v = (i == n - 1) ? 0 : (voiced(i) ? 1 : 0);
+      const int p = (i - 1 >= 1) ? (voiced(i - 1) ? 1 : 0) : 0;
+      flag = v != p;
+    }
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0) sh4[wv] = __popcll(bal);
+    __syncthreads();
+    int base = cnt;
+    for (int q = 0; q < wv; ++q) base += sh4[q];
+    if (flag) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      list[pos] = i - (pos & 1);
+    }
+    cnt += sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    __syncthreads();
+  }
+  return cnt;
+}
+
+// SelectBestF0 (harvest.cpp:783-797) with the candidates of the row spread over the lanes of a wave.
+// The sequential rule "skip if e > best_e, else take" keeps the LAST candidate among those of minimal
+// error (<= allowed).  cv[q] is this lane's candidate lane + 64 q (nc <= 64 * kSelPer).
+constexpr int kSelPer = 3;
+__device__ __forceinline__ double hv_select_wave(double ref, const double (&cv)[kSelPer], int nc, double allowed,
+                                                 int lane) {
+  double be = HUGE_VAL;
+  int bi = -1;
+#pragma unroll
+  for (int q = 0; q < kSelPer; ++q) {
+    if (lane + 64 * q < nc) {
+      const double e = fabs(ref - cv[q]) / ref;
+      if (!(e > allowed) && !(e > be)) { be = e; bi = lane + 64 * q; }
+    }
+  }
+  double mn = be;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) mn = fmin(mn, __shfl_xor(mn, sh, 64));
+  int pick = (bi >= 0 && be == mn) ? bi : -1;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) pick = max(pick, __shfl_xor(pick, sh, 64));
+  if (pick < 0) return 0.0;
+  double out = 0.0;
+#pragma unroll
+  for (int q = 0; q < kSelPer; ++q) {
+    const double a = __shfl(cv[q], pick & 63, 64);
+    if ((pick >> 6) == q) out = a;
+  }
+  return out;
+}
+
+// ExtendF0 (harvest.cpp:791-820) on one wavefront: uniform control flow, candidates over lanes, the
+// row of the next step requested while the current one is evaluated.
+__device__ __forceinline__ int hv_extend_f0_wave(int origin, int last_point, int shift, const HvCand& cd,
+                                                 double allowed, double* md, const HvSec& sec, int lane) {
+  double tmp_f0 = hv_get(md, sec, origin);
+  int shifted_origin = origin;
+  const int distance = last_point > origin ? last_point - origin : origin - last_point;
+  int count = 0;
+  int li[kSelPer];
+#pragma unroll
+  for (int q = 0; q < kSelPer; ++q) li[q] = lane + 64 * q < cd.nc ? lane + 64 * q : 0;
+  const double* row = cd.c + (int64_t)(origin + shift) * cd.stride;
+  double nx[kSelPer];
+#pragma unroll
+  for (int q = 0; q < kSelPer; ++q) nx[q] = row[li[q]];
+  for (int i = 0; i <= distance; ++i) {
+    const int idx = origin + shift * i;
+    double cur[kSelPer];
+#pragma unroll
+    for (int q = 0; q < kSelPer; ++q) cur[q] = nx[q];
+    if (i < distance) {                                  // next step's row
+      const double* nrow = cd.c + (int64_t)(idx + 2 * shift) * cd.stride;
+#pragma unroll
+      for (int q = 0; q < kSelPer; ++q) nx[q] = nrow[li[q]];
+    }
+    const double v = hv_select_wave(tmp_f0, cur, cd.nc, allowed, lane);
+    if (lane == 0) hv_set(md, sec, idx + shift, v);
+    if (v == 0.0) {
+      count++;
+    } else {
+      tmp_f0 = v;
+      count = 0;
+      shifted_origin = idx + shift;
+    }
+    if (count == 4) break;
+  }
+  return shifted_origin;
+}
+
+// SearchScore (harvest.cpp:901-907) for one frame, one thread
+__device__ __forceinline__ double hv_search_score_row(double f0, const double* __restrict__ c,
+                                                      const double* __restrict__ sc, int n) {
+  double score = 0.0;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    double cv[8], sv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = imin(n - 1, i0 + r); cv[r] = c[i]; sv[r] = sc[i]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (i0 + r < n && f0 == cv[r] && score < sv[r]) score = sv[r];
+  }
+  return score;
+}
+
+// x += v[0] + v[1] + ... + v[n-1] in exactly that order, the values read 64 at a time by the lanes of
+// a wavefront (uniform result; adding 0.0 for the lanes beyond n is exact)
+template <class F>
+__device__ __forceinline__ double hv_seq_sum_wave(double x, F value, int n, int lane) {
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const double v = (j0 + lane < n) ? value(j0 + lane) : 0.0;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) x += __shfl(v, r, 64);
+  }
+  return x;
+}
+
 constexpr int kSmLag = 300;      // SmoothF0Contour lag (harvest.cpp:1085)
 constexpr int kSmPar = 32;       // sections filtered concurrently
 
@@ -510,115 +638,149 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
   }
   __syncthreads();
 
-  if (threadIdx.x == 0) {
-    // FixStep2 (:748-762, minimum 6): c2 -> c1
-    for (int i = 0; i < nf; ++i) c1[i] = c2[i];
-    int nb = hv_boundaries(c2, nf, bl);
-    for (int i = 0; i < nb / 2; ++i) {
-      if (bl[i * 2 + 1] - bl[i * 2] >= 6) continue;
-      for (int j = bl[i * 2]; j <= bl[i * 2 + 1]; ++j) c1[j] = 0.0;
-    }
-    // FixStep3 (:968-995, allowed 0.18): c1 -> c2
-    for (int i = 0; i < nf; ++i) c2[i] = c1[i];
-    nb = hv_boundaries(c1, nf, bl);
-    const int nsec = nb / 2;
+  // ---- from here on all 256 threads run with uniform control flow; bulk loops are thread-parallel,
+  // decisions are recomputed by every thread from values in memory, single writers are thread 0 ----
+  __shared__ int sh4[4];
+  __shared__ int sh_key[2048], sh_ord[2048];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  // FixStep2 (:748-762, minimum 6): c2 -> c1
+  for (int i = tid; i < nf; i += 256) c1[i] = c2[i];
+  int nb = hv_boundaries_wg([&](int i) { return c2[i] > 0; }, nf, bl, sh4);
+  for (int i = tid; i < nb / 2; i += 256) {
+    const int lo = bl[i * 2], hi = bl[i * 2 + 1];
+    if (hi - lo >= 6) continue;
+    for (int j = lo; j <= hi; ++j) c1[j] = 0.0;
+  }
+  __syncthreads();
+  // FixStep3 (:968-995, allowed 0.18): c1 -> c2
+  for (int i = tid; i < nf; i += 256) c2[i] = c1[i];
+  nb = hv_boundaries_wg([&](int i) { return c1[i] > 0; }, nf, bl, sh4);
+  const int nsec = nb / 2;
+  if (tid == 0) {                                                  // GetMultiChannelF0 :767-778 (banded rows)
     int64_t used = 0;
-    for (int i = 0; i < nsec; ++i) {                               // GetMultiChannelF0 :767-778 (banded)
-      HvSec sc;
-      sc.lo = imax(0, bl[i * 2] - 102);
-      sc.hi = imin(nf - 1, bl[i * 2 + 1] + 102);
-      sc.off = used;
-      used += sc.hi - sc.lo + 1;
-      s_lo[i] = sc.lo; s_hi[i] = sc.hi; s_of[i] = (int)sc.off;
-      for (int j = sc.lo; j <= sc.hi; ++j) md[sc.off + (j - sc.lo)] = (j >= bl[i * 2] && j <= bl[i * 2 + 1]) ? c1[j] : 0.0;
+    for (int i = 0; i < nsec; ++i) {
+      const int lo = imax(0, bl[i * 2] - 102), hi = imin(nf - 1, bl[i * 2 + 1] + 102);
+      s_lo[i] = lo; s_hi[i] = hi; s_of[i] = (int)used;
+      used += hi - lo + 1;
     }
-    for (int i = 0; i < nsec; ++i) {                               // Extend :861-878 (in place)
+  }
+  __syncthreads();
+  for (int i = 0; i < nsec; ++i) {
+    const int lo = s_lo[i], hi = s_hi[i], of = s_of[i], v0 = bl[i * 2], v1 = bl[i * 2 + 1];
+    for (int j = lo + tid; j <= hi; j += 256) md[of + (j - lo)] = (j >= v0 && j <= v1) ? c1[j] : 0.0;
+  }
+  __syncthreads();
+  // Extend :861-878 (in place): a section only touches its own row, so sections go to the four waves
+  for (int i = wv; i < nsec; i += 4) {
+    HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
+    const int o1 = bl[i * 2 + 1], o0 = bl[i * 2];
+    const int e1 = hv_extend_f0_wave(o1, imin(nf - 2, o1 + 100), 1, cd, 0.18, md, sc, lane);
+    const int e0 = hv_extend_f0_wave(o0, imax(1, o0 - 100), -1, cd, 0.18, md, sc, lane);
+    if (lane == 0) { bl[i * 2 + 1] = e1; bl[i * 2] = e0; }
+  }
+  __syncthreads();
+  // ExtendSub :840-856: the running mean is NOT reset between sections (quirk), so the sections are
+  // walked in order on wave 0 and every sum keeps the reference's sequential association
+  if (wv == 0) {
+    int nchn = 0;
+    double mean_f0 = 0.0;
+    for (int i = 0; i < nsec; ++i) {
       HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
-      bl[i * 2 + 1] = hv_extend_f0(bl[i * 2 + 1], imin(nf - 2, bl[i * 2 + 1] + 100), 1, cd, 0.18, md, sc);
-      bl[i * 2] = hv_extend_f0(bl[i * 2], imax(1, bl[i * 2] - 100), -1, cd, 0.18, md, sc);
-    }
-    int nchn = 0;                                                  // ExtendSub :840-856
-    {
-      double mean_f0 = 0.0;                                        // not reset between sections (quirk)
-      for (int i = 0; i < nsec; ++i) {
-        HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
-        const int st = bl[i * 2], ed = bl[i * 2 + 1];
-        for (int j = st; j < ed; ++j) mean_f0 += hv_get(md, sc, j);
-        mean_f0 /= ed - st;
-        if (2200.0 / mean_f0 < ed - st) {                          // Swap :826-838
+      const int st = bl[i * 2], ed = bl[i * 2 + 1];
+      mean_f0 = hv_seq_sum_wave(mean_f0, [&](int q) { return hv_get(md, sc, st + q); }, ed - st, lane);
+      mean_f0 /= ed - st;
+      if (2200.0 / mean_f0 < ed - st) {                            // Swap :826-838
+        if (lane == 0 && nchn != i) {
           int tv;
           tv = s_lo[nchn]; s_lo[nchn] = s_lo[i]; s_lo[i] = tv;
           tv = s_hi[nchn]; s_hi[nchn] = s_hi[i]; s_hi[i] = tv;
           tv = s_of[nchn]; s_of[nchn] = s_of[i]; s_of[i] = tv;
           tv = bl[nchn * 2]; bl[nchn * 2] = bl[i * 2]; bl[i * 2] = tv;
           tv = bl[nchn * 2 + 1]; bl[nchn * 2 + 1] = bl[i * 2 + 1]; bl[i * 2 + 1] = tv;
-          nchn++;
         }
+        nchn++;
       }
     }
-    if (nchn != 0) {                                               // MergeF0 :937-963
-      int* order = bl2;                                            // scratch: nchn ints
-      for (int i = 0; i < nchn; ++i) order[i] = i;                 // MakeSortedOrder :883-896
+    if (lane == 0) sh_n = nchn;
+  }
+  __syncthreads();
+  const int nchn = sh_n;
+  __syncthreads();
+  if (nchn != 0) {                                                 // MergeF0 :937-963
+    const bool in_lds = nchn <= 2048;
+    int* order = in_lds ? sh_ord : bl2;                            // MakeSortedOrder :883-896
+    if (in_lds) {
+      for (int i = tid; i < nchn; i += 256) sh_key[i] = bl[i * 2];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      for (int i = 0; i < nchn; ++i) order[i] = i;
       for (int i = 1; i < nchn; ++i)
         for (int j = i - 1; j >= 0; --j) {
-          if (bl[order[j] * 2] > bl[order[i] * 2]) { const int tv = order[i]; order[i] = order[j]; order[j] = tv; }
+          const int kj = in_lds ? sh_key[order[j]] : bl[order[j] * 2];
+          const int ki = in_lds ? sh_key[order[i]] : bl[order[i] * 2];
+          if (kj > ki) { const int tv = order[i]; order[i] = order[j]; order[j] = tv; }
           else break;
         }
-      {
-        HvSec s0; s0.lo = s_lo[0]; s0.hi = s_hi[0]; s0.off = s_of[0];
-        for (int i = 0; i < nf; ++i) c2[i] = hv_get(md, s0, i);
-      }
-      for (int i = 1; i < nchn; ++i) {
-        const int o = order[i];
-        HvSec so; so.lo = s_lo[o]; so.hi = s_hi[o]; so.off = s_of[o];
-        if (bl[o * 2] - bl[1] > 0) {
-          for (int j = bl[o * 2]; j <= bl[o * 2 + 1]; ++j) c2[j] = hv_get(md, so, j);
-          bl[0] = bl[o * 2];
-          bl[1] = bl[o * 2 + 1];
-        } else {                                                   // MergeF0Sub :912-932
-          const int st1 = bl[0], ed1 = bl[1], st2 = bl[o * 2], ed2 = bl[o * 2 + 1];
-          if (st1 <= st2 && ed1 >= ed2) {
-            bl[1] = ed1;
-          } else {
-            double sc1 = 0.0, sc2 = 0.0;
-            for (int k = st2; k <= ed1; ++k) {
-              const double* cr = cd.c + (int64_t)k * cd.stride;
-              const double* sr = cd.s + (int64_t)k * cd.stride;
-              sc1 += hv_search_score(c2[k], cr, sr, nc);
-              sc2 += hv_search_score(hv_get(md, so, k), cr, sr, nc);
-            }
-            if (sc1 > sc2) for (int k = ed1; k <= ed2; ++k) c2[k] = hv_get(md, so, k);
-            else for (int k = st2; k <= ed2; ++k) c2[k] = hv_get(md, so, k);
-            bl[1] = ed2;
+    }
+    __syncthreads();
+    {
+      HvSec s0; s0.lo = s_lo[0]; s0.hi = s_hi[0]; s0.off = s_of[0];
+      for (int i = tid; i < nf; i += 256) c2[i] = hv_get(md, s0, i);
+    }
+    // boundary_list[0], [1] of the reference double as the running start / end of the merged contour
+    int run_st = bl[0], run_ed = bl[1];
+    __syncthreads();
+    for (int i = 1; i < nchn; ++i) {
+      const int o = order[i];
+      HvSec so; so.lo = s_lo[o]; so.hi = s_hi[o]; so.off = s_of[o];
+      const int st2 = o == 0 ? run_st : bl[o * 2], ed2 = o == 0 ? run_ed : bl[o * 2 + 1];
+      if (st2 - run_ed > 0) {
+        for (int j = st2 + tid; j <= ed2; j += 256) c2[j] = hv_get(md, so, j);
+        run_st = st2;
+        run_ed = ed2;
+      } else {                                                     // MergeF0Sub :912-932
+        const int st1 = run_st, ed1 = run_ed;
+        if (!(st1 <= st2 && ed1 >= ed2)) {
+          // per-frame scores in parallel (c1 / best are free here), then the two sums in frame order
+          for (int k = st2 + tid; k <= ed1; k += 256) {
+            const double* cr = cd.c + (int64_t)k * cd.stride;
+            const double* sr = cd.s + (int64_t)k * cd.stride;
+            c1[k] = hv_search_score_row(c2[k], cr, sr, nc);
+            best[k] = hv_search_score_row(hv_get(md, so, k), cr, sr, nc);
           }
+          __syncthreads();
+          const double sc1 = hv_seq_sum_wave(0.0, [&](int q) { return c1[st2 + q]; }, ed1 - st2 + 1, lane);
+          const double sc2 = hv_seq_sum_wave(0.0, [&](int q) { return best[st2 + q]; }, ed1 - st2 + 1, lane);
+          __syncthreads();
+          if (sc1 > sc2) { for (int k = ed1 + tid; k <= ed2; k += 256) c2[k] = hv_get(md, so, k); }
+          else { for (int k = st2 + tid; k <= ed2; k += 256) c2[k] = hv_get(md, so, k); }
+          run_ed = ed2;
         }
       }
+      __syncthreads();
     }
-    // FixStep4 (:1000-1022, threshold 9): c2 -> best
-    for (int i = 0; i < nf; ++i) best[i] = c2[i];
-    nb = hv_boundaries(c2, nf, bl);
-    for (int i = 0; i < nb / 2 - 1; ++i) {
-      const int distance = bl[(i + 1) * 2] - bl[i * 2 + 1] - 1;
-      if (distance >= 9) continue;
-      const double tmp0 = c2[bl[i * 2 + 1]] + 1, tmp1 = c2[bl[(i + 1) * 2]] - 1;
-      const double coef = (tmp1 - tmp0) / (distance + 1.0);
-      int count = 1;
-      for (int j = bl[i * 2 + 1] + 1; j <= bl[(i + 1) * 2] - 1; ++j) best[j] = tmp0 + coef * count++;
-    }
-    // SmoothF0Contour (:1079-1113): boundaries of the zero-padded contour.  The padded array is
-    // `best` shifted by lag, so boundaries are those of best (with its first/last frame forced
-    // unvoiced only by the padding, i.e. not forced) shifted by lag.
-    {
-      int cnt = 0, prev = 0;
-      const int nn = nf + 2 * kSmLag;
-      for (int i = 1; i < nn; ++i) {
-        const int j = i - kSmLag;
-        const int v = (i == nn - 1) ? 0 : ((j >= 0 && j < nf && best[j] > 0) ? 1 : 0);
-        if (v - prev != 0) { bl[cnt] = i - cnt % 2; cnt++; }
-        prev = v;
-      }
-      sh_n = cnt / 2;
-    }
+  }
+  // FixStep4 (:1000-1022, threshold 9): c2 -> best
+  for (int i = tid; i < nf; i += 256) best[i] = c2[i];
+  nb = hv_boundaries_wg([&](int i) { return c2[i] > 0; }, nf, bl, sh4);
+  for (int i = tid; i < nb / 2 - 1; i += 256) {
+    const int e0 = bl[i * 2 + 1], s1 = bl[(i + 1) * 2];
+    const int distance = s1 - e0 - 1;
+    if (distance >= 9) continue;
+    const double tmp0 = c2[e0] + 1, tmp1 = c2[s1] - 1;
+    const double coef = (tmp1 - tmp0) / (distance + 1.0);
+    int count = 1;
+    for (int j = e0 + 1; j <= s1 - 1; ++j) best[j] = tmp0 + coef * count++;
+  }
+  __syncthreads();
+  // SmoothF0Contour (:1079-1113): boundaries of the zero-padded contour (best shifted by the lag)
+  {
+    const int nn = nf + 2 * kSmLag;
+    const int cnt = hv_boundaries_wg([&](int i) { const int j = i - kSmLag; return j >= 0 && j < nf && best[j] > 0; },
+                                     nn, bl, sh4);
+    if (tid == 0) sh_n = cnt / 2;
   }
   __syncthreads();
   // FilteringF0 (:1049-1074) per section, kSmPar sections at a time, one thread each
@@ -635,20 +797,47 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
         const int st = bl[sidx * 2], ed = bl[sidx * 2 + 1];          // padded coordinates
         double* tmp = sm + (int64_t)threadIdx.x * nn;
         const double xs = best[st - kSmLag], xe = best[ed - kSmLag];
+        // Both passes are strictly sequential recurrences; what can be taken off the chain is the
+        // memory traffic: inputs are fetched 16 steps at a time (independent loads, one round trip per
+        // block instead of one per step) and results are stored without waiting.
+        constexpr int kBlk = 16;
         double w0 = 0.0, w1 = 0.0;
-        for (int i = 0; i < nn; ++i) {
-          const double xi = i < st ? xs : (i > ed ? xe : best[i - kSmLag]);
-          const double wt = xi + fa0 * w0 + fa1 * w1;
-          tmp[nn - i - 1] = fb0 * wt + fb1 * w0 + fb0 * w1;
-          w1 = w0; w0 = wt;
+        for (int i0 = 0; i0 < nn; i0 += kBlk) {
+          double xin[kBlk];
+#pragma unroll
+          for (int r = 0; r < kBlk; ++r) {
+            const int i = i0 + r;
+            const int jc = imin(nf - 1, imax(0, imin(ed, imax(st, i)) - kSmLag));
+            xin[r] = best[jc];
+          }
+#pragma unroll
+          for (int r = 0; r < kBlk; ++r) {
+            const int i = i0 + r;
+            if (i < nn) {
+              const double xi = i < st ? xs : (i > ed ? xe : xin[r]);
+              const double wt = xi + fa0 * w0 + fa1 * w1;
+              tmp[nn - i - 1] = fb0 * wt + fb1 * w0 + fb0 * w1;
+              w1 = w0; w0 = wt;
+            }
+          }
         }
+        __threadfence_block();                                    // the second pass reads what the first wrote
         w0 = w1 = 0.0;
-        for (int i = 0; i < nn; ++i) {
-          const double wt = tmp[i] + fa0 * w0 + fa1 * w1;
-          const double o = fb0 * wt + fb1 * w0 + fb0 * w1;
-          w1 = w0; w0 = wt;
-          const int j = nn - i - 1;
-          if (j >= st && j <= ed) smooth[j - kSmLag] = o;
+        for (int i0 = 0; i0 < nn; i0 += kBlk) {
+          double tin[kBlk];
+#pragma unroll
+          for (int r = 0; r < kBlk; ++r) tin[r] = tmp[imin(nn - 1, i0 + r)];
+#pragma unroll
+          for (int r = 0; r < kBlk; ++r) {
+            const int i = i0 + r;
+            if (i < nn) {
+              const double wt = tin[r] + fa0 * w0 + fa1 * w1;
+              const double o = fb0 * wt + fb1 * w0 + fb0 * w1;
+              w1 = w0; w0 = wt;
+              const int j = nn - i - 1;
+              if (j >= st && j <= ed) smooth[j - kSmLag] = o;
+            }
+          }
         }
       }
       __syncthreads();
@@ -679,6 +868,7 @@ static int hv_setup(Batch& b) {
   m.lag = m.r == 1 ? 0 : (int)(ceil(140.0 / m.r) * m.r);
   m.cpf = matlab_round(m.nch / 10.0);
   m.maxc = m.cpf * kHvOverlap;
+  if (m.maxc > 64 * kSelPer) { b.harvest_ws = nullptr; delete W; return WM_ERR_UNSUPPORTED; }   // hv_select_wave: candidates over lanes
   std::vector<double> bf((size_t)m.nch), taps;
   std::vector<int> half((size_t)m.nch), tapoff((size_t)m.nch);
   m.ntap_max = 0;
