@@ -23,6 +23,8 @@
 // linear one.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "batch.hpp"
 #include "common.hpp"
 #include "decimate.hpp"
@@ -210,57 +212,23 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const int* __restrict__ 
 // RefineF0Candidates (harvest.cpp:622-631) over the overlapped candidate table that
 // OverlapF0Candidates (:417-429) would build: slot s = j + ncand1 * blk reads frame k - blk
 // (blk = 1..3) or k + blk - 3 (blk = 4..6); out-of-range or unwritten entries are zero.
-template <int NB>
-__device__ __forceinline__ void hv_dft_bins(const double* __restrict__ ys, int ylen, const double* mw, int L,
-                                            int basic, const int (&bin)[NB], int nh, int fftn, int lane,
-                                            double (&pw)[NB], double (&num)[NB]) {
-  cpx mainv[NB], diffv[NB], w[NB], st[NB];
-  const double inv_fftn = 1.0 / fftn;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    mainv[b] = make_double2(0.0, 0.0);
-    diffv[b] = make_double2(0.0, 0.0);
-    // fftn is a power of two: the modulo is a mask and the division an exact multiplication
-    w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
-    st[b] = cis_neg2pi((double)((bin[b] * 64) & (fftn - 1)) * inv_fftn);
-  }
-  // four trips at a time: the samples of a group are requested together (one memory round trip)
-  for (int i0 = 0; i0 < L; i0 += 256) {
-    double xv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xv[q] = ys[imax(0, imin(ylen - 1, basic + imin(L - 1, i0 + 64 * q + lane) - 1))];   // :481-484
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = i0 + 64 * q + lane;
-      if (i0 + 64 * q < L) {                                          // uniform
-        const bool in = i < L;
-        const int ic = in ? i : L - 1;
-        const double mm = mw[ic];
-        double d;                                                     // :462-468
-        if (ic == 0) d = -mw[1] / 2.0;
-        else if (ic == L - 1) d = mw[L - 2] / 2.0;
-        else d = -(mw[ic + 1] - mw[ic - 1]) / 2.0;
-        const double am = in ? xv[q] * mm : 0.0, ad = in ? xv[q] * d : 0.0;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          if (b < nh) {
-            mainv[b].x += am * w[b].x; mainv[b].y += am * w[b].y;
-            diffv[b].x += ad * w[b].x; diffv[b].y += ad * w[b].y;
-            w[b] = cmul(w[b], st[b]);
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    double mr = mainv[b].x, mi = mainv[b].y, dr = diffv[b].x, di = diffv[b].y;
-    wave_sum4(mr, mi, dr, di);
-    num[b] = mr * di - mi * dr;                                     // :565-566
-    pw[b] = mr * mr + mi * mi;                                      // :567-568
-  }
+
+// sum over the 16 lanes of a DPP row, returned to every lane of the row
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_get<0x128, 0xf, 0xf>(v);              // row_ror:8
+  v += dpp_get<0x124, 0xf, 0xf>(v);              // row_ror:4
+  v += dpp_get<0x122, 0xf, 0xf>(v);              // row_ror:2
+  v += dpp_get<0x121, 0xf, 0xf>(v);              // row_ror:1
+  return v;
 }
 
+// RefineF0Candidates / GetRefinedF0 (harvest.cpp:434-617).  One wavefront per basic frame.  The
+// candidates of all slots are fetched side by side (lane = slot), empty slots are answered at once,
+// and the occupied ones are refined FOUR AT A TIME, one per 16-lane row: the windows are short at
+// the decimated rate (3 periods of 8 kHz: 100-340 samples), so a whole wavefront per candidate spends
+// most of its instructions on per-candidate scalar work replicated over 64 lanes (twiddle bases,
+// FixF0's divisions and square roots); a row per candidate shares that work four ways and reduces
+// over 16 lanes with four row rotations.
 __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ bframe_utt,
                                                        const int64_t* __restrict__ boff,
                                                        const int* __restrict__ nb1_a, HvMeta m,
@@ -268,11 +236,14 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
                                                        const int* __restrict__ ylen_a, const double* __restrict__ y,
                                                        const double* __restrict__ offc,
                                                        const int* __restrict__ ncand1_a, double f0_floor,
-                                                       double f0_ceil, int64_t tot_b, double* __restrict__ rc,
-                                                       double* __restrict__ rs) {
-  extern __shared__ __attribute__((aligned(16))) double mw[];
-  const int lane = threadIdx.x;
+                                                       double f0_ceil, int lmax, int64_t tot_b,
+                                                       double* __restrict__ rc, double* __restrict__ rs) {
+  extern __shared__ __attribute__((aligned(16))) double mw_all[];   // [4][lmax + 2]
+  const int lane0 = threadIdx.x;
   for (int64_t fr = blockIdx.x; fr < tot_b; fr += gridDim.x) {
+    const int lane = opaque_lane(lane0);
+    const int row = lane >> 4, l16 = lane & 15;
+    double* mw = mw_all + row * (lmax + 2);
     const int u = bframe_utt[fr];
     const int k = (int)(fr - boff[u]);
     const int nb1 = nb1_a[u];
@@ -281,8 +252,7 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
     const int ylen = ylen_a[u];
     const double pos = k * 1 / 1000.0;
     const double fs = m.afs;
-    // the candidates of all slots are fetched side by side (lane = slot); empty slots are answered at
-    // once and only the occupied ones are walked
+    const double inv_fs = 1.0 / fs;
     const int ns = nc1 * kHvOverlap;
     for (int s0 = 0; s0 < ns; s0 += 64) {
       const int sl_ = s0 + lane;
@@ -298,52 +268,107 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
       }
       unsigned long long todo = __ballot(f0s > 0.0);
       while (todo) {
-      const int pick = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int s = s0 + pick;
-      const double f0 = __shfl(f0s, pick, 64);
-      double rf0 = 0.0, rscore = 0.0;
-      {                                                            // GetRefinedF0 :589-617
+        // this row's candidate: the (row)-th set bit of todo; rows without one idle through the group
+        unsigned long long t = todo;
+        int pick = -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = t ? __ffsll((long long)t) - 1 : -1;
+          if (r == row) pick = p;
+          if (t) t &= t - 1;
+        }
+        todo = t;
+        const bool live = pick >= 0;
+        // the shuffle must run on every lane: a lane of an idle row may be the SOURCE of a live one, and
+        // ds_bpermute returns 0 for sources that are masked off
+        const double f0_any = __shfl(f0s, pick < 0 ? 0 : pick, 64);
+        const double f0 = live ? f0_any : 100.0;
+        const int slot = s0 + pick;
+        // GetRefinedF0 :589-617
         const int hw = (int)(1.5 * fs / f0 + 1.0);
         const int L = 2 * hw + 1;
         const double wlen = (2.0 * hw + 1.0) / fs;
+        const double inv_wlen = 1.0 / wlen;
         const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
+        const double inv_fftn = 1.0 / fftn;               // power of two: exact
         const double bt0 = (-hw + 0) / fs;
         const int basic = matlab_round((pos + bt0) * fs + 0.001);  // GetBaseIndex :434-441
-        __syncthreads();
-        const double inv_fs = 1.0 / fs, inv_wlen = 1.0 / wlen;
-        for (int i = lane; i < L; i += 64) {                       // GetMainWindow :446-456
-          const double tm = ((basic + i) - 1.0) * inv_fs - pos;
-          const double c1 = cospi(2.0 * tm * inv_wlen);             // cos(2 pi tm / wlen); cos(4 pi ..) = 2 c^2 - 1
-          mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+        int Lmax = L;
+#pragma unroll
+        for (int sh = 32; sh >= 16; sh >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, sh, 64));
+        wave_sync();
+        for (int i0 = 0; i0 < Lmax; i0 += 16) {                     // GetMainWindow :446-456
+          const int i = i0 + l16;
+          if (i < L) {
+            const double tm = ((basic + i) - 1.0) * inv_fs - pos;
+            const double c1 = cospi(2.0 * tm * inv_wlen);           // cos(2 pi tm / wlen); cos(4 pi ..) = 2 c^2 - 1
+            mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+          }
         }
-        __syncthreads();
+        wave_sync();
         const int nh = imin((int)(fs / 2.0 / f0), 6);              // :571-572
         int bin[6];
-        double pw[6], num[6];
+        cpx mainv[6], diffv[6], w[6], st[6];
 #pragma unroll
-        for (int h = 0; h < 6; ++h) bin[h] = matlab_round(f0 * fftn / fs * (h + 1));   // FixF0 :515
-        hv_dft_bins<6>(ys, ylen, mw, L, basic, bin, nh, fftn, lane, pw, num);
+        for (int h = 0; h < 6; ++h) {
+          bin[h] = matlab_round(f0 * fftn / fs * (h + 1));          // FixF0 :515
+          mainv[h] = make_double2(0.0, 0.0);
+          diffv[h] = make_double2(0.0, 0.0);
+          w[h] = cis_neg2pi((double)((bin[h] * l16) & (fftn - 1)) * inv_fftn);
+          st[h] = cis_neg2pi((double)((bin[h] * 16) & (fftn - 1)) * inv_fftn);
+        }
+        // windowed DFT bins (GetSpectra / GetMainWindow / GetDiffWindow :462-568), four trips per round
+        for (int i0 = 0; i0 < Lmax; i0 += 64) {
+          double xv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            xv[q] = ys[imax(0, imin(ylen - 1, basic + imin(L - 1, i0 + 16 * q + l16) - 1))];   // :481-484
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 16 * q + l16;
+            if (i0 + 16 * q < Lmax) {                                // uniform
+              const bool in = i < L;
+              const int ic = in ? i : L - 1;
+              const double mm = mw[ic];
+              double d;                                             // :462-468
+              if (ic == 0) d = -mw[1] / 2.0;
+              else if (ic == L - 1) d = mw[L - 2] / 2.0;
+              else d = -(mw[ic + 1] - mw[ic - 1]) / 2.0;
+              const double am = in ? xv[q] * mm : 0.0, ad = in ? xv[q] * d : 0.0;
+#pragma unroll
+              for (int h = 0; h < 6; ++h) {
+                if (h < nh) {
+                  mainv[h].x += am * w[h].x; mainv[h].y += am * w[h].y;
+                  diffv[h].x += ad * w[h].x; diffv[h].y += ad * w[h].y;
+                  w[h] = cmul(w[h], st[h]);
+                }
+              }
+            }
+          }
+        }
         double numer = 0.0, denom = 0.0, sc = 0.0;
 #pragma unroll
         for (int h = 0; h < 6; ++h) {
+          const double mr = row_sum16(mainv[h].x), mi = row_sum16(mainv[h].y);
+          const double dr = row_sum16(diffv[h].x), di = row_sum16(diffv[h].y);
           if (h < nh) {
-            const double p = bin[h] <= fftn / 2 ? pw[h] : 0.0;
-            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * (1.0 / fftn) + num[h] / p * fs / 2.0 / kPi;
+            const double num = mr * di - mi * dr;                   // :565-566
+            const double pwv = mr * mr + mi * mi;                   // :567-568
+            const double p = bin[h] <= fftn / 2 ? pwv : 0.0;
+            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * inv_fftn + num / p * fs / 2.0 / kPi;
             const double amp = sqrt(p);
             numer += amp * inst;
             denom += amp * (h + 1.0);
             sc += fabs((inst / (h + 1.0) - f0) / f0);
           }
         }
-        rf0 = numer / (denom + kSafe);
-        rscore = 1.0 / (sc / nh + kSafe);
+        double rf0 = numer / (denom + kSafe);
+        double rscore = 1.0 / (sc / nh + kSafe);
         if (rf0 < f0_floor || rf0 > f0_ceil || rscore < 2.5) { rf0 = 0.0; rscore = 0.0; }   // :610-614
-      }
-      if (lane == 0) {
-        rc[fr * m.maxc + s] = rf0;
-        rs[fr * m.maxc + s] = rscore;
-      }
+        if (live && l16 == 0) {
+          rc[fr * m.maxc + slot] = rf0;
+          rs[fr * m.maxc + slot] = rscore;
+        }
       }
     }
   }
@@ -1020,11 +1045,11 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   {
     TimedScope ts_(b.ctx, "hv_refine_kernel");
     const int lmax = 2 * (int)(1.5 * m.afs / b.p.f0_floor + 1.0) + 1;
-    const size_t lds = sizeof(double) * (size_t)(lmax + 2);
+    const size_t lds = sizeof(double) * 4 * (size_t)(lmax + 2);
     const int grid = (int)(W.tot_b < (int64_t)c.frame_grid ? W.tot_b : (int64_t)c.frame_grid);
     hipLaunchKernelGGL(hv_refine_kernel, dim3(grid), dim3(64), lds, st, W.d_bframe_utt, W.d_boff, W.d_nb1, m,
-                       W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, W.tot_b, W.d_rc,
-                       W.d_rs);
+                       W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, lmax, W.tot_b,
+                       W.d_rc, W.d_rs);
   }
   {
     const int64_t items = W.tot_b * m.maxc;
