@@ -276,3 +276,37 @@ def test_dio_option_sweep(gpu, oracle, kw):
     assert ((f0.cpu().numpy() > 0) == (fo > 0)).all()
     np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
     b.close()
+
+
+def test_fir_tile_edges(gpu, oracle):
+    """DIO / Harvest filter tiles are 2046 samples; StoneMask, the synthesis chain and the smoothing scan work in
+    chunks of 64..2048.  Lengths sitting on, just below and just above those boundaries, in one ragged batch."""
+    torch, W, ctx = gpu
+    fs = 16000
+    base = sd.make_utterance(77, fs, duration=1.2)
+    lens = [2045, 2046, 2047, 2 * 2046 - 1, 2 * 2046, 2 * 2046 + 1, 4 * 2046 + 1, 8191, 8192, 8193]
+    xs = [np.ascontiguousarray(base[:n]) for n in lens]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+    xc = torch.from_numpy(np.concatenate(xs)).cuda()
+    t, f0d = b.dio(xc)
+    ro = [oracle.dio(x, fs, 5.0) for x in xs]
+    np.testing.assert_array_equal(t.cpu().numpy(), np.concatenate([r[0] for r in ro]))
+    fo = np.concatenate([r[1] for r in ro])
+    assert ((f0d.cpu().numpy() > 0) == (fo > 0)).all()
+    np.testing.assert_allclose(f0d.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+    th, f0h = b.harvest(xc)
+    rh = [oracle.harvest(x, fs, 5.0) for x in xs]
+    fh = np.concatenate([r[1] for r in rh])
+    assert ((f0h.cpu().numpy() > 0) == (fh > 0)).all()
+    np.testing.assert_allclose(f0h.cpu().numpy(), fh, atol=F0_TOL, rtol=0)
+    b.close()
+    # the sequential phase chain of Synthesis: output lengths around its 64 / 1024 / 2048 sample blocks
+    x = sd.make_utterance(78, fs, duration=0.6)
+    r = oracle_chain(oracle, x, fs)
+    for ylen in (1023, 1024, 1025, 2047, 2048, 2049, 4097):
+        yo = oracle.synthesis(r["f0"], r["sp"], r["ap"], r["F"], 5.0, fs, y_length=ylen)
+        bb = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)], y_lengths=[ylen])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        y = bb.synthesize(dev(r["f0"]), dev(r["sp"]), dev(r["ap"]))
+        np.testing.assert_allclose(y.cpu().numpy(), yo, atol=Y_TOL, rtol=0)
+        bb.close()
