@@ -151,3 +151,43 @@ def synthesis(f0, spectrogram, aperiodicity, fft_size, frame_period, fs, y_lengt
     y = np.zeros(y_length)
     L.Synthesis(_p(f0), len(f0), _rows(sp), _rows(ap), fft_size, frame_period, fs, y_length, _p(y))
     return y
+
+
+# ---- world/codec.h -------------------------------------------------------------------------------
+def get_number_of_aperiodicities(fs):
+    L = _lib()
+    L.GetNumberOfAperiodicities.restype = C.c_int
+    return int(L.GetNumberOfAperiodicities(int(fs)))
+
+
+def code_spectral_envelope(spectrogram, fs, fft_size, number_of_dimensions):
+    """CodeSpectralEnvelope (codec.h:69-72) -> [f0_length][number_of_dimensions]."""
+    L, sp = _lib(), _c(spectrogram)
+    out = np.zeros((sp.shape[0], number_of_dimensions))
+    L.CodeSpectralEnvelope(_rows(sp), sp.shape[0], int(fs), int(fft_size), int(number_of_dimensions), _rows(out))
+    return out
+
+
+def decode_spectral_envelope(coded, fs, fft_size):
+    """DecodeSpectralEnvelope (codec.h:86-88) -> [f0_length][fft_size/2+1]."""
+    L, cd = _lib(), _c(coded)
+    out = np.zeros((cd.shape[0], fft_size // 2 + 1))
+    L.DecodeSpectralEnvelope(_rows(cd), cd.shape[0], int(fs), int(fft_size), cd.shape[1], _rows(out))
+    return out
+
+
+def code_aperiodicity(aperiodicity, fs, fft_size):
+    """CodeAperiodicity (codec.h:38-39) -> [f0_length][GetNumberOfAperiodicities(fs)]."""
+    L, ap = _lib(), _c(aperiodicity)
+    nap = get_number_of_aperiodicities(fs)
+    out = np.zeros((ap.shape[0], nap))
+    L.CodeAperiodicity(_rows(ap), ap.shape[0], int(fs), int(fft_size), nap, _rows(out))
+    return out
+
+
+def decode_aperiodicity(coded, fs, fft_size):
+    """DecodeAperiodicity; arguments in the order of the reference's DEFINITION (codec.cpp:237-238)."""
+    L, cd = _lib(), _c(coded)
+    out = np.zeros((cd.shape[0], fft_size // 2 + 1))
+    L.DecodeAperiodicity(_rows(cd), cd.shape[0], int(fs), cd.shape[1], int(fft_size), _rows(out))
+    return out

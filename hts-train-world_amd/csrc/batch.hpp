@@ -111,6 +111,7 @@ struct Batch {
   double* d_dio_cand = nullptr;      // [band][total_f]
   double* d_dio_score = nullptr;     // [band][total_f]
   void* harvest_ws = nullptr;        // HarvestWs (harvest.hip)
+  void* codec_tables = nullptr;      // CodecTables (codec.hip)
   // Synthesis workspace
   int* d_pulse_idx = nullptr;        // [total_y]
   double* d_pulse_shift = nullptr;   // [total_y]
@@ -134,5 +135,12 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
 int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp);
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
+int codec_num_aperiodicities(int fs);
+int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded);
+int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);
+int launch_code_aperiodicity(Batch& b, const double* d_ap, double* d_coded);
+int launch_decode_aperiodicity(Batch& b, const double* d_coded, double* d_ap);
+int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, int spec_dim,
+                           int ap_dim, float* d_lf0, float* d_mgc, float* d_bap);
 
 }  // namespace wm

@@ -18,6 +18,7 @@
 #include "batch.hpp"
 #include "common.hpp"
 #include "world/cheaptrick.h"
+#include "world/codec.h"
 #include "world/d4c.h"
 #include "world/dio.h"
 #include "world/harvest.h"
@@ -203,6 +204,24 @@ int WorldMi355D4C(WorldMi355Batch* b, const double* x, const double* t, const do
 int WorldMi355Synthesis(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
                         double* y) {
   return launch_synthesis(b->b, f0, sp, ap, y);
+}
+int WorldMi355GetNumberOfAperiodicities(int fs) { return codec_num_aperiodicities(fs); }
+int WorldMi355CodeSpectralEnvelope(WorldMi355Batch* b, const double* sp, int number_of_dimensions, double* coded) {
+  return launch_code_spectral_envelope(b->b, sp, number_of_dimensions, coded);
+}
+int WorldMi355DecodeSpectralEnvelope(WorldMi355Batch* b, const double* coded, int number_of_dimensions,
+                                     double* sp) {
+  return launch_decode_spectral_envelope(b->b, coded, number_of_dimensions, sp);
+}
+int WorldMi355CodeAperiodicity(WorldMi355Batch* b, const double* ap, double* coded) {
+  return launch_code_aperiodicity(b->b, ap, coded);
+}
+int WorldMi355DecodeAperiodicity(WorldMi355Batch* b, const double* coded, double* ap) {
+  return launch_decode_aperiodicity(b->b, coded, ap);
+}
+int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
+                             int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap) {
+  return launch_recipe_features(b->b, f0, sp, ap, spec_dim, ap_dim, lf0, mgc, bap);
 }
 int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0) {
   return wm::launch_harvest(b->b, x, t, f0);
@@ -420,6 +439,75 @@ void D4C(const double* x, int x_length, int fs, const double* temporal_positions
   dt.put(temporal_positions, (size_t)f0_length);
   df.put(f0, (size_t)f0_length);
   sync_or_die("D4C", WorldMi355D4C(ob.b, dx.p, dt.p, df.p, da.p));
+  get_rows(da, aperiodicity, f0_length, w);
+}
+
+// ---- world/codec.h --------------------------------------------------------------------------------
+int GetNumberOfAperiodicities(int fs) { return codec_num_aperiodicities(fs); }   // codec.cpp:212-215
+
+namespace {
+// a frames-only batch: the codec needs fs, fft_size and the frame count
+struct CodecBatch {
+  WorldMi355Params p;
+  OneBatch* ob = nullptr;
+  CodecBatch(int fs, int fft_size, int f0_length) {
+    WorldMi355DefaultParams(fs, 5.0, &p);
+    p.fft_size = fft_size;
+    ob = new OneBatch(p, nullptr, &f0_length, nullptr);
+  }
+  ~CodecBatch() { delete ob; }
+};
+}  // namespace
+
+void CodeSpectralEnvelope(const double* const* spectrogram, int f0_length, int fs, int fft_size,
+                          int number_of_dimensions, double** coded_spectral_envelope) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int w = fft_size / 2 + 1;
+  CodecBatch cb(fs, fft_size, f0_length);
+  DevBuf ds((size_t)f0_length * w), dc((size_t)f0_length * number_of_dimensions);
+  put_rows(ds, spectrogram, f0_length, w);
+  sync_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(cb.ob->b, ds.p, number_of_dimensions, dc.p));
+  get_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
+}
+
+void DecodeSpectralEnvelope(const double* const* coded_spectral_envelope, int f0_length, int fs, int fft_size,
+                            int number_of_dimensions, double** spectrogram) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int w = fft_size / 2 + 1;
+  CodecBatch cb(fs, fft_size, f0_length);
+  DevBuf dc((size_t)f0_length * number_of_dimensions), ds((size_t)f0_length * w);
+  put_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
+  sync_or_die("DecodeSpectralEnvelope",
+              WorldMi355DecodeSpectralEnvelope(cb.ob->b, dc.p, number_of_dimensions, ds.p));
+  get_rows(ds, spectrogram, f0_length, w);
+}
+
+void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, int fft_size,
+                      int number_of_aperiodicities, double** coded_aperiodicity) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (number_of_aperiodicities != codec_num_aperiodicities(fs))
+    die("CodeAperiodicity: number_of_aperiodicities must be GetNumberOfAperiodicities(fs)", WM_ERR_BAD_ARG);
+  const int w = fft_size / 2 + 1;
+  CodecBatch cb(fs, fft_size, f0_length);
+  DevBuf da((size_t)f0_length * w), dc((size_t)f0_length * number_of_aperiodicities);
+  put_rows(da, aperiodicity, f0_length, w);
+  sync_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(cb.ob->b, da.p, dc.p));
+  get_rows(dc, coded_aperiodicity, f0_length, number_of_aperiodicities);
+}
+
+// Positional meaning of the reference's DEFINITION (codec.cpp:237-238): the 4th argument is the number
+// of aperiodicities and the 5th the FFT size, whatever the header calls them.
+void DecodeAperiodicity(const double* const* coded_aperiodicity, int f0_length, int fs, int arg4_number_of_aperiodicities,
+                        int arg5_fft_size, double** aperiodicity) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  const int nap = arg4_number_of_aperiodicities, fft_size = arg5_fft_size;
+  if (nap != codec_num_aperiodicities(fs))
+    die("DecodeAperiodicity: 4th argument must be GetNumberOfAperiodicities(fs) (codec.cpp:237-238)", WM_ERR_BAD_ARG);
+  const int w = fft_size / 2 + 1;
+  CodecBatch cb(fs, fft_size, f0_length);
+  DevBuf dc((size_t)f0_length * nap), da((size_t)f0_length * w);
+  put_rows(dc, coded_aperiodicity, f0_length, nap);
+  sync_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(cb.ob->b, dc.p, da.p));
   get_rows(da, aperiodicity, f0_length, w);
 }
 

@@ -1,0 +1,388 @@
+// codec.hip -- WORLD's feature codec on the device.
+//
+// Replaces externs/WORLD_v2/src/codec.cpp:
+//   codec_code_sp_kernel     CodeSpectralEnvelope :268-295 (CodeOneFrame :122-133, DCTForCodec :73-88)
+//   codec_decode_sp_kernel   DecodeSpectralEnvelope :297-324 (DecodeOneFrame :138-157, IDCTForCodec :93-117)
+//   codec_code_ap_kernel     CodeAperiodicity :217-235
+//   codec_decode_ap_kernel   DecodeAperiodicity :237-266 (CheckVUV :30-41, GetAperiodicity :46-54)
+// plus the feature packing of the analysis CLI (test/analysis.cpp:292-366: x 1e4, offsets, log f0,
+// float32) as options of the coding kernel, so that the recipe's coded `lf0/mgc/bap` come straight
+// out of HBM-resident sp/ap.
+//
+// Both interp1 calls of the spectral codec run between two FIXED axes (they depend on fs and fft_size
+// only), so the knot index and the fraction of every query point are tabulated once per batch on the
+// host -- with the same expressions the reference evaluates per frame -- and a frame costs one
+// lookup-and-lerp per point.  The DCT is the reference's own construction: even/odd reordering and a
+// real FFT of fft_size/2 points (one wavefront, fft.hpp), then the weights; the inverse is a complex
+// FFT of fft_size/2 points of which only the real parts are used (fft.cpp's c2c "backward" returns the
+// conjugate of the forward transform of its input).
+#include <math.h>
+
+#include <vector>
+
+#include "batch.hpp"
+#include "common.hpp"
+#include "fft.hpp"
+#include "window.hpp"
+
+namespace wm {
+
+constexpr double kCodecM0 = 1127.01048;        // constantnumbers.h
+constexpr double kCodecF0 = 700.0;
+constexpr double kCodecFloorFreq = 40.0;
+constexpr double kCodecCeilFreq = 20000.0;
+constexpr double kCodecFreqInterval = 3000.0;
+constexpr double kCodecUpperLimit = 15000.0;
+
+struct CodeOpts {            // analysis.cpp:296-348 applied around CodeSpectralEnvelope; identity by default
+  double pre_scale;          // input multiplied by this before the log
+  double zero_value;         // a scaled input of exactly 0 becomes this (0 = leave it)
+  double c0_add;             // added to coefficient 0
+  int c0_snap;               // 1: coefficient 0 in (0, 1e-4) becomes 0 (analysis.cpp:343-345)
+};
+
+template <int F, class OUT>
+__global__ __launch_bounds__(64) void codec_code_sp_kernel(const double* __restrict__ in,
+                                                           const int* __restrict__ kidx,
+                                                           const double* __restrict__ sfrac,
+                                                           const cpx* __restrict__ weight, int ndim, CodeOpts o,
+                                                           int64_t total_frames, OUT* __restrict__ out) {
+  constexpr int MD = F / 2, BINS = F / 2 + 1, N = MD, M = N / 64;
+  __shared__ __attribute__((aligned(16))) double ls[BINS + 1];
+  __shared__ __attribute__((aligned(16))) double wave[MD];
+  __shared__ __attribute__((aligned(16))) cpx img[FftLds<N>::kElems];
+  const int lane0 = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane0);
+  const double inv_norm = 1.0 / sqrt((double)MD);
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
+    const double* row = in + frame * (int64_t)BINS;
+    wave_sync();
+    for (int j = lane; j < BINS; j += 64) {
+      double v = row[j] * o.pre_scale;
+      if (o.zero_value != 0.0 && v == 0.0) v = o.zero_value;
+      ls[j] = log(v);
+    }
+    wave_sync();
+    // interp1 onto the mel axis (codec.cpp:126-129) and the even/odd reordering of DCTForCodec (:77-82)
+    for (int m = lane; m < MD; m += 64) {
+      const int k = kidx[m];
+      const double y0 = ls[k - 1];
+      const double v = y0 + sfrac[m] * (ls[k] - y0);
+      wave[(m & 1) ? (MD - 1 - m) / 2 + MD / 2 : m / 2] = v;
+    }
+    wave_sync();
+    // DFT of the MD real points: the reference takes a real FFT; the one-wavefront engine starts at 512
+    // complex points, so the sequence goes in as complex with zero imaginary parts (bins 0..MD/2 are the
+    // same numbers)
+    cpx v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) v[m] = make_double2(wave[lane + 64 * m], 0.0);
+    fft_forward<N>(v, img, tw, lane);
+    OUT* orow = out + frame * (int64_t)ndim;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i = lane + 64 * m;
+      if (i < ndim) {
+        const cpx w = weight[i];
+        double c = (v[m].x * w.x - v[m].y * w.y) * inv_norm;
+        if (i == 0) {
+          c += o.c0_add;
+          if (o.c0_snap && c > 0.0 && c < 1e-4) c = 0.0;
+        }
+        orow[i] = (OUT)c;
+      }
+    }
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(64) void codec_decode_sp_kernel(const double* __restrict__ coded, int ndim,
+                                                             const int* __restrict__ kidx,
+                                                             const double* __restrict__ sfrac,
+                                                             const cpx* __restrict__ weight, int64_t total_frames,
+                                                             double* __restrict__ sp) {
+  constexpr int MD = F / 2, BINS = F / 2 + 1, N = MD, M = N / 64;
+  __shared__ __attribute__((aligned(16))) cpx img[FftLds<N>::kElems];
+  __shared__ __attribute__((aligned(16))) double knots[MD + 2];
+  const int lane0 = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane0);
+  const double norm = sqrt((double)MD), inv_md = 1.0 / MD;
+  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+    const int lane = opaque_lane(lane0);
+    const double* crow = coded + frame * (int64_t)ndim;
+    cpx v[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {                                   // IDCTForCodec :96-106
+      const int i = lane + 64 * m;
+      v[m] = make_double2(0.0, 0.0);
+      if (i < ndim) {
+        const double c = crow[i];
+        const cpx w = weight[i];
+        v[m] = make_double2(c * w.x * norm, -c * w.y * norm);
+      }
+    }
+    fft_forward<N>(v, img, tw, lane);                               // real parts == the wrapper's output
+    wave_sync();
+    // mel_spectrum[2 i] = out[i], mel_spectrum[2 i + 1] = out[MD - i - 1] (:110-114), padded by its own
+    // end values (DecodeOneFrame :147-148)
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i = lane + 64 * m;                                  // FFT output index
+      const int j = i < MD / 2 ? 2 * i : 2 * (MD - 1 - i) + 1;      // mel_spectrum index
+      knots[1 + j] = v[m].x;
+      if (j == 0) knots[0] = v[m].x;
+      if (j == MD - 1) knots[MD + 1] = v[m].x;
+    }
+    wave_sync();
+    double* orow = sp + frame * (int64_t)BINS;
+    for (int b = lane; b < BINS; b += 64) {
+      const int k = kidx[b];
+      const double y0 = knots[k - 1];
+      orow[b] = exp((y0 + sfrac[b] * (knots[k] - y0)) * inv_md);
+    }
+    wave_sync();
+  }
+}
+
+// coded[frame][k] = interp1Q(0, fs/fft, 20 log10(ap[frame][.]), 3000 (k+1))  (codec.cpp:217-235)
+__global__ __launch_bounds__(256) void codec_code_ap_kernel(const double* __restrict__ ap, int bins, int fs,
+                                                            int fft_size, int nap, int64_t total_frames,
+                                                            double* __restrict__ coded) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_frames * nap) return;
+  const int64_t frame = idx / nap;
+  const int k = (int)(idx - frame * nap);
+  const double xi = kCodecFreqInterval * (k + 1.0);
+  const double q = (xi - 0) / ((double)fs / fft_size);            // interp1Q, matlabfunctions.cpp:220-241
+  const int b = (int)q;
+  const double frac = q - b;
+  const double* row = ap + frame * (int64_t)bins;
+  const double y0 = 20 * log10(row[b]);
+  const double dy = (b == bins - 1) ? 0.0 : 20 * log10(row[b + 1]) - y0;
+  coded[idx] = y0 + dy * frac;
+}
+
+__global__ __launch_bounds__(256) void codec_decode_ap_kernel(const double* __restrict__ coded, int nap, int fs,
+                                                              int fft_size, int64_t total_frames,
+                                                              double* __restrict__ ap) {
+  const int bins = fft_size / 2 + 1;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_frames * bins) return;
+  const int64_t frame = idx / bins;
+  const int b = (int)(idx - frame * bins);
+  const double* c = coded + frame * (int64_t)nap;
+  double tmp = 0.0;                                                // CheckVUV :30-41
+  for (int k = 0; k < nap; ++k) tmp += c[k];
+  tmp /= nap;
+  if (tmp > -0.5) { ap[idx] = 1.0 - kSafe; return; }                // keeps InitializeAperiodicity's value
+  const double f = (double)fs / fft_size * b;
+  const int n = nap + 2;                                           // knots 0, 3000 k, fs/2 (:244-252)
+  int cnt = 0;
+  for (int j = 0; j < n; ++j) {
+    const double xj = j <= nap ? j * kCodecFreqInterval : fs / 2.0;
+    cnt += xj <= f ? 1 : 0;
+  }
+  const int k = cnt < 1 ? 1 : (cnt > n - 1 ? n - 1 : cnt);
+  const double x0 = (k - 1) <= nap ? (k - 1) * kCodecFreqInterval : fs / 2.0;
+  const double x1 = k <= nap ? k * kCodecFreqInterval : fs / 2.0;
+  const double y0 = k - 1 == 0 ? -60.0 : c[k - 2];
+  const double y1 = k == nap + 1 ? -kSafe : c[k - 1];
+  const double s = (f - x0) / (x1 - x0);
+  ap[idx] = pow(10.0, (y0 + s * (y1 - y0)) / 20.0);
+}
+
+// lf0 = log f0, 0 where unvoiced (analysis.cpp:216-224), as float32
+__global__ __launch_bounds__(256) void codec_lf0_kernel(const double* __restrict__ f0, int64_t n,
+                                                        float* __restrict__ lf0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) lf0[i] = (float)(f0[i] != 0 ? log(f0[i]) : 0.0);
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static double to_mel(double f) { return kCodecM0 * log(f / kCodecF0 + 1.0); }         // codec.cpp:59-61
+static double from_mel(double m) { return kCodecF0 * (exp(m / kCodecM0) - 1.0); }     // codec.cpp:66-68
+
+// interp1's knot choice and fraction (matlabfunctions.cpp:136-182) for fixed axes
+static void interp_table(const std::vector<double>& x, const std::vector<double>& xi, std::vector<int>& k,
+                         std::vector<double>& s) {
+  const int n = (int)x.size();
+  k.resize(xi.size());
+  s.resize(xi.size());
+  for (size_t i = 0; i < xi.size(); ++i) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (x[(size_t)mid] <= xi[i]) lo = mid + 1; else hi = mid;
+    }
+    const int kk = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    k[i] = kk;
+    s[i] = (xi[i] - x[(size_t)kk - 1]) / (x[(size_t)kk] - x[(size_t)kk - 1]);
+  }
+}
+
+struct CodecTables {
+  int* d_code_k = nullptr; double* d_code_s = nullptr; cpx* d_code_w = nullptr;
+  int* d_dec_k = nullptr; double* d_dec_s = nullptr; cpx* d_dec_w = nullptr;
+};
+
+static int codec_setup(Batch& b) {
+  if (b.codec_tables) return WM_OK;
+  const int fs = b.p.fs, F = b.p.fft_size, md = F / 2, bins = F / 2 + 1;
+  const double ceilf = fs / 2.0 < kCodecCeilFreq ? fs / 2.0 : kCodecCeilFreq;
+  const double floor_mel = to_mel(kCodecFloorFreq), ceil_mel = to_mel(ceilf);
+  CodecTables* T = new CodecTables();
+  int rc = WM_OK;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (rc) return;
+    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  };
+  {   // coding: frequency axis in mel (knots) -> uniform mel axis (queries), GetParametersForCoding :161-180
+    std::vector<double> x((size_t)bins), xi((size_t)md);
+    for (int i = 0; i < bins; ++i) x[(size_t)i] = to_mel((double)i * fs / F);   // knot F/2 is never reached
+    for (int i = 0; i < md; ++i) xi[(size_t)i] = (ceil_mel - floor_mel) * i / md + floor_mel;
+    std::vector<int> k; std::vector<double> s;
+    interp_table(x, xi, k, s);
+    std::vector<cpx> w((size_t)md);
+    for (int i = 0; i < md; ++i)
+      w[(size_t)i] = make_double2(2.0 * cos(i * kPi / F) / sqrt((double)F), 2.0 * sin(i * kPi / F) / sqrt((double)F));
+    w[0].x /= sqrt(2.0);
+    up((void**)&T->d_code_k, k.data(), sizeof(int) * k.size());
+    up((void**)&T->d_code_s, s.data(), sizeof(double) * s.size());
+    up((void**)&T->d_code_w, w.data(), sizeof(cpx) * w.size());
+  }
+  {   // decoding: mel axis in Hz padded by 0 and fs/2 (knots) -> uniform Hz axis, GetParametersForDecoding :185-208
+    std::vector<double> x((size_t)md + 2), xi((size_t)bins);
+    for (int i = 0; i < md; ++i) x[(size_t)i + 1] = from_mel((ceil_mel - floor_mel) * i / md + floor_mel);
+    x[0] = 0;
+    x[(size_t)md + 1] = fs / 2.0;
+    for (int i = 0; i < bins; ++i) xi[(size_t)i] = (double)i * fs / F;
+    std::vector<int> k; std::vector<double> s;
+    interp_table(x, xi, k, s);
+    std::vector<cpx> w((size_t)md);
+    for (int i = 0; i < md; ++i)
+      w[(size_t)i] = make_double2(cos(i * kPi / F) * sqrt((double)F), sin(i * kPi / F) * sqrt((double)F));
+    w[0].x /= sqrt(2.0);
+    up((void**)&T->d_dec_k, k.data(), sizeof(int) * k.size());
+    up((void**)&T->d_dec_s, s.data(), sizeof(double) * s.size());
+    up((void**)&T->d_dec_w, w.data(), sizeof(cpx) * w.size());
+  }
+  b.codec_tables = T;
+  return rc;
+}
+
+void codec_free(void* p) {
+  CodecTables* T = (CodecTables*)p;
+  if (!T) return;
+  void* ptrs[] = {T->d_code_k, T->d_code_s, T->d_code_w, T->d_dec_k, T->d_dec_s, T->d_dec_w};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete T;
+}
+
+int codec_num_aperiodicities(int fs) {                              // codec.cpp:212-215
+  const double lim = fs / 2.0 - kCodecFreqInterval;
+  return (int)((kCodecUpperLimit < lim ? kCodecUpperLimit : lim) / kCodecFreqInterval);
+}
+
+template <class OUT>
+static int code_sp(Batch& b, const double* d_in, int ndim, CodeOpts o, OUT* d_out, const char* name) {
+  const int F = b.p.fft_size;
+  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (ndim < 1 || ndim > F / 4 + 1) return WM_ERR_BAD_ARG;      // the reference reads spectrum[i], i <= fft_size/4
+  int rc = codec_setup(b);
+  if (rc) return rc;
+  const CodecTables& T = *(CodecTables*)b.codec_tables;
+  const int64_t tf = b.total_f;
+  if (tf <= 0) return WM_OK;
+  hipStream_t st = b.ctx->stream;
+  TimedScope ts_(b.ctx, name);
+#define WM_CODE_CASE(FF)                                                                                     \
+  case FF: {                                                                                                 \
+    static const int per_ = persistent_grid(*b.ctx, codec_code_sp_kernel<FF, OUT>, 64, (int64_t)1 << 40);    \
+    hipLaunchKernelGGL((codec_code_sp_kernel<FF, OUT>), dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st, \
+                       d_in, T.d_code_k, T.d_code_s, T.d_code_w, ndim, o, tf, d_out);                        \
+  } break;
+  switch (F) {
+    WM_CODE_CASE(1024)
+    WM_CODE_CASE(2048)
+  }
+#undef WM_CODE_CASE
+  return wm_check(hipGetLastError());
+}
+
+int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded) {
+  const CodeOpts o = {1.0, 0.0, 0.0, 0};
+  return code_sp<double>(b, d_sp, ndim, o, d_coded, "codec_code_sp_kernel");
+}
+
+int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp) {
+  const int F = b.p.fft_size;
+  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (ndim < 1 || ndim > F / 2) return WM_ERR_BAD_ARG;
+  int rc = codec_setup(b);
+  if (rc) return rc;
+  const CodecTables& T = *(CodecTables*)b.codec_tables;
+  const int64_t tf = b.total_f;
+  if (tf <= 0) return WM_OK;
+  hipStream_t st = b.ctx->stream;
+  TimedScope ts_(b.ctx, "codec_decode_sp_kernel");
+#define WM_DEC_CASE(FF)                                                                                      \
+  case FF: {                                                                                                 \
+    static const int per_ = persistent_grid(*b.ctx, codec_decode_sp_kernel<FF>, 64, (int64_t)1 << 40);       \
+    hipLaunchKernelGGL(codec_decode_sp_kernel<FF>, dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st,      \
+                       d_coded, ndim, T.d_dec_k, T.d_dec_s, T.d_dec_w, tf, d_sp);                            \
+  } break;
+  switch (F) {
+    WM_DEC_CASE(1024)
+    WM_DEC_CASE(2048)
+  }
+#undef WM_DEC_CASE
+  return wm_check(hipGetLastError());
+}
+
+int launch_code_aperiodicity(Batch& b, const double* d_ap, double* d_coded) {
+  const int nap = codec_num_aperiodicities(b.p.fs);
+  const int64_t n = b.total_f * nap;
+  if (n <= 0) return WM_OK;
+  TimedScope ts_(b.ctx, "codec_code_ap_kernel");
+  hipLaunchKernelGGL(codec_code_ap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.ctx->stream, d_ap,
+                     b.p.fft_size / 2 + 1, b.p.fs, b.p.fft_size, nap, b.total_f, d_coded);
+  return wm_check(hipGetLastError());
+}
+
+int launch_decode_aperiodicity(Batch& b, const double* d_coded, double* d_ap) {
+  const int nap = codec_num_aperiodicities(b.p.fs);
+  if (nap < 1) return WM_ERR_UNSUPPORTED;
+  const int64_t n = b.total_f * (b.p.fft_size / 2 + 1);
+  if (n <= 0) return WM_OK;
+  TimedScope ts_(b.ctx, "codec_decode_ap_kernel");
+  hipLaunchKernelGGL(codec_decode_ap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.ctx->stream, d_coded,
+                     nap, b.p.fs, b.p.fft_size, b.total_f, d_ap);
+  return wm_check(hipGetLastError());
+}
+
+// The coded feature set the recipe's `analysis wav lf0 mgc bap 5 2048 50 25` call writes
+// (data/Makefile.in:214; test/analysis.cpp:292-366), as float32, from resident f0 / sp / ap:
+//   mgc = CodeSpectralEnvelope(sp * 1e4, zeros -> 1e-4)[spec_dim], coefficient 0 + 12.0
+//   bap = CodeSpectralEnvelope(ap * 1e4)[ap_dim], coefficient 0 - 9.210340, (0, 1e-4) -> 0
+//         (the mcep result computed just before is overwritten by the reference, :332-341)
+//   lf0 = log f0, 0 where unvoiced
+int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, int spec_dim,
+                           int ap_dim, float* d_lf0, float* d_mgc, float* d_bap) {
+  const CodeOpts osp = {1e4, 0.0001, 12.0, 0};
+  int rc = code_sp<float>(b, d_sp, spec_dim, osp, d_mgc, "codec_code_sp_kernel");
+  if (rc) return rc;
+  const CodeOpts oap = {1e4, 0.0, -9.210340, 1};
+  rc = code_sp<float>(b, d_ap, ap_dim, oap, d_bap, "codec_code_sp_kernel");
+  if (rc) return rc;
+  if (b.total_f > 0)
+    hipLaunchKernelGGL(codec_lf0_kernel, dim3((unsigned)((b.total_f + 255) / 256)), dim3(256), 0, b.ctx->stream, d_f0,
+                       b.total_f, d_lf0);
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm

@@ -90,6 +90,7 @@ int64_t Batch::rng_bound_synthesis() const { return (int64_t)max_y_len + 64; }
 namespace wm {
 void dio_free_host(void* h);
 void harvest_free(void* p);
+void codec_free(void* p);
 
 void free_batch_buffers(Batch& b) {
   void* ptrs[] = {b.d_x_off, b.d_f_off, b.d_y_off, b.d_x_len, b.d_f0_len, b.d_y_len, b.d_frame_utt,
@@ -106,5 +107,7 @@ void free_batch_buffers(Batch& b) {
   b.dio_host = nullptr;
   if (b.harvest_ws) harvest_free(b.harvest_ws);
   b.harvest_ws = nullptr;
+  if (b.codec_tables) codec_free(b.codec_tables);
+  b.codec_tables = nullptr;
 }
 }  // namespace wm

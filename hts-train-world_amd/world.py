@@ -73,6 +73,12 @@ def load_library():
     L.WorldMi355D4C.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.WorldMi355GetNumberOfAperiodicities.argtypes = [C.c_int]
+    L.WorldMi355CodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
+    L.WorldMi355DecodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
+    L.WorldMi355CodeAperiodicity.argtypes = [vp, vp, vp]
+    L.WorldMi355DecodeAperiodicity.argtypes = [vp, vp, vp]
+    L.WorldMi355RecipeFeatures.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.WorldMi355TestRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.WorldMi355TimingEnable.argtypes = [vp, C.c_int]
     L.WorldMi355TimingQuery.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -211,6 +217,46 @@ class WorldBatch:
         _check(load_library().WorldMi355Synthesis(self.handle, self._p(f0), self._p(sp), self._p(ap), self._p(y)),
                "Synthesis")
         return y
+
+    # ---- feature codec (world/codec.h) ----
+    def code_spectral_envelope(self, sp, number_of_dimensions):
+        import torch
+        out = torch.empty(self.total_frames, number_of_dimensions, dtype=torch.float64, device="cuda")
+        _check(load_library().WorldMi355CodeSpectralEnvelope(self.handle, self._p(sp), number_of_dimensions,
+                                                             self._p(out)), "CodeSpectralEnvelope")
+        return out
+
+    def decode_spectral_envelope(self, coded):
+        import torch
+        out = torch.empty(self.total_frames, self.fft_size // 2 + 1, dtype=torch.float64, device="cuda")
+        _check(load_library().WorldMi355DecodeSpectralEnvelope(self.handle, self._p(coded), int(coded.shape[1]),
+                                                               self._p(out)), "DecodeSpectralEnvelope")
+        return out
+
+    def code_aperiodicity(self, ap):
+        import torch
+        nap = load_library().WorldMi355GetNumberOfAperiodicities(int(self.params.fs))
+        out = torch.empty(self.total_frames, nap, dtype=torch.float64, device="cuda")
+        _check(load_library().WorldMi355CodeAperiodicity(self.handle, self._p(ap), self._p(out)), "CodeAperiodicity")
+        return out
+
+    def decode_aperiodicity(self, coded):
+        import torch
+        out = torch.empty(self.total_frames, self.fft_size // 2 + 1, dtype=torch.float64, device="cuda")
+        _check(load_library().WorldMi355DecodeAperiodicity(self.handle, self._p(coded), self._p(out)),
+               "DecodeAperiodicity")
+        return out
+
+    def recipe_features(self, f0, sp, ap, spec_dim=50, ap_dim=25):
+        """float32 lf0 / mgc / bap as the recipe's `analysis ... 5 2048 50 25` call writes them."""
+        import torch
+        lf0 = torch.empty(self.total_frames, dtype=torch.float32, device="cuda")
+        mgc = torch.empty(self.total_frames, spec_dim, dtype=torch.float32, device="cuda")
+        bap = torch.empty(self.total_frames, ap_dim, dtype=torch.float32, device="cuda")
+        _check(load_library().WorldMi355RecipeFeatures(self.handle, self._p(f0), self._p(sp), self._p(ap), spec_dim,
+                                                       ap_dim, C.c_void_p(lf0.data_ptr()), C.c_void_p(mgc.data_ptr()),
+                                                       C.c_void_p(bap.data_ptr())), "RecipeFeatures")
+        return lf0, mgc, bap
 
     def split_frames(self, a):
         return [a[self.frame_offsets[u]:self.frame_offsets[u + 1]] for u in range(self.n_utt)]

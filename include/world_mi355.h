@@ -101,6 +101,25 @@ int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0
 int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
                       double* ap);
 
+/* ---- Feature codec (externs/WORLD_v2/src/codec.cpp), SURVEY.md section 8(f) ---------------------------
+ * All arrays are device pointers over the batch's frames (row-major, frame order of the batch).
+ *   coded sp : double[total_frames][number_of_dimensions]
+ *   coded ap : double[total_frames][WorldMi355GetNumberOfAperiodicities(fs)]
+ * fs and fft_size are the batch's. */
+int WorldMi355GetNumberOfAperiodicities(int fs);                                  /* codec.cpp:212-215 */
+int WorldMi355CodeSpectralEnvelope(WorldMi355Batch* b, const double* sp, int number_of_dimensions,
+                                   double* coded);                                /* codec.cpp:268-295 */
+int WorldMi355DecodeSpectralEnvelope(WorldMi355Batch* b, const double* coded, int number_of_dimensions,
+                                     double* sp);                                 /* codec.cpp:297-324 */
+int WorldMi355CodeAperiodicity(WorldMi355Batch* b, const double* ap, double* coded);    /* codec.cpp:217-235 */
+int WorldMi355DecodeAperiodicity(WorldMi355Batch* b, const double* coded, double* ap);  /* codec.cpp:237-266 */
+/* The coded float32 feature set of the recipe's call `analysis wav lf0 mgc bap 5 2048 50 25`
+ * (data/Makefile.in:214, test/analysis.cpp:292-366): lf0[total_frames], mgc[total_frames][spec_dim],
+ * bap[total_frames][ap_dim] from resident f0 / sp / ap. */
+int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
+                             int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap);
+
+
 /* Per-kernel timing with HIP events recorded on the context's stream around each launch of the
  * named kernels ("dio_lowcut_kernel", "dio_band_kernel", "stonemask_kernel", "cheaptrick_kernel",
  * "d4c_lovetrain_kernel", "d4c_kernel", "synth_timebase_kernel", "synth_pulse_kernel",

@@ -96,6 +96,36 @@ class Oracle:
         self.lib.orc_stonemask(_p(x), len(x), fs, _p(t), _p(f0), len(f0), _p(out))
         return out
 
+    # -- feature codec (codec.cpp) -------------------------------------------
+    def num_aperiodicities(self, fs):
+        return int(self.lib.orc_num_aperiodicities(int(fs)))
+
+    def code_aperiodicity(self, ap, fs, fft_size):
+        ap = _c(ap)
+        nap = self.num_aperiodicities(fs)
+        out = np.zeros((ap.shape[0], nap))
+        self.lib.orc_code_aperiodicity(_p(ap), ap.shape[0], int(fs), int(fft_size), nap, _p(out))
+        return out
+
+    def decode_aperiodicity(self, coded, fs, fft_size):
+        coded = _c(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.orc_decode_aperiodicity(_p(coded), coded.shape[0], int(fs), coded.shape[1], int(fft_size), _p(out))
+        return out
+
+    def code_spectral_envelope(self, sp, fs, fft_size, ndim):
+        sp = _c(sp)
+        out = np.zeros((sp.shape[0], ndim))
+        self.lib.orc_code_spectral_envelope(_p(sp), sp.shape[0], int(fs), int(fft_size), int(ndim), _p(out))
+        return out
+
+    def decode_spectral_envelope(self, coded, fs, fft_size):
+        coded = _c(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.orc_decode_spectral_envelope(_p(coded), coded.shape[0], int(fs), int(fft_size), coded.shape[1],
+                                              _p(out))
+        return out
+
     def cheaptrick_fft_size(self, fs, f0_floor=71.0):
         return self.lib.orc_cheaptrick_fft_size(fs, f0_floor)
 
@@ -307,6 +337,38 @@ class WorldCApi:
         self.lib.Synthesis(_p(f0), len(f0), _rows(sp), _rows(ap), fft_size, frame_period, fs,
                            y_length, _p(y))
         return y
+
+    # -- feature codec (world/codec.h) ---------------------------------------
+    def num_aperiodicities(self, fs):
+        self.lib.GetNumberOfAperiodicities.restype = C.c_int
+        return int(self.lib.GetNumberOfAperiodicities(int(fs)))
+
+    def code_aperiodicity(self, ap, fs, fft_size):
+        ap = _c(ap)
+        nap = self.num_aperiodicities(fs)
+        out = np.zeros((ap.shape[0], nap))
+        self.lib.CodeAperiodicity(_rows(ap), ap.shape[0], int(fs), int(fft_size), nap, _rows(out))
+        return out
+
+    def decode_aperiodicity(self, coded, fs, fft_size):
+        """Arguments follow the DEFINITION's order (codec.cpp:237-238): (.., fs, nap, fft_size, ..)."""
+        coded = _c(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.DecodeAperiodicity(_rows(coded), coded.shape[0], int(fs), coded.shape[1], int(fft_size), _rows(out))
+        return out
+
+    def code_spectral_envelope(self, sp, fs, fft_size, ndim):
+        sp = _c(sp)
+        out = np.zeros((sp.shape[0], ndim))
+        self.lib.CodeSpectralEnvelope(_rows(sp), sp.shape[0], int(fs), int(fft_size), int(ndim), _rows(out))
+        return out
+
+    def decode_spectral_envelope(self, coded, fs, fft_size):
+        coded = _c(coded)
+        out = np.zeros((coded.shape[0], fft_size // 2 + 1))
+        self.lib.DecodeSpectralEnvelope(_rows(coded), coded.shape[0], int(fs), int(fft_size), coded.shape[1],
+                                        _rows(out))
+        return out
 
 
 class Reference(WorldCApi):

@@ -50,6 +50,36 @@ def harvest_case(ref, name, index, fs, duration, frame_period):
     print(name, "frames", len(t), "voiced", int((f0 > 0).sum()))
 
 
+def codec_case(ref, name, index, fs, duration, spec_dim, frame_period=5.0):
+    """world/codec.h on real analysis output, plus the recipe's packing (test/analysis.cpp:292-366)."""
+    x = sd.make_utterance(index, fs, duration=duration)
+    t, f0_dio = ref.dio(x, fs, frame_period)
+    f0 = ref.stonemask(x, fs, t, f0_dio)
+    fft_size = ref.cheaptrick_fft_size(fs)
+    sp = ref.cheaptrick(x, fs, t, f0, -0.15, fft_size)
+    ap = ref.d4c(x, fs, t, f0, fft_size, 0.0)
+    csp = ref.code_spectral_envelope(sp, fs, fft_size, spec_dim)
+    dsp = ref.decode_spectral_envelope(csp, fs, fft_size)
+    cap = ref.code_aperiodicity(ap, fs, fft_size)
+    dap = ref.decode_aperiodicity(cap, fs, fft_size)
+    sp4 = sp * 1e4
+    sp4[sp4 == 0.0] = 0.0001
+    mgc = ref.code_spectral_envelope(sp4, fs, fft_size, spec_dim)
+    mgc[:, 0] += 12.0
+    bap = ref.code_spectral_envelope(ap * 1e4, fs, fft_size, 25)
+    bap[:, 0] -= 9.210340
+    snap = (bap[:, 0] > 0) & (bap[:, 0] < 1e-4)
+    bap[snap, 0] = 0
+    lf0 = np.where(f0 != 0, np.log(np.where(f0 != 0, f0, 1.0)), 0.0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), index=index, fs=fs, duration=duration,
+                        frame_period=frame_period, fft_size=fft_size, spec_dim=spec_dim, f0=f0,
+                        sp_check=checks(sp), ap_check=checks(ap), coded_sp=csp, coded_ap=cap,
+                        decoded_sp_sub=dsp[::8], decoded_sp_check=checks(dsp), decoded_ap_sub=dap[::8],
+                        decoded_ap_check=checks(dap), lf0=lf0.astype(np.float32), mgc=mgc.astype(np.float32),
+                        bap=bap.astype(np.float32))
+    print(name, "frames", len(t), "coded", csp.shape, cap.shape)
+
+
 def primitives(ref):
     rng = np.random.default_rng(12345)
     out = {"randn4096": ref.randn_table(4096)}
@@ -82,6 +112,8 @@ def main():
     analysis_case(ref, "world_48k", 9, 48000, 1.5, frame_step=32, sample_step=23)
     harvest_case(ref, "harvest_16k", 3, 16000, 1.5, 5.0)
     harvest_case(ref, "harvest_48k_1ms", 4, 48000, 1.0, 1.0)
+    codec_case(ref, "codec_16k", 11, 16000, 1.6, 50)
+    codec_case(ref, "codec_48k", 12, 48000, 0.8, 60)
 
 
 if __name__ == "__main__":

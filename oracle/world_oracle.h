@@ -79,6 +79,17 @@ void orc_harvest(const double *x, int x_length, int fs, double f0_floor,
                  double f0_ceil, double frame_period, double *t,
                  double *f0);                                      /* harvest.cpp:1223-1255 */
 
+/* ---- Feature codec (codec.cpp), world_oracle_codec.c; flat row-major arrays ---- */
+int  orc_num_aperiodicities(int fs);                                       /* codec.cpp:212-215 */
+void orc_code_aperiodicity(const double *ap, int nf, int fs, int fft_size, int nap,
+                           double *coded);                                 /* codec.cpp:217-235 */
+void orc_decode_aperiodicity(const double *coded, int nf, int fs, int nap, int fft_size,
+                             double *ap);                                  /* codec.cpp:237-266 (definition's order) */
+void orc_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size, int ndim,
+                                double *coded);                            /* codec.cpp:268-295 */
+void orc_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size, int ndim,
+                                  double *sp);                             /* codec.cpp:297-324 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,175 @@
+/* world_oracle_codec.c -- CPU restatement of WORLD's feature codec.
+ *
+ * TEST INFRASTRUCTURE ONLY (see world_oracle.h).  Follows externs/WORLD_v2/src/codec.cpp; pinned
+ * against the compiled reference by tests/test_oracle_vs_ref.py and tests/golden/codec_*.npz.
+ *
+ * Notes on the reference that shape this file:
+ *  - the c2c "backward" wrapper (fft.cpp BackwardFFT, c2c branch) returns conj(sum_j in[j] e^{-j 2 pi jk/n});
+ *    DecodeOneFrame only reads the real parts, i.e. Re of the FORWARD DFT of the weighted cepstrum;
+ *  - GetParametersForCoding fills fft_size/2 entries of a frequency axis that interp1 is told has
+ *    fft_size/2 + 1 knots (codec.cpp:161-180, :126-129); the last knot is never reached because the
+ *    largest mel-axis point lies below knot fft_size/2 - 1; it is defined here as the natural next value;
+ *  - DecodeAperiodicity's definition takes (.., fs, number_of_aperiodicities, fft_size, ..) while the
+ *    header declares (.., fs, fft_size, number_of_aperiodicities, ..) (codec.h:53-54 vs codec.cpp:237-238):
+ *    same types, so the ABI is the definition's POSITIONAL meaning, which is what is restated.
+ */
+#include <math.h>
+#include <stdlib.h>
+
+#include "world_oracle.h"
+
+#define ORC_M0 1127.01048                 /* constantnumbers.h: kM0 */
+#define ORC_F0 700.0                      /* kF0 */
+#define ORC_FLOOR_FREQ 40.0               /* kFloorFrequency */
+#define ORC_CEIL_FREQ 20000.0             /* kCeilFrequency */
+#define ORC_FREQ_INTERVAL 3000.0          /* kFrequencyInterval */
+#define ORC_UPPER_LIMIT 15000.0           /* kUpperLimit */
+#define ORC_SAFE 0.000000000001           /* kMySafeGuardMinimum */
+#define ORC_PI_C 3.1415926535897932384
+
+static double to_mel(double f) { return ORC_M0 * log(f / ORC_F0 + 1.0); }        /* codec.cpp:59-61 */
+static double from_mel(double m) { return ORC_F0 * (exp(m / ORC_M0) - 1.0); }    /* codec.cpp:66-68 */
+
+int orc_num_aperiodicities(int fs) {                                             /* codec.cpp:212-215 */
+  double lim = fs / 2.0 - ORC_FREQ_INTERVAL;
+  return (int)((ORC_UPPER_LIMIT < lim ? ORC_UPPER_LIMIT : lim) / ORC_FREQ_INTERVAL);
+}
+
+/* CodeAperiodicity, codec.cpp:217-235.  ap: [nf][fft_size/2+1], coded: [nf][nap]. */
+void orc_code_aperiodicity(const double *ap, int nf, int fs, int fft_size, int nap, double *coded) {
+  const int bins = fft_size / 2 + 1;
+  double *axis = (double *)malloc(sizeof(double) * (size_t)(nap > 0 ? nap : 1));
+  double *la = (double *)malloc(sizeof(double) * (size_t)bins);
+  for (int i = 0; i < nap; ++i) axis[i] = ORC_FREQ_INTERVAL * (i + 1.0);
+  for (int i = 0; i < nf; ++i) {
+    for (int j = 0; j < bins; ++j) la[j] = 20 * log10(ap[(size_t)i * bins + j]);
+    orc_interp1q(0, (double)fs / fft_size, la, bins, axis, nap, coded + (size_t)i * nap);
+  }
+  free(axis); free(la);
+}
+
+/* DecodeAperiodicity, codec.cpp:237-266 (+ CheckVUV :30-41, GetAperiodicity :46-54).
+ * Positional arguments of the DEFINITION: (coded, nf, fs, nap, fft_size, ap). */
+void orc_decode_aperiodicity(const double *coded, int nf, int fs, int nap, int fft_size, double *ap) {
+  const int bins = fft_size / 2 + 1;
+  double *faxis = (double *)malloc(sizeof(double) * (size_t)bins);
+  double *caxis = (double *)malloc(sizeof(double) * (size_t)(nap + 2));
+  double *cval = (double *)malloc(sizeof(double) * (size_t)(nap + 2));
+  for (int i = 0; i < bins; ++i) faxis[i] = (double)fs / fft_size * i;
+  for (int i = 0; i <= nap; ++i) caxis[i] = i * ORC_FREQ_INTERVAL;
+  caxis[nap + 1] = fs / 2.0;
+  cval[0] = -60.0;
+  cval[nap + 1] = -ORC_SAFE;
+  for (int i = 0; i < nf; ++i) {
+    double *row = ap + (size_t)i * bins;
+    for (int j = 0; j < bins; ++j) row[j] = 1.0 - ORC_SAFE;                      /* InitializeAperiodicity :20-25 */
+    double tmp = 0.0;
+    for (int k = 0; k < nap; ++k) {
+      tmp += coded[(size_t)i * nap + k];
+      cval[k + 1] = coded[(size_t)i * nap + k];
+    }
+    tmp /= nap;
+    if (tmp > -0.5) continue;                                                    /* CheckVUV == 1 */
+    orc_interp1(caxis, cval, nap + 2, faxis, bins, row);
+    for (int j = 0; j < bins; ++j) row[j] = pow(10.0, row[j] / 20.0);
+  }
+  free(faxis); free(caxis); free(cval);
+}
+
+/* CodeSpectralEnvelope, codec.cpp:268-295 (+ GetParametersForCoding :161-180, CodeOneFrame :122-133,
+ * DCTForCodec :73-88).  sp: [nf][fft_size/2+1], coded: [nf][ndim]. */
+void orc_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size, int ndim, double *coded) {
+  const int md = fft_size / 2, bins = fft_size / 2 + 1;
+  const double ceilf = fs / 2.0 < ORC_CEIL_FREQ ? fs / 2.0 : ORC_CEIL_FREQ;
+  const double floor_mel = to_mel(ORC_FLOOR_FREQ), ceil_mel = to_mel(ceilf);
+  double *mel_axis = (double *)malloc(sizeof(double) * (size_t)md);
+  double *faxis = (double *)malloc(sizeof(double) * (size_t)bins);
+  double *wr = (double *)malloc(sizeof(double) * (size_t)md), *wi = (double *)malloc(sizeof(double) * (size_t)md);
+  double *ls = (double *)malloc(sizeof(double) * (size_t)bins);
+  double *ms = (double *)malloc(sizeof(double) * (size_t)md);
+  double *wave = (double *)malloc(sizeof(double) * (size_t)md);
+  double *re = (double *)malloc(sizeof(double) * (size_t)(md / 2 + 1)), *im = (double *)malloc(sizeof(double) * (size_t)(md / 2 + 1));
+  for (int i = 0; i < md; ++i) {
+    mel_axis[i] = (ceil_mel - floor_mel) * i / md + floor_mel;
+    wr[i] = 2.0 * cos(i * ORC_PI_C / fft_size) / sqrt((double)fft_size);
+    wi[i] = 2.0 * sin(i * ORC_PI_C / fft_size) / sqrt((double)fft_size);
+  }
+  wr[0] /= sqrt(2.0);
+  for (int i = 0; i < md; ++i) faxis[i] = to_mel((double)i * fs / fft_size);
+  faxis[md] = to_mel((double)md * fs / fft_size);       /* never reached, see the header comment */
+  const double norm = sqrt((double)md);
+  for (int t = 0; t < nf; ++t) {
+    for (int j = 0; j < bins; ++j) ls[j] = log(sp[(size_t)t * bins + j]);
+    orc_interp1(faxis, ls, bins, mel_axis, md, ms);
+    const int bias = md / 2;
+    for (int i = 0; i < md / 2; ++i) {
+      wave[i] = ms[i * 2];
+      wave[i + bias] = ms[md - (i * 2) - 1];
+    }
+    orc_fft_r2c(wave, md, re, im);
+    for (int i = 0; i < ndim; ++i) coded[(size_t)t * ndim + i] = (re[i] * wr[i] - im[i] * wi[i]) / norm;
+  }
+  free(mel_axis); free(faxis); free(wr); free(wi); free(ls); free(ms); free(wave); free(re); free(im);
+}
+
+/* own radix-2 complex DFT (forward, e^{-j}); md is a power of two */
+static void dft_forward(double *re, double *im, int n) {
+  for (int i = 1, j = 0; i < n; ++i) {
+    int bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { double a = re[i]; re[i] = re[j]; re[j] = a; a = im[i]; im[i] = im[j]; im[j] = a; }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    const int half = len >> 1;
+    for (int base = 0; base < n; base += len)
+      for (int k = 0; k < half; ++k) {
+        const double ang = -2.0 * ORC_PI_C * k / len, c = cos(ang), s = sin(ang);
+        const int p = base + k, q = p + half;
+        const double xr = re[q] * c - im[q] * s, xi = re[q] * s + im[q] * c;
+        re[q] = re[p] - xr; im[q] = im[p] - xi;
+        re[p] += xr; im[p] += xi;
+      }
+  }
+}
+
+/* DecodeSpectralEnvelope, codec.cpp:297-324 (+ GetParametersForDecoding :185-208, DecodeOneFrame :138-157,
+ * IDCTForCodec :93-117).  coded: [nf][ndim], sp: [nf][fft_size/2+1]. */
+void orc_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size, int ndim, double *sp) {
+  const int md = fft_size / 2, bins = fft_size / 2 + 1;
+  const double ceilf = fs / 2.0 < ORC_CEIL_FREQ ? fs / 2.0 : ORC_CEIL_FREQ;
+  const double floor_mel = to_mel(ORC_FLOOR_FREQ), ceil_mel = to_mel(ceilf);
+  double *mel_axis = (double *)malloc(sizeof(double) * (size_t)(md + 2));
+  double *faxis = (double *)malloc(sizeof(double) * (size_t)bins);
+  double *wr = (double *)malloc(sizeof(double) * (size_t)md), *wi = (double *)malloc(sizeof(double) * (size_t)md);
+  double *ms = (double *)malloc(sizeof(double) * (size_t)(md + 2));
+  double *re = (double *)malloc(sizeof(double) * (size_t)md), *im = (double *)malloc(sizeof(double) * (size_t)md);
+  for (int i = 0; i < ndim; ++i) {
+    wr[i] = cos(i * ORC_PI_C / fft_size) * sqrt((double)fft_size);
+    wi[i] = sin(i * ORC_PI_C / fft_size) * sqrt((double)fft_size);
+  }
+  wr[0] /= sqrt(2.0);
+  for (int i = 0; i < md; ++i) mel_axis[i + 1] = from_mel((ceil_mel - floor_mel) * i / md + floor_mel);
+  mel_axis[0] = 0;
+  mel_axis[md + 1] = fs / 2.0;
+  for (int i = 0; i < bins; ++i) faxis[i] = (double)i * fs / fft_size;
+  const double norm = sqrt((double)md);
+  for (int t = 0; t < nf; ++t) {
+    for (int i = 0; i < ndim; ++i) {
+      re[i] = coded[(size_t)t * ndim + i] * wr[i] * norm;
+      im[i] = -coded[(size_t)t * ndim + i] * wi[i] * norm;
+    }
+    for (int i = ndim; i < md; ++i) { re[i] = 0.0; im[i] = 0.0; }
+    dft_forward(re, im, md);                       /* real part == the wrapper's conj(...) real part */
+    for (int i = 0; i < md / 2; ++i) {
+      ms[1 + i * 2] = re[i];
+      ms[1 + i * 2 + 1] = re[md - i - 1];
+    }
+    ms[0] = ms[1];
+    ms[md + 1] = ms[md];
+    double *row = sp + (size_t)t * bins;
+    orc_interp1(mel_axis, ms, md + 2, faxis, bins, row);
+    for (int i = 0; i < bins; ++i) row[i] = exp(row[i] / md);
+  }
+  free(mel_axis); free(faxis); free(wr); free(wi); free(ms); free(re); free(im);
+}

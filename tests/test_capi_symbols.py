@@ -28,6 +28,8 @@ def test_headers_declare_the_world_api():
     for want in ("Dio", "InitializeDioOption", "GetSamplesForDIO", "Harvest", "InitializeHarvestOption",
                  "GetSamplesForHarvest", "StoneMask", "CheapTrick", "InitializeCheapTrickOption",
                  "GetFFTSizeForCheapTrick", "GetF0FloorForCheapTrick", "D4C", "InitializeD4COption", "Synthesis",
+                 "GetNumberOfAperiodicities", "CodeAperiodicity", "DecodeAperiodicity", "CodeSpectralEnvelope",
+                 "DecodeSpectralEnvelope", "WorldMi355CodeSpectralEnvelope", "WorldMi355RecipeFeatures",
                  "WorldMi355Analyze", "WorldMi355Synthesis", "WorldMi355CreateBatch"):
         assert want in names, want
 
@@ -70,6 +72,7 @@ def test_option_initialisers_and_size_helpers(pkg):
     assert o.threshold == 0.85
     assert L.GetSamplesForDIO(16000, 53680, 5.0) == 672
     assert L.GetSamplesForHarvest(48000, 192000, 1.0) == 4001
+    assert [L.GetNumberOfAperiodicities(fs) for fs in (16000, 22050, 44100, 48000)] == [1, 2, 5, 5]   # codec.cpp:212-215
 
 
 def test_no_cpu_fallback_without_device(pkg):

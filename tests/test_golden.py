@@ -57,3 +57,44 @@ def test_harvest_vs_reference_vectors(oracle, name):
     np.testing.assert_array_equal(t, g["t"])
     assert ((f0 > 0) == (g["f0"] > 0)).all()
     np.testing.assert_allclose(f0, g["f0"], atol=1e-8, rtol=0)
+
+
+def recipe_pack(o, f0, sp, ap, fs, F, spec_dim, ap_dim=25):
+    """test/analysis.cpp:292-366 around the coder (scaling, offsets, log f0, float32)."""
+    sp4 = sp * 1e4
+    sp4[sp4 == 0.0] = 0.0001
+    mgc = o.code_spectral_envelope(sp4, fs, F, spec_dim)
+    mgc[:, 0] += 12.0
+    bap = o.code_spectral_envelope(ap * 1e4, fs, F, ap_dim)
+    bap[:, 0] -= 9.210340
+    bap[(bap[:, 0] > 0) & (bap[:, 0] < 1e-4), 0] = 0
+    lf0 = np.where(f0 != 0, np.log(np.where(f0 != 0, f0, 1.0)), 0.0)
+    return lf0.astype(np.float32), mgc.astype(np.float32), bap.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["codec_16k", "codec_48k"])
+def test_codec_vs_reference_vectors(oracle, name):
+    """world/codec.h: the fixtures hold the reference's coded / decoded features of its own
+    analysis; sp/ap are rebuilt with the oracle (pinned above to 1e-9 of the reference's) from the stored f0."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fs, fp, F, nd = int(g["fs"]), float(g["frame_period"]), int(g["fft_size"]), int(g["spec_dim"])
+    x = sd.make_utterance(int(g["index"]), fs, duration=float(g["duration"]))
+    t = np.arange(len(g["f0"])) * fp / 1000.0
+    sp = oracle.cheaptrick(x, fs, t, g["f0"], -0.15, F)
+    ap = oracle.d4c(x, fs, t, g["f0"], F, 0.0)
+    np.testing.assert_allclose(checks(sp), g["sp_check"], rtol=1e-9)
+    np.testing.assert_allclose(checks(ap), g["ap_check"], rtol=1e-9)
+    assert oracle.num_aperiodicities(fs) == g["coded_ap"].shape[1]
+    csp = oracle.code_spectral_envelope(sp, fs, F, nd)
+    np.testing.assert_allclose(csp, g["coded_sp"], atol=1e-9, rtol=0)
+    cap = oracle.code_aperiodicity(ap, fs, F)
+    np.testing.assert_allclose(cap, g["coded_ap"], atol=1e-7, rtol=0)
+    dsp = oracle.decode_spectral_envelope(g["coded_sp"], fs, F)
+    np.testing.assert_allclose(dsp[::8], g["decoded_sp_sub"], rtol=1e-10)
+    np.testing.assert_allclose(checks(dsp), g["decoded_sp_check"], rtol=1e-10)
+    dap = oracle.decode_aperiodicity(g["coded_ap"], fs, F)
+    np.testing.assert_allclose(dap[::8], g["decoded_ap_sub"], atol=1e-12, rtol=0)
+    lf0, mgc, bap = recipe_pack(oracle, g["f0"], sp, ap, fs, F, nd)
+    np.testing.assert_array_equal(lf0, g["lf0"])
+    np.testing.assert_allclose(mgc, g["mgc"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(bap, g["bap"], atol=2e-6, rtol=0)

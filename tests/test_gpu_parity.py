@@ -310,3 +310,64 @@ def test_fir_tile_edges(gpu, oracle):
         y = bb.synthesize(dev(r["f0"]), dev(r["sp"]), dev(r["ap"]))
         np.testing.assert_allclose(y.cpu().numpy(), yo, atol=Y_TOL, rtol=0)
         bb.close()
+
+
+@pytest.mark.parametrize("fs,nd", [(16000, 50), (48000, 60)])
+def test_codec_against_oracle(gpu, pkg, oracle, fs, nd):
+    """world/codec.h on the device: batched API, the C ABI, the recipe packing."""
+    torch, W, ctx = gpu
+    xs = [sd.make_utterance(i, fs, duration=d) for i, d in ((21, 0.7), (22, 1.1))]
+    rs = [oracle_chain(oracle, x, fs) for x in xs]
+    F = rs[0]["F"]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    sp, ap, f0 = cat(rs, "sp"), cat(rs, "ap"), cat(rs, "f0")
+    csp = b.code_spectral_envelope(dev(sp), nd).cpu().numpy()
+    ref_csp = oracle.code_spectral_envelope(sp, fs, F, nd)
+    np.testing.assert_allclose(csp, ref_csp, atol=1e-11, rtol=0)
+    dsp = b.decode_spectral_envelope(dev(ref_csp)).cpu().numpy()
+    np.testing.assert_allclose(dsp, oracle.decode_spectral_envelope(ref_csp, fs, F), rtol=1e-10)
+    cap = b.code_aperiodicity(dev(ap)).cpu().numpy()
+    ref_cap = oracle.code_aperiodicity(ap, fs, F)
+    np.testing.assert_allclose(cap, ref_cap, atol=1e-10, rtol=0)
+    mix = ref_cap.copy()
+    mix[::3] = -0.1                                             # CheckVUV keeps the default row
+    dap = b.decode_aperiodicity(dev(mix)).cpu().numpy()
+    np.testing.assert_allclose(dap, oracle.decode_aperiodicity(mix, fs, F), atol=1e-12, rtol=0)
+    # recipe packing (float32): lf0 / mgc / bap
+    from test_golden import recipe_pack
+    lf0, mgc, bap = b.recipe_features(dev(f0), dev(sp), dev(ap), nd, 25)
+    rl, rm, rb = recipe_pack(oracle, f0, sp, ap, fs, F, nd)
+    np.testing.assert_allclose(lf0.cpu().numpy(), rl, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(mgc.cpu().numpy(), rm, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(bap.cpu().numpy(), rb, atol=2e-6, rtol=0)
+    b.close()
+    # C ABI, one utterance, host pointers
+    C = pkg.capi
+    assert C.get_number_of_aperiodicities(fs) == oracle.num_aperiodicities(fs)
+    r = rs[0]
+    np.testing.assert_allclose(C.code_spectral_envelope(r["sp"], fs, F, nd),
+                               oracle.code_spectral_envelope(r["sp"], fs, F, nd), atol=1e-11, rtol=0)
+    c1 = oracle.code_spectral_envelope(r["sp"], fs, F, nd)
+    np.testing.assert_allclose(C.decode_spectral_envelope(c1, fs, F), oracle.decode_spectral_envelope(c1, fs, F), rtol=1e-10)
+    a1 = oracle.code_aperiodicity(r["ap"], fs, F)
+    np.testing.assert_allclose(C.code_aperiodicity(r["ap"], fs, F), a1, atol=1e-10, rtol=0)
+    np.testing.assert_allclose(C.decode_aperiodicity(a1, fs, F), oracle.decode_aperiodicity(a1, fs, F), atol=1e-12, rtol=0)
+
+
+def test_codec_golden_on_gpu(gpu, oracle):
+    """The reference's own coded features (tests/golden/codec_16k.npz) from the device path end to end."""
+    torch, W, ctx = gpu
+    g = np.load(os.path.join(GOLDEN, "codec_16k.npz"))
+    fs, F, nd = int(g["fs"]), int(g["fft_size"]), int(g["spec_dim"])
+    x = sd.make_utterance(int(g["index"]), fs, duration=float(g["duration"]))
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    t, f0, sp, ap = b.analyze(torch.from_numpy(x).cuda())
+    np.testing.assert_allclose(f0.cpu().numpy(), g["f0"], atol=F0_TOL, rtol=0)
+    np.testing.assert_allclose(b.code_spectral_envelope(sp, nd).cpu().numpy(), g["coded_sp"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(b.code_aperiodicity(ap).cpu().numpy(), g["coded_ap"], atol=1e-6, rtol=0)
+    lf0, mgc, bap = b.recipe_features(f0, sp, ap, nd, 25)
+    np.testing.assert_allclose(lf0.cpu().numpy(), g["lf0"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(mgc.cpu().numpy(), g["mgc"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(bap.cpu().numpy(), g["bap"], atol=1e-5, rtol=0)
+    b.close()

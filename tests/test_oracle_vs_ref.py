@@ -80,3 +80,22 @@ def test_harvest_options(oracle, reference):
     tr, fr = reference.harvest(x, 16000, 5.0, 50.0, 500.0)
     to, fo = oracle.harvest(x, 16000, 5.0, 50.0, 500.0)
     np.testing.assert_allclose(fo, fr, atol=1e-8, rtol=0)
+
+
+@pytest.mark.parametrize("fs,F,nd", [(16000, 1024, 50), (22050, 1024, 40), (48000, 2048, 60)])
+def test_codec(oracle, reference, fs, F, nd):
+    """world/codec.h, full arrays on seeded positive spectra (codec.cpp:212-324)."""
+    rng = np.random.default_rng(fs + nd)
+    sp = np.exp(rng.normal(size=(7, F // 2 + 1)) * 2 - 8)
+    ap = np.clip(rng.random((7, F // 2 + 1)), 1e-6, 1 - 1e-12)
+    assert oracle.num_aperiodicities(fs) == reference.num_aperiodicities(fs)
+    co, cr = oracle.code_spectral_envelope(sp, fs, F, nd), reference.code_spectral_envelope(sp, fs, F, nd)
+    np.testing.assert_allclose(co, cr, atol=1e-13, rtol=0)
+    np.testing.assert_allclose(oracle.decode_spectral_envelope(cr, fs, F), reference.decode_spectral_envelope(cr, fs, F),
+                               rtol=1e-12)
+    ao, ar = oracle.code_aperiodicity(ap, fs, F), reference.code_aperiodicity(ap, fs, F)
+    np.testing.assert_allclose(ao, ar, atol=1e-12, rtol=0)
+    ar2 = ar.copy()
+    ar2[::2] = -0.1                                             # CheckVUV: mean > -0.5 keeps the default row
+    np.testing.assert_allclose(oracle.decode_aperiodicity(ar2, fs, F), reference.decode_aperiodicity(ar2, fs, F),
+                               atol=1e-13, rtol=0)
