@@ -56,9 +56,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=48, help="utterances of the CPU baseline sample")
     ap.add_argument("--workers", type=int, default=0, help="processes for synthetic data generation (0 = auto)")
-    ap.add_argument("--workload", choices=["analysis_synthesis", "harvest", "synthesis"], default="analysis_synthesis",
+    ap.add_argument("--workload", choices=["analysis_synthesis", "harvest", "synthesis", "codec"], default="analysis_synthesis",
                     help="analysis_synthesis = configs[1] (the headline metric); harvest = configs[2] (48 kHz, 1 ms, "
-                         "64 utterances); synthesis = configs[4] (Synthesis only from precomputed features)")
+                         "64 utterances); synthesis = configs[4] (Synthesis only from precomputed features); codec = the recipe's "
+                         "coded lf0/mgc/bap from resident features plus the decoders (SURVEY.md 8(f))")
     return ap.parse_args()
 
 
@@ -194,6 +195,9 @@ def side_workload(args, torch, dist, W, sd, rank, world):
     if args.workload == "harvest":
         fs, fp = 48000, 1.0
         utts = args.utts if args.utts != 256 else 64
+    elif args.workload == "codec":
+        fs, fp = 16000, 5.0
+        utts = args.utts
     else:
         fs, fp = 16000, 5.0
         utts = args.utts if args.utts != 256 else 1024
@@ -205,6 +209,17 @@ def side_workload(args, torch, dist, W, sd, rank, world):
     if args.workload == "harvest":
         names = ("hv_decimate", "hv_band_kernel", "hv_raw_kernel", "hv_refine_kernel", "hv_contour_kernel")
         step = lambda: batch.harvest(x)
+    elif args.workload == "codec":
+        # the recipe's coded features from resident sp/ap, and the decoders back
+        t, f0, sp, ap = batch.analyze(x)
+        names = ("codec_code_sp_kernel", "codec_decode_sp_kernel", "codec_code_ap_kernel", "codec_decode_ap_kernel")
+
+        def step():
+            lf0, mgc, bap = batch.recipe_features(f0, sp, ap, 50, 25)
+            csp = batch.code_spectral_envelope(sp, 50)
+            cap = batch.code_aperiodicity(ap)
+            batch.decode_spectral_envelope(csp)
+            batch.decode_aperiodicity(cap)
     else:
         t, f0, sp, ap = batch.analyze(x)
         y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
@@ -237,13 +252,17 @@ def side_workload(args, torch, dist, W, sd, rank, world):
     if rank == 0:
         value = total * args.steps / elapsed
         bpf = 400 if args.workload == "harvest" else 8856
-        line = {"metric": "WORLD %s frames/sec" % ("Harvest @48kHz, 1ms hop" if args.workload == "harvest"
-                                                    else "Synthesis-only @16kHz, 5ms hop"),
+        if args.workload == "codec":
+            # per frame: recipe packing reads sp+ap (2 x 4104 B), coders read them again, decoders write them
+            bpf = 4 * 4104 + 2 * 4104
+        mname = {"harvest": "Harvest @48kHz, 1ms hop", "codec": "feature codec (recipe packing + code + decode) @16kHz",
+                 "synthesis": "Synthesis-only @16kHz, 5ms hop"}[args.workload]
+        line = {"metric": "WORLD %s frames/sec" % mname,
                 "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "configs[%d]: %d synthetic utterances (%g-%g s) per GPU, fs %d, hop %g ms"
-                                       % (2 if args.workload == "harvest" else 4, utts, args.dur[0], args.dur[1], fs, fp),
+                                       % ({"harvest": 2, "codec": 1}.get(args.workload, 4), utts, args.dur[0], args.dur[1], fs, fp),
                            "frames_per_gpu": frames},
                 "roofline": {"bound": "hbm", "achieved": round(value / world * bpf / 1e9, 3), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(value / world * bpf / 1e9 / HBM_PEAK_GBS, 7),
@@ -265,6 +284,28 @@ def side_workload(args, torch, dist, W, sd, rank, world):
             line["cpu_baseline"] = {"value": round(nfr / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
                                     "sample": "first utterances of the same batch (%d frames), %.1f s" % (nfr, tcpu)}
             line["parity"] = {"vs": lib.kind, "max_abs_dF0_hz": df0}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "codec":
+            from oracle.bindings import Oracle, Reference
+            lib = Reference() if Reference.available() else Oracle()
+            F = batch.fft_size
+            fo = batch.frame_offsets
+            n_u = min(len(xs), 24)
+            sp_h, ap_h = sp[:fo[n_u]].cpu().numpy(), ap[:fo[n_u]].cpu().numpy()
+            got = batch.code_spectral_envelope(sp, 50)[:fo[n_u]].cpu().numpy()
+            a = time.perf_counter()
+            sp4 = sp_h * 1e4
+            sp4[sp4 == 0.0] = 0.0001
+            lib.code_spectral_envelope(sp4, fs, F, 50)
+            lib.code_spectral_envelope(ap_h * 1e4, fs, F, 25)
+            csp = lib.code_spectral_envelope(sp_h, fs, F, 50)
+            cap = lib.code_aperiodicity(ap_h, fs, F)
+            lib.decode_spectral_envelope(csp, fs, F)
+            lib.decode_aperiodicity(cap, fs, F)
+            tcpu = time.perf_counter() - a
+            line["cpu_baseline"] = {"value": round(fo[n_u] / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
+                                    "sample": "the same step on the first %d utterances (%d frames), %.1f s"
+                                              % (n_u, fo[n_u], tcpu)}
+            line["parity"] = {"vs": lib.kind, "max_abs_d_coded_sp": float(np.abs(got - csp).max())}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

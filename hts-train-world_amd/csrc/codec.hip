@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void codec_decode_ap_kernel(const double* __re
   const double y0 = k - 1 == 0 ? -60.0 : c[k - 2];
   const double y1 = k == nap + 1 ? -kSafe : c[k - 1];
   const double s = (f - x0) / (x1 - x0);
-  ap[idx] = pow(10.0, (y0 + s * (y1 - y0)) / 20.0);
+  ap[idx] = exp((y0 + s * (y1 - y0)) * (2.302585092994045684 / 20.0));   // 10^(x/20), codec.cpp:52-53
 }
 
 // lf0 = log f0, 0 where unvoiced (analysis.cpp:216-224), as float32
