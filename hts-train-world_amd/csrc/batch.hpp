@@ -140,6 +140,8 @@ int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double
 int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);
 int launch_code_aperiodicity(Batch& b, const double* d_ap, double* d_coded);
 int launch_decode_aperiodicity(Batch& b, const double* d_coded, double* d_ap);
+int launch_compose_cmp(Batch& b, int n_streams, const float* const* d_data, const int* dims, const int* n_windows,
+                       const double* const* const* windows, const int* const* window_sizes, float* d_out);
 int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, int spec_dim,
                            int ap_dim, float* d_lf0, float* d_mgc, float* d_bap);
 

@@ -223,6 +223,20 @@ int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double*
                              int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap) {
   return launch_recipe_features(b->b, f0, sp, ap, spec_dim, ap_dim, lf0, mgc, bap);
 }
+int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* streams, const int* dims,
+                         const int* n_windows, const double* const* const* windows,
+                         const int* const* window_sizes, float* out) {
+  return launch_compose_cmp(b->b, n_streams, streams, dims, n_windows, windows, window_sizes, out);
+}
+void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_samples, int bytes_per_frame,
+                         int htk_type, unsigned char out12[12]) {              // addhtkheader.pl:60-75
+  const int32_t a = n_frames, fs100 = (int32_t)(10000000.0 * frame_shift_samples / sampling_rate);
+  const int16_t c = (int16_t)bytes_per_frame, d = (int16_t)htk_type;
+  memcpy(out12, &a, 4);
+  memcpy(out12 + 4, &fs100, 4);
+  memcpy(out12 + 8, &c, 2);
+  memcpy(out12 + 10, &d, 2);
+}
 int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0) {
   return wm::launch_harvest(b->b, x, t, f0);
 }

@@ -17,6 +17,7 @@
 // FFT of fft_size/2 points of which only the real parts are used (fft.cpp's c2c "backward" returns the
 // conjugate of the forward transform of its input).
 #include <math.h>
+#include <string.h>
 
 #include <vector>
 
@@ -382,6 +383,91 @@ int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, con
   if (b.total_f > 0)
     hipLaunchKernelGGL(codec_lf0_kernel, dim3((unsigned)((b.total_f + 255) / 256)), dim3(256), 0, b.ctx->stream, d_f0,
                        b.total_f, d_lf0);
+  return wm_check(hipGetLastError());
+}
+
+}  // namespace wm
+
+// ---- dynamic-feature windows and `cmp` composition -------------------------
+// Replaces data/scripts/window.pl:45-146 for every stream and the SPTK `merge` chain of
+// data/Makefile.in:296-299 in one pass: out[frame] = [stream 0: win 1 | win 2 | ... ][stream 1: ...]...
+// Frames outside an utterance are clamped to its first / last frame; a frame whose checked taps touch
+// the ignore value -1e10 (unvoiced lf0) yields -1e10.  Accumulation in double, in tap order, no FMA
+// contraction: the float32 results are bit-identical to the script's.
+namespace wm {
+
+constexpr int kCmpMaxStreams = 4, kCmpMaxWin = 4, kCmpMaxTaps = 15;
+struct CmpMeta {
+  int n_streams, total_cols;
+  int dim[kCmpMaxStreams], nwin[kCmpMaxStreams], col0[kCmpMaxStreams];
+  int wsize[kCmpMaxStreams][kCmpMaxWin];
+  unsigned chk[kCmpMaxStreams][kCmpMaxWin];                 // bit k: tap k takes part in the boundary check
+  double w[kCmpMaxStreams][kCmpMaxWin][kCmpMaxTaps];
+  const float* data[kCmpMaxStreams];
+};
+
+__global__ __launch_bounds__(256) void cmp_compose_kernel(CmpMeta m, const int* __restrict__ frame_utt,
+                                                          const int64_t* __restrict__ f_off, int64_t total_frames,
+                                                          float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_frames * m.total_cols) return;
+  const int64_t frame = idx / m.total_cols;
+  const int col = (int)(idx - frame * m.total_cols);
+  int s = 0;
+#pragma unroll
+  for (int q = 1; q < kCmpMaxStreams; ++q)
+    if (q < m.n_streams && col >= m.col0[q]) s = q;
+  const int dim = m.dim[s];
+  const int c = col - m.col0[s];
+  const int wi = c / dim, j = c - wi * dim;
+  const int size = m.wsize[s][wi], nlr = (size - 1) / 2;
+  const int u = frame_utt[frame];
+  const int64_t lo = f_off[u], hi = f_off[u + 1] - 1;
+  const float* src = m.data[s];
+  bool boundary = false;
+  double acc = 0.0;
+  for (int k = 0; k < size; ++k) {
+    int64_t l = frame + (k - nlr);
+    l = l < lo ? lo : (l > hi ? hi : l);
+    const double v = (double)src[l * dim + j];
+    if (((m.chk[s][wi] >> k) & 1u) && v == -1.0e+10) boundary = true;
+    acc += m.w[s][wi][k] * v;
+  }
+  out[idx] = boundary ? -1.0e+10f : (float)acc;
+}
+
+int launch_compose_cmp(Batch& b, int n_streams, const float* const* d_data, const int* dims, const int* n_windows,
+                       const double* const* const* windows, const int* const* window_sizes, float* d_out) {
+  if (n_streams < 1 || n_streams > kCmpMaxStreams) return WM_ERR_BAD_ARG;
+  CmpMeta m;
+  memset(&m, 0, sizeof(m));
+  m.n_streams = n_streams;
+  int col = 0;
+  for (int s = 0; s < n_streams; ++s) {
+    if (dims[s] < 1 || n_windows[s] < 1 || n_windows[s] > kCmpMaxWin) return WM_ERR_BAD_ARG;
+    m.dim[s] = dims[s];
+    m.nwin[s] = n_windows[s];
+    m.col0[s] = col;
+    m.data[s] = d_data[s];
+    for (int i = 0; i < n_windows[s]; ++i) {
+      const int size = window_sizes[s][i];
+      if (size < 1 || size > kCmpMaxTaps || size % 2 != 1) return WM_ERR_BAD_ARG;   // window.pl:96-98
+      m.wsize[s][i] = size;
+      unsigned chk = (1u << size) - 1u;                           // window.pl:83-94: leading / trailing zero taps
+      for (int k = 0; k < size; ++k) { if (windows[s][i][k] != 0.0) break; chk &= ~(1u << k); }
+      for (int k = size - 1; k >= 0; --k) { if (windows[s][i][k] != 0.0) break; chk &= ~(1u << k); }
+      m.chk[s][i] = chk;
+      for (int k = 0; k < size; ++k) m.w[s][i][k] = windows[s][i][k];
+    }
+    col += dims[s] * n_windows[s];
+  }
+  m.total_cols = col;
+  const int64_t n = b.total_f * col;
+  if (n <= 0) return WM_OK;
+  TimedScope ts_(b.ctx, "cmp_compose_kernel");
+  hipLaunchKernelGGL(cmp_compose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b.ctx->stream, m,
+                     b.d_frame_utt, b.d_f_off, b.total_f, d_out);
   return wm_check(hipGetLastError());
 }
 

@@ -79,6 +79,9 @@ def load_library():
     L.WorldMi355CodeAperiodicity.argtypes = [vp, vp, vp]
     L.WorldMi355DecodeAperiodicity.argtypes = [vp, vp, vp]
     L.WorldMi355RecipeFeatures.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.WorldMi355ComposeCmp.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.WorldMi355HtkHeader.restype = None
+    L.WorldMi355HtkHeader.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.WorldMi355TestRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.WorldMi355TimingEnable.argtypes = [vp, C.c_int]
     L.WorldMi355TimingQuery.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -258,6 +261,30 @@ class WorldBatch:
                                                        C.c_void_p(bap.data_ptr())), "RecipeFeatures")
         return lf0, mgc, bap
 
+    def compose_cmp(self, streams):
+        """streams: list of (float32 cuda tensor [total_frames][dim], list of window coefficient lists).
+        Returns float32 [total_frames][sum n_windows * dim] (window.pl + merge of the recipe's cmp stage)."""
+        import torch
+        n = len(streams)
+        dp = C.POINTER(C.c_double)
+        data = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t, _ in streams])
+        dims = (C.c_int * n)(*[int(t.shape[1]) for t, _ in streams])
+        nwin = (C.c_int * n)(*[len(w) for _, w in streams])
+        keep, wptrs, sptrs = [], (C.POINTER(dp) * n)(), (C.POINTER(C.c_int) * n)()
+        for s, (t, wins) in enumerate(streams):
+            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32" and t.shape[0] == self.total_frames
+            arrs = [(C.c_double * len(w))(*w) for w in wins]
+            pa = (dp * len(wins))(*[C.cast(a, dp) for a in arrs])
+            sz = (C.c_int * len(wins))(*[len(w) for w in wins])
+            keep += [arrs, pa, sz]
+            wptrs[s] = C.cast(pa, C.POINTER(dp))
+            sptrs[s] = C.cast(sz, C.POINTER(C.c_int))
+        cols = sum(int(t.shape[1]) * len(w) for t, w in streams)
+        out = torch.empty(self.total_frames, cols, dtype=torch.float32, device="cuda")
+        _check(load_library().WorldMi355ComposeCmp(self.handle, n, data, dims, nwin, wptrs, sptrs,
+                                                   C.c_void_p(out.data_ptr())), "ComposeCmp")
+        return out
+
     def split_frames(self, a):
         return [a[self.frame_offsets[u]:self.frame_offsets[u + 1]] for u in range(self.n_utt)]
 
@@ -282,3 +309,11 @@ def test_rfft(ctx: Context, x):
                                              C.c_void_p(xb.data_ptr())), "TestRfft")
     ctx.synchronize()
     return re, im, xb
+
+
+def htk_header(n_frames, sampling_rate, frame_shift_samples, bytes_per_frame, htk_type=9):
+    """12-byte HTK header of the recipe's cmp files (addhtkheader.pl:60-75)."""
+    buf = (C.c_ubyte * 12)()
+    load_library().WorldMi355HtkHeader(int(n_frames), int(sampling_rate), int(frame_shift_samples), int(bytes_per_frame),
+                                       int(htk_type), buf)
+    return bytes(buf)

@@ -119,6 +119,20 @@ int WorldMi355DecodeAperiodicity(WorldMi355Batch* b, const double* coded, double
 int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
                              int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap);
 
+/* ---- `cmp` composition (data/scripts/window.pl:45-146, addhtkheader.pl:45-82), SURVEY.md section 8(f) rank 3 ----
+ * Applies each stream's dynamic-feature windows and lays the results side by side per frame:
+ *   out[frame] = [stream 0: window 0 (dim) | window 1 | ...][stream 1: ...]...      (float32)
+ * streams[s]: device pointer, float32 [total_frames][dims[s]].  windows[s][i]: HOST pointer to the
+ * window_sizes[s][i] coefficients of window i of stream s (the content of data/win/*.win<i> without the
+ * leading size).  Frames are clamped per utterance; -1e10 is the ignore value of unvoiced lf0.
+ * Limits: 4 streams, 4 windows per stream, odd window sizes up to 15. */
+int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* streams, const int* dims,
+                         const int* n_windows, const double* const* const* windows,
+                         const int* const* window_sizes, float* out);
+/* The 12-byte HTK header of addhtkheader.pl:60-75 (host only, native byte order). */
+void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_samples, int bytes_per_frame,
+                         int htk_type, unsigned char out12[12]);
+
 
 /* Per-kernel timing with HIP events recorded on the context's stream around each launch of the
  * named kernels ("dio_lowcut_kernel", "dio_band_kernel", "stonemask_kernel", "cheaptrick_kernel",

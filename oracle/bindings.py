@@ -151,6 +151,22 @@ class Oracle:
                                y_length, _p(y))
         return y
 
+    # -- cmp composition (window.pl, addhtkheader.pl) --------------------------
+    def window_stream(self, data, windows):
+        """data: float32 [T][dim]; windows: list of coefficient lists (the window files without the size)."""
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        T, dim = d.shape
+        ws = [np.array([len(w)] + list(w), dtype=np.float64) for w in windows]
+        arr = (_dp * len(ws))(*[w.ctypes.data_as(_dp) for w in ws])
+        out = np.zeros((T, len(ws) * dim), dtype=np.float32)
+        self.lib.orc_window_stream(d.ctypes.data_as(C.c_void_p), T, dim, len(ws), arr, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def htk_header(self, nframes, samprate, frameshift, bytes_per_frame, kind=9):
+        buf = (C.c_ubyte * 12)()
+        self.lib.orc_htk_header(int(nframes), int(samprate), int(frameshift), int(bytes_per_frame), int(kind), buf)
+        return bytes(buf)
+
     # -- primitives ----------------------------------------------------------
     def randn_table(self, n):
         out = np.zeros(n)

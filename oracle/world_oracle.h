@@ -90,6 +90,12 @@ void orc_code_spectral_envelope(const double *sp, int nf, int fs, int fft_size, 
 void orc_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_size, int ndim,
                                   double *sp);                             /* codec.cpp:297-324 */
 
+/* ---- cmp composition (data/scripts/window.pl, addhtkheader.pl), world_oracle_codec.c ---- */
+void orc_window_stream(const float *in, int T, int dim, int nwin, const double *const *win,
+                       float *out);                                        /* window.pl:45-146 */
+void orc_htk_header(int nframes, int samprate, int frameshift, int bytes_per_frame, int type,
+                    unsigned char *out12);                                 /* addhtkheader.pl:45-82 */
+
 #ifdef __cplusplus
 }
 #endif

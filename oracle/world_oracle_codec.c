@@ -14,6 +14,7 @@
  *    same types, so the ABI is the definition's POSITIONAL meaning, which is what is restated.
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "world_oracle.h"
@@ -172,4 +173,55 @@ void orc_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_s
     for (int i = 0; i < bins; ++i) row[i] = exp(row[i] / md);
   }
   free(mel_axis); free(faxis); free(wr); free(wi); free(ms); free(re); free(im);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* delta windows and HTK packing of the recipe's `cmp` stage.                 */
+/* Restates data/scripts/window.pl:45-146 (dynamic-feature windows with edge clamping and the         */
+/* -1e10 "ignore" value) and data/scripts/addhtkheader.pl:45-82 (12-byte header, native endian).     */
+/* ------------------------------------------------------------------------------------------------ */
+#define ORC_IGNORE (-1.0e+10)
+
+/* one stream of one utterance: in[T][dim] float32 -> out[T][nwin*dim] float32 (window i occupies
+ * columns (i-1)*dim .. i*dim-1).  win[i] is the window file's content: size, then `size` coefficients. */
+void orc_window_stream(const float *in, int T, int dim, int nwin, const double *const *win, float *out) {
+  for (int i = 1; i <= nwin; ++i) {
+    const double *w = win[i - 1];
+    const int size = (int)w[0];
+    const int nlr = (size - 1) / 2;
+    int chk[64];
+    for (int j = 0; j <= size && j < 64; ++j) chk[j] = 1;            /* window.pl:83-94 */
+    for (int j = 1; j <= size; ++j) { if (w[j] != 0.0) break; chk[j] = 0; }
+    for (int j = size; j >= 1; --j) { if (w[j] != 0.0) break; chk[j] = 0; }
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < dim; ++j) {
+        int boundary = 0;                                            /* :106-123 */
+        for (int k = -nlr; k <= nlr; ++k)
+          if (chk[k + nlr + 1] == 1) {
+            int l = t + k < 0 ? 0 : (t + k >= T ? T - 1 : t + k);
+            if ((double)in[(size_t)l * dim + j] == ORC_IGNORE) boundary = 1;
+          }
+        double acc = ORC_IGNORE;
+        if (!boundary) {                                             /* :124-137 */
+          acc = 0.0;
+          for (int k = -nlr; k <= nlr; ++k) {
+            int l = t + k < 0 ? 0 : (t + k >= T ? T - 1 : t + k);
+            acc += w[k + nlr + 1] * (double)in[(size_t)l * dim + j];
+          }
+        }
+        out[(size_t)t * nwin * dim + (size_t)dim * (i - 1) + j] = (float)acc;
+      }
+  }
+}
+
+/* addhtkheader.pl:60-75: int32 nframes, int32 frame shift in 100 ns units (integer part of
+ * 1e7 * frameshift / samprate), int16 bytes per frame, int16 type; native byte order */
+void orc_htk_header(int nframes, int samprate, int frameshift, int bytes_per_frame, int type, unsigned char *out12) {
+  int32_t a = nframes, b = (int32_t)(10000000.0 * frameshift / samprate);
+  int16_t c = (int16_t)bytes_per_frame, d = (int16_t)type;
+  unsigned char *p = out12;
+  for (int i = 0; i < 4; ++i) p[i] = ((unsigned char *)&a)[i];
+  for (int i = 0; i < 4; ++i) p[4 + i] = ((unsigned char *)&b)[i];
+  for (int i = 0; i < 2; ++i) p[8 + i] = ((unsigned char *)&c)[i];
+  for (int i = 0; i < 2; ++i) p[10 + i] = ((unsigned char *)&d)[i];
 }

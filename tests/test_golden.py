@@ -98,3 +98,30 @@ def test_codec_vs_reference_vectors(oracle, name):
     np.testing.assert_array_equal(lf0, g["lf0"])
     np.testing.assert_allclose(mgc, g["mgc"], atol=2e-6, rtol=0)
     np.testing.assert_allclose(bap, g["bap"], atol=2e-6, rtol=0)
+
+
+CMP_WINDOWS = [[1.0], [-0.5, 0.0, 0.5], [1.0, -2.0, 1.0]]          # data/win/*.win1..3
+
+
+def cmp_stream(seed, T, dim, holes):
+    """The generator of oracle/gen_golden_cmp.py (inputs are seeds, outputs are the Perl scripts')."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((T, dim)).astype(np.float32)
+    if holes:
+        a[:3] = -1.0e10
+        a[10:17] = -1.0e10
+        a[T - 2:] = -1.0e10
+        a[25, :] = -1.0e10
+    return a
+
+
+def test_cmp_windows_vs_reference_scripts(oracle):
+    """window.pl / addhtkheader.pl outputs (tests/golden/cmp_windows.npz), bit for bit."""
+    g = np.load(os.path.join(GOLDEN, "cmp_windows.npz"))
+    for name in ("mgc", "lf0", "bap"):
+        T, dim = (int(v) for v in g[name + "_shape"])
+        a = cmp_stream(int(g[name + "_seed"]), T, dim, bool(g[name + "_holes"]))
+        w = oracle.window_stream(a, CMP_WINDOWS)
+        np.testing.assert_array_equal(w.view(np.uint32), g[name + "_windowed"].view(np.uint32))
+    sr, shift, byte, kind = (int(v) for v in g["htk_args"])
+    assert oracle.htk_header(37, sr, shift, byte, kind) == bytes(g["htk_header"])

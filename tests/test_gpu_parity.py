@@ -371,3 +371,35 @@ def test_codec_golden_on_gpu(gpu, oracle):
     np.testing.assert_allclose(mgc.cpu().numpy(), g["mgc"], atol=1e-5, rtol=0)
     np.testing.assert_allclose(bap.cpu().numpy(), g["bap"], atol=1e-5, rtol=0)
     b.close()
+
+
+def test_cmp_composition(gpu, pkg, oracle):
+    """window.pl + merge + HTK header on the device, bit for bit against the reference
+    scripts' outputs (golden) and, on a ragged two-utterance batch, against the oracle per utterance."""
+    from test_golden import CMP_WINDOWS, cmp_stream
+    torch, W, ctx = gpu
+    g = np.load(os.path.join(GOLDEN, "cmp_windows.npz"))
+    fs = 16000
+    T = int(g["mgc_shape"][0])
+    n = (T - 1) * 80 + 1                                         # x_length giving T frames at 5 ms
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[n])
+    assert b.total_frames == T
+    streams = []
+    for name in ("mgc", "lf0", "bap"):
+        _, dim = (int(v) for v in g[name + "_shape"])
+        a = cmp_stream(int(g[name + "_seed"]), T, dim, bool(g[name + "_holes"]))
+        streams.append((torch.from_numpy(a).cuda(), CMP_WINDOWS))
+    out = b.compose_cmp(streams).cpu().numpy()
+    want = np.concatenate([g[k + "_windowed"] for k in ("mgc", "lf0", "bap")], axis=1)
+    np.testing.assert_array_equal(out.view(np.uint32), want.view(np.uint32))
+    sr, shift, byte, kind = (int(v) for v in g["htk_args"])
+    assert W.htk_header(T, sr, shift, byte, kind) == bytes(g["htk_header"])
+    b.close()
+    # ragged batch: clamping happens at each utterance's own first / last frame
+    lens = [(29 - 1) * 80 + 1, (41 - 1) * 80 + 1]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+    parts = [cmp_stream(7, 29, 4, True), cmp_stream(8, 41, 4, True)]
+    got = b.compose_cmp([(torch.from_numpy(np.concatenate(parts)).cuda(), CMP_WINDOWS)]).cpu().numpy()
+    ref = np.concatenate([oracle.window_stream(p, CMP_WINDOWS) for p in parts])
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    b.close()
