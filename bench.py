@@ -71,22 +71,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    pkg = importlib.import_module("hts-train-world_amd")
+    W, sd, sh = pkg.world, pkg.synth_data, pkg.sharding
+
+    # ---- synthetic workload (not timed).  Generated BEFORE the GPU is touched: the generator forks a
+    # worker pool, and a process that has initialised HIP / RCCL should not be forked ----
+    fs, fp, utts = workload_spec(args)
+    ncpu = os.cpu_count() or 1
+    workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
+    xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    pkg = importlib.import_module("hts-train-world_amd")
-    W, sd, sh = pkg.world, pkg.synth_data, pkg.sharding
-    fs, fp = 16000, 5.0
     if args.workload != "analysis_synthesis":
-        return side_workload(args, torch, dist, W, sd, rank, world)
+        return side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts)
 
-    # ---- synthetic workload (not timed) ----
-    ncpu = os.cpu_count() or 1
-    workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
-    xs = sd.make_batch(args.utts, fs, tuple(args.dur), first=rank * args.utts, workers=workers)
     lens = [len(x) for x in xs]
     x = torch.from_numpy(np.concatenate(xs)).cuda()
     ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
@@ -188,20 +191,17 @@ def main():
         dist.destroy_process_group()
 
 
-def side_workload(args, torch, dist, W, sd, rank, world):
-    """configs[2] (Harvest) and configs[4] (Synthesis only): same contract, separate metric names."""
-    ncpu = os.cpu_count() or 1
-    workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
+def workload_spec(args):
+    """(fs, frame period, utterances per GPU) of the selected workload."""
     if args.workload == "harvest":
-        fs, fp = 48000, 1.0
-        utts = args.utts if args.utts != 256 else 64
-    elif args.workload == "codec":
-        fs, fp = 16000, 5.0
-        utts = args.utts
-    else:
-        fs, fp = 16000, 5.0
-        utts = args.utts if args.utts != 256 else 1024
-    xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
+        return 48000, 1.0, (args.utts if args.utts != 256 else 64)
+    if args.workload == "synthesis":
+        return 16000, 5.0, (args.utts if args.utts != 256 else 1024)
+    return 16000, 5.0, args.utts
+
+
+def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
+    """configs[2] (Harvest), configs[4] (Synthesis only) and the feature codec: same contract, separate metric names."""
     x = torch.from_numpy(np.concatenate(xs)).cuda()
     ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
     batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(v) for v in xs])
