@@ -19,7 +19,6 @@
 #include "bfft.hpp"
 #include "common.hpp"
 #include "fft.hpp"
-#include "ilp.hpp"
 #include "window.hpp"
 
 namespace wm {
