@@ -173,7 +173,9 @@ template <int N> struct FftTw {
   }
 };
 
-template <int N> __device__ __forceinline__ int fft_pad(int i) { return i + i / FftCfg<N>::R1; }
+// unsigned on purpose: with signed ints the compiler cannot prove (b + R1 * r) / R1 == b / R1 + r and emits
+// a full index computation per element instead of one base plus immediate offsets
+template <int N> __device__ __forceinline__ unsigned fft_pad(unsigned i) { return i + i / (unsigned)FftCfg<N>::R1; }
 
 // Forward complex FFT (e^{-j}).  v[m] holds element lane + 64 m on entry and on
 // exit.  `lds` must provide FftLds<N>::kElems cpx.  Caller guarantees no other
@@ -198,7 +200,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
 #pragma unroll
     for (int r = 0; r < R1; ++r) a[r] = v[b + r * S1];
     Dft<R1>::run(a);
-    const int j = lane + 64 * b;
+    const unsigned j = (unsigned)lane + 64u * b;
 #pragma unroll
     for (int r = 0; r < R1; ++r) lds[fft_pad<N>(j * R1 + r)] = a[r];
 #if !WM_FFT_ILP
@@ -207,7 +209,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
   }
   wave_sync();
 #pragma unroll
-  for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>(lane + 64 * m)];
+  for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
   wave_sync();
   // ---- pass 2: radix R2, Ns = R1; twiddle W_{R1 R2}^{k r}, k = j % R1 = lane % R1
 #pragma unroll
@@ -217,17 +219,17 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     for (int r = 0; r < R2; ++r) a[r] = v[b + r * S2];
     apply_twiddle_powers<R2>(a, tw.w2);
     Dft<R2>::run(a);
-    const int j = lane + 64 * b;
-    const int base = (j / R1) * (R1 * R2) + (j % R1);
+    const unsigned j = (unsigned)lane + 64u * b;
+    const unsigned base = (j / R1) * (R1 * R2) + (j % R1);
 #pragma unroll
-    for (int r = 0; r < R2; ++r) lds[fft_pad<N>(base + r * R1)] = a[r];
+    for (int r = 0; r < R2; ++r) lds[fft_pad<N>(base + (unsigned)r * R1)] = a[r];
 #if !WM_FFT_ILP
     __builtin_amdgcn_sched_barrier(0);
 #endif
   }
   wave_sync();
 #pragma unroll
-  for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>(lane + 64 * m)];
+  for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
   // ---- pass 3: radix R3, Ns = N / R3; twiddle W_N^{j r}; output lands in the register layout
 #pragma unroll
   for (int b = 0; b < S3; ++b) {
