@@ -204,30 +204,36 @@ __device__ __forceinline__ void linear_smoothing_lds(const double* in, double wi
     v[q] = q == 0 ? term : v[q - 1] + term;
   }
   const double carry = wave_scan_incl(v[CH - 1]) - v[CH - 1];
+  // unconditional: seg has 64 * CH entries, the ones beyond len are never read (a predicate per element
+  // turns into CH exec-mask branches)
 #pragma unroll
-  for (int q = 0; q < CH; ++q)
-    if (beg + q < len) seg[beg + q] = v[q] + carry;
+  for (int q = 0; q < CH; ++q) seg[beg + q] = v[q] + carry;
   wave_sync();
   const double c_lo = (b - 0.5) - 0.5 * wq, c_hi = c_lo + wq;
   const int bl = (int)c_lo, bh = (int)c_hi;
   const double fl = c_lo - bl, fh = c_hi - bh;
   const double inv_width = 1.0 / width;
   constexpr int GI = 8;
-  for (int i0 = 0; i0 <= half; i0 += 64 * GI) {
+  int i0 = 0;
+  for (; i0 + 64 * GI <= half + 1; i0 += 64 * GI) {          // full groups: no predicates
     double lo0[GI], lo1[GI], hi0[GI], hi1[GI];
 #pragma unroll
     for (int q = 0; q < GI; ++q) {
-      const int i = imin(half, i0 + 64 * q + lane);
+      const int i = i0 + 64 * q + lane;
       lo0[q] = seg[i + bl]; lo1[q] = seg[i + bl + 1];
       hi0[q] = seg[i + bh]; hi1[q] = seg[i + bh + 1];
     }
 #pragma unroll
     for (int q = 0; q < GI; ++q) {
-      const int i = i0 + 64 * q + lane;
       const double lo = lo0[q] + (lo1[q] - lo0[q]) * fl;
       const double hi = hi0[q] + (hi1[q] - hi0[q]) * fh;
-      if (i <= half) out[i] = (hi - lo) * inv_width;
+      out[i0 + 64 * q + lane] = (hi - lo) * inv_width;
     }
+  }
+  for (int i = i0 + lane; i <= half; i += 64) {               // tail (bin half of a power-of-two spectrum)
+    const double lo = seg[i + bl] + (seg[i + bl + 1] - seg[i + bl]) * fl;
+    const double hi = seg[i + bh] + (seg[i + bh + 1] - seg[i + bh]) * fh;
+    out[i] = (hi - lo) * inv_width;
   }
   wave_sync();
 }

@@ -716,10 +716,8 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         const double wmx = wave_max(cur);
         const unsigned long long vote = __ballot(cur == wmx);
         const int winner = __ffsll((long long)vote) - 1;
-        if (lane == winner) {
-          ++taken;
-          cur = heads[taken * 64 + lane];
-        }
+        taken += lane == winner ? 1 : 0;                      // branch-free: every lane re-reads its head
+        cur = heads[taken * 64 + lane];
       }
       double low = 0.0;
 #pragma unroll
