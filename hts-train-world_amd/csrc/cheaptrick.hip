@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
   tw.init(lane0);
   const double f0_floor = 3.0 * fs / (F - 3.0);                // cheaptrick.cpp:196-198
 
-  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+  WM_FOR_EACH_FRAME(frame, total_frames) {
     const int lane = opaque_lane(lane0);
     tw.fence();
     const int u = frame_utt[frame];

@@ -33,6 +33,23 @@ __device__ __forceinline__ double randn_at(const uint32_t* __restrict__ tab, int
   return (double)tab[k] / 268435456.0 - 6.0;
 }
 
+// Frames are dealt to the persistent workgroups one per round (runs of consecutive frames per workgroup
+// were measured: 8 per run costs 15 % through voiced / unvoiced imbalance).  Within a round the
+// workgroups of one XCD (workgroup id mod 8, a placement heuristic, not a guarantee) take CONSECUTIVE
+// frames: neighbouring frames read almost the same samples (windows of 3-4 pitch periods every 80
+// samples), so they are served by that XCD's L2 instead of every XCD fetching every sample.
+__device__ __forceinline__ int64_t xcd_dealt(int64_t round_base, int64_t total) {
+  const unsigned g = blockIdx.x, G = gridDim.x;
+  if (G & 7u) return round_base + g;                     // grid not a multiple of 8: plain dealing
+  const unsigned per = G >> 3;
+  (void)total;
+  return round_base + (int64_t)((g & 7u) * per + (g >> 3));
+}
+#define WM_FOR_EACH_FRAME(frame, total)                                                                   \
+  for (int64_t base_ = 0, frame = xcd_dealt(0, (total)); base_ < (int64_t)(total);                        \
+       base_ += gridDim.x, frame = xcd_dealt(base_, (total)))                                             \
+    if (frame < (int64_t)(total))
+
 // Compiler fence for the lane index inside persistent frame loops (see FftTw::fence): address
 // arithmetic derived from the returned value cannot be hoisted out of the loop and spilled.
 __device__ __forceinline__ int opaque_lane(int lane) {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
   FftTw<N> tw;
   tw.init(lane0);
   const int b0 = (int)ceil(100.0 * FL / fs), b1 = (int)ceil(4000.0 * FL / fs), b2 = (int)ceil(7900.0 * FL / fs);
-  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+  WM_FOR_EACH_FRAME(frame, total_frames) {
     const int lane = opaque_lane(lane0);
     const double f0v = f0[frame];
     if (f0v == 0.0) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
   bf.init(tid);
   const int out_bins = out_fft / 2 + 1;
 
-  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+  WM_FOR_EACH_FRAME(frame, total_frames) {
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];
     bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
   tw.init(lane0);
   const int out_bins = out_fft / 2 + 1;
 
-  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+  WM_FOR_EACH_FRAME(frame, total_frames) {
     const int lane = opaque_lane(lane0);
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
   double* xs = sm_lds + lmax + 2;           // [lmax + 2] samples, then x * main window
   const int lane0 = threadIdx.x;
   const double inv_fs = 1.0 / fs;
-  for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
+  WM_FOR_EACH_FRAME(frame, total_frames) {
     const int lane = opaque_lane(lane0);
     const double f = f0[frame];
     if (f <= kFloorF0StoneMask || f > fs / 12.0) {                 // stonemask.cpp:186-187
