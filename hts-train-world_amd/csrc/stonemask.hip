@@ -125,7 +125,10 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = imin(L - 1, i0 + 64 * q + lane);
-        raw[q] = matlab_round((pos + (double)(-hw + i) * inv_fs) * fs);   // GetBaseIndex :24-28
+        // GetBaseIndex :24-28.  The division stays a division: at rates where pos * fs is not an integer
+        // (22.05 kHz: 110.25 samples per frame) the argument of the rounding lands on exact .5 ties and a
+        // reciprocal multiplication flips them
+        raw[q] = matlab_round((pos + (double)(-hw + i) / fs) * fs);
         xv[q] = xu[imax(0, imin(xl - 1, raw[q] - 1))];
       }
 #pragma unroll

@@ -147,6 +147,29 @@ def test_48k_path(gpu, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("fs,fft", [(22050, 1024), (32000, 2048), (44100, 2048)])
+def test_other_sampling_rates(gpu, oracle, fs, fft):
+    """The rates between the two benchmark configurations: other FFT-size / band-count combinations
+    (22.05 kHz: fft 1024, D4C 2048, 2 bands; 32 kHz: 2048 / 4096 / 4 bands; 44.1 kHz: 2048 / 4096 / 5 bands)."""
+    torch, W, ctx = gpu
+    x = sd.make_utterance(30 + fs // 1000, fs, duration=0.7)
+    r = oracle_chain(oracle, x, fs)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    assert b.fft_size == fft == r["F"]
+    t, f0, sp, ap = b.analyze(torch.from_numpy(x).cuda())
+    y = b.synthesize(f0, sp, ap)
+    assert ((f0.cpu().numpy() > 0) == (r["f0"] > 0)).all()
+    np.testing.assert_allclose(f0.cpu().numpy(), r["f0"], atol=F0_TOL, rtol=0)
+    sp_close(sp.cpu().numpy(), r["sp"])
+    np.testing.assert_allclose(ap.cpu().numpy(), r["ap"], atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y.cpu().numpy(), r["y"], atol=Y_TOL, rtol=0)
+    th, fh = b.harvest(torch.from_numpy(x).cuda())
+    to, fo = oracle.harvest(x, fs, 5.0)
+    assert ((fh.cpu().numpy() > 0) == (fo > 0)).all()
+    np.testing.assert_allclose(fh.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+    b.close()
+
+
 def test_edge_cases(gpu, oracle):
     torch, W, ctx = gpu
     fs = 16000
