@@ -170,6 +170,24 @@ def test_other_sampling_rates(gpu, oracle, fs, fft):
     b.close()
 
 
+@pytest.mark.parametrize("fs,fp", [(16000, 1.0), (16000, 10.0), (16000, 2.5), (22050, 3.0), (48000, 4.0)])
+def test_other_frame_periods(gpu, oracle, fs, fp):
+    """Frame periods other than 5 ms, including ones that are not a whole number of samples (rounding ties)."""
+    torch, W, ctx = gpu
+    xs = [sd.make_utterance(50, fs, duration=0.6), sd.make_utterance(51, fs, duration=0.9)]
+    rs = [oracle_chain(oracle, x, fs, fp) for x in xs]
+    b = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(x) for x in xs])
+    t, f0, sp, ap = b.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
+    y = b.synthesize(f0, sp, ap)
+    np.testing.assert_array_equal(t.cpu().numpy(), cat(rs, "t"))
+    assert ((f0.cpu().numpy() > 0) == (cat(rs, "f0") > 0)).all()
+    np.testing.assert_allclose(f0.cpu().numpy(), cat(rs, "f0"), atol=F0_TOL, rtol=0)
+    sp_close(sp.cpu().numpy(), cat(rs, "sp"))
+    np.testing.assert_allclose(ap.cpu().numpy(), cat(rs, "ap"), atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y.cpu().numpy(), cat(rs, "y"), atol=Y_TOL, rtol=0)
+    b.close()
+
+
 def test_edge_cases(gpu, oracle):
     torch, W, ctx = gpu
     fs = 16000
