@@ -315,7 +315,10 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
           mainv[h] = make_double2(0.0, 0.0);
           diffv[h] = make_double2(0.0, 0.0);
           w[h] = cis_neg2pi((double)((bin[h] * l16) & (fftn - 1)) * inv_fftn);
-          st[h] = cis_neg2pi((double)((bin[h] * 16) & (fftn - 1)) * inv_fftn);
+          // the step of 16 samples is the twiddle of the row's lane 8, squared
+          const int src8 = (lane & 48) | 8;
+          const cpx hh = make_double2(__shfl(w[h].x, src8, 64), __shfl(w[h].y, src8, 64));
+          st[h] = cmul(hh, hh);
         }
         // windowed DFT bins (GetSpectra / GetMainWindow / GetDiffWindow :462-568), four trips per round
         for (int i0 = 0; i0 < Lmax; i0 += 64) {

@@ -28,7 +28,10 @@ __device__ __forceinline__ void sm_bins(double* ad_mw, double* am_xs, int L, con
     diffv[b] = make_double2(0.0, 0.0);
     // fftn is a power of two: the modulo is a mask and the division an exact multiplication
     w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
-    st[b] = cis_neg2pi((double)((bin[b] * 64) & (fftn - 1)) * inv_fftn);
+    // the step of 64 samples is lane 32's twiddle squared (a broadcast and one complex product
+    // instead of a second sincospi evaluated identically by all lanes)
+    const cpx h = make_double2(__shfl(w[b].x, 32, 64), __shfl(w[b].y, 32, 64));
+    st[b] = cmul(h, h);
   }
   double carry = 0.0;                                 // mw of the previous trip's last lane
   for (int i = lane; i < ((L + 63) & ~63); i += 64) {
