@@ -131,17 +131,6 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
   }
 }
 
-// diagnostic cycle stamps (s_memtime) per phase of d4c_wave_kernel; enabled with dbg bit 32
-__device__ unsigned long long g_d4c_stamps[16];
-#define WM_STAMP(id)                                                                   \
-  do {                                                                                 \
-    if (dbg & 32) {                                                                    \
-      const long long tn_ = clock64();                                                 \
-      if (lane == 0) atomicAdd(&g_d4c_stamps[id], (unsigned long long)(tn_ - tprev_)); \
-      tprev_ = clock64();                                                              \
-    }                                                                                  \
-  } while (0)
-
 // Descending sort of a[0..NS) in registers, NS a power of two: Batcher's odd-even merge sort.  All
 // loop bounds are compile-time, so after unrolling every compare-exchange has static register indices.
 template <int NS>
@@ -546,7 +535,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     const double pos = tpos[frame];
     const int roff = rng_off[frame];
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
-    long long tprev_ = clock64();
 
     // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
     double sc[MB];
@@ -559,7 +547,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       cpx v[M];
       const FrameWindow fw = windowed_waveform_lds<kBlackman, false, 8>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
                                                                      smem, FD);
-    WM_STAMP(1);
       double pwr = 0.0;                                   // d4c.cpp:96-100
       for (int i = lane; i < fw.L; i += 64) pwr += smem[i] * smem[i];
       // normalisation by sqrt(power) (d4c.cpp:99-100) applied as a multiplication by its reciprocal
@@ -568,9 +555,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       cpx fv[M];                                          // normalised frame, kept for the ramped transform
 #pragma unroll
       for (int m = 0; m < M; ++m) { v[m].x *= rnrm; v[m].y *= rnrm; fv[m] = v[m]; }
-      WM_STAMP(2);
       rfft_forward<N>(v, img, img, tw, lane);
-      WM_STAMP(3);
       cpx s1[MB];
 #pragma unroll
       for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
@@ -582,7 +567,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         v[m] = make_double2(fv[m].x * (i0 + 1.0), fv[m].y * (i0 + 2.0));
       }
       rfft_forward<N>(v, img, img, tw, lane);
-      WM_STAMP(4);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         cpx s2 = img[lane + 64 * m];
@@ -593,7 +577,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         sc[M] += s2.x * s1[M].x + s1[M].y * s2.y;
       }
       wave_sync();
-      WM_STAMP(5);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m];
@@ -604,14 +587,12 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
     sc[M] = arr[N];
     wave_sync();
-    WM_STAMP(6);
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
     double gd[MB];
     if (!(dbg & 2)) {
       cpx v[M];
       windowed_waveform_lds<kHann, false, 8>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
-      WM_STAMP(7);
       load_packed<N>(smem, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
@@ -629,13 +610,11 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
       if (lane == 0) arr[N] = p[M];
       wave_sync();
-      WM_STAMP(8);
     }
     if (!(dbg & 4)) {
     dc_correction_lds(arr, cf0, fs, FD, seg, lane);
     linear_smoothing_lds<kCh>(arr, cf0, fs, FD, seg, arr, lane);
     }
-    WM_STAMP(9);
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
@@ -651,7 +630,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[N];
     wave_sync();
-    WM_STAMP(10);
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
     const int wl = tab.window_length;
@@ -674,9 +652,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
         if (i0 + 1 < wl) a1 = arr[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
         v[m] = make_double2(a0, a1);
       }
-      WM_STAMP(11);
       rfft_forward<N>(v, img, img, tw, lane);
-      WM_STAMP(12);
       double p[MB];
       double tot = 0.0;
 #pragma unroll
@@ -730,7 +706,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       for (int j = 0; j < 6; ++j)
         if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
       wave_sync();
-      WM_STAMP(13);
     }
 
     // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
@@ -762,7 +737,6 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       }
     }
     wave_sync();
-    WM_STAMP(14);
   }
 }
 
@@ -850,16 +824,6 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     }
   }
 #undef WM_D4C_CASE
-  if (dbg & 32) {
-    unsigned long long h[16];
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_d4c_stamps), sizeof(h));
-    fprintf(stderr, "d4c stamps (Mcycles):");
-    for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d]=%.1f", i, h[i] / 1e6);
-    fprintf(stderr, "\n");
-    memset(h, 0, sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_d4c_stamps), h, sizeof(h));
-  }
   return wm_check(hipGetLastError());
 }
 
