@@ -97,6 +97,7 @@ struct Batch {
   int64_t dio_tot_y = 0;
   int dio_bands = 0;
   double* d_dio_mean = nullptr;      // [n_utt]
+  double* d_dio_mean_part = nullptr; // [n_utt][32] partial sums
   double* d_dio_z = nullptr;         // low-cut output, per utterance y_len + 2*pad
   int64_t* d_dio_z_off = nullptr;
   std::vector<int64_t> dio_z_off;

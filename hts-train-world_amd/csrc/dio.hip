@@ -39,20 +39,33 @@ struct DioMeta {
 
 // src is x itself (speed 1: y_length = N + 1, the extra sample is zero) or the decimated signal
 // (speed > 1: all y_length samples materialised, zeros beyond decimate's output).
-__global__ __launch_bounds__(256) void dio_mean_kernel(const double* __restrict__ src,
-                                                       const int64_t* __restrict__ src_off,
-                                                       const int* __restrict__ src_len,
-                                                       const int* __restrict__ ylen_a, double* __restrict__ mean) {
-  __shared__ double part[4];
-  const int u = blockIdx.x;
+// Two stages with a fixed summation tree (deterministic, no atomics): kMeanTiles partial sums per
+// utterance, then one thread per utterance adds them in order.
+constexpr int kMeanTiles = 32;
+__global__ __launch_bounds__(256) void dio_mean_partial_kernel(const double* __restrict__ src,
+                                                               const int64_t* __restrict__ src_off,
+                                                               const int* __restrict__ src_len,
+                                                               double* __restrict__ part) {
+  __shared__ double wsum[4];
+  const int u = blockIdx.y, t = blockIdx.x;
   const double* xu = src + src_off[u];
   const int n = src_len[u];
+  const int chunk = (n + kMeanTiles - 1) / kMeanTiles;
+  const int lo = t * chunk, hi = imin(n, lo + chunk);
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += xu[i];
+  for (int i = lo + threadIdx.x; i < hi; i += 256) s += xu[i];
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) mean[u] = (part[0] + part[1] + part[2] + part[3]) / ylen_a[u];   // dio.cpp:74-77
+  if (threadIdx.x == 0) part[u * kMeanTiles + t] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void dio_mean_kernel(const double* __restrict__ part, const int* __restrict__ ylen_a,
+                                                       int n_utt, double* __restrict__ mean) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n_utt) return;
+  double s = 0.0;
+  for (int t = 0; t < kMeanTiles; ++t) s += part[u * kMeanTiles + t];
+  mean[u] = s / ylen_a[u];                                        // dio.cpp:74-77
 }
 
 // circular, zero-padded, mean-removed signal of the reference (dio.cpp:63-79)
@@ -429,6 +442,7 @@ static int dio_setup(Batch& b) {
     rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
   };
   al((void**)&b.d_dio_mean, sizeof(double) * (size_t)b.n_utt);
+  al((void**)&b.d_dio_mean_part, sizeof(double) * (size_t)b.n_utt * kMeanTiles);
   if (m.ratio > 1) {
     al((void**)&b.d_dio_y, sizeof(double) * (size_t)yoff[(size_t)b.n_utt]);
     al((void**)&b.d_dio_tmp, sizeof(double) * (size_t)toff[(size_t)b.n_utt]);
@@ -477,8 +491,10 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        b.d_dio_tmp, b.d_dio_yoff, b.d_dio_ylen, b.d_dio_y);
     src = b.d_dio_y; src_off = b.d_dio_yoff; src_len = b.d_dio_ylen;
   }
-  hipLaunchKernelGGL(dio_mean_kernel, dim3(b.n_utt), dim3(256), 0, st, src, src_off, src_len, b.d_dio_ylen,
-                     b.d_dio_mean);
+  hipLaunchKernelGGL(dio_mean_partial_kernel, dim3(kMeanTiles, b.n_utt), dim3(256), 0, st, src, src_off, src_len,
+                     b.d_dio_mean_part);
+  hipLaunchKernelGGL(dio_mean_kernel, dim3((b.n_utt + 255) / 256), dim3(256), 0, st, b.d_dio_mean_part, b.d_dio_ylen,
+                     b.n_utt, b.d_dio_mean);
   {
     const int total_max = b.max_x_len / m.ratio + 1 + 2 * m.pad;
     const int tiles = (total_max + kBandTile - 1) / kBandTile;
