@@ -485,33 +485,61 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
 
 // y[n] += sum over pulses p (of this utterance, within [p_begin, p_end)) covering n, in pulse order:
 // index = j + idx - F/2 + 1  (synthesis.cpp:378-383)  ->  j = n - idx + F/2 - 1.
+// A workgroup owns 256 consecutive samples: the pulses that can touch any of them are found once
+// (two uniform binary searches), their indices staged in LDS, and every thread walks that list with
+// four response loads in flight; a pulse that does not cover the thread's sample contributes an exact
+// + 0.0, so the association is still the reference's sequential += in pulse order.
 __global__ __launch_bounds__(256) void synth_ola_kernel(const int64_t* __restrict__ y_off,
                                                         const int64_t* __restrict__ p_off,
                                                         const int* __restrict__ pulse_idx, int fft_size,
                                                         int64_t p_begin, int64_t p_end,
                                                         const double* __restrict__ resp, double* __restrict__ y) {
+  __shared__ int sidx[256];
   const int u = blockIdx.y;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  int64_t pa = p_off[u] > p_begin ? p_off[u] : p_begin;
-  int64_t pb = p_off[u + 1] < p_end ? p_off[u + 1] : p_end;
-  if (n >= ylen || pa >= pb) return;
+  const int n0 = blockIdx.x * 256;
+  const int n = n0 + threadIdx.x;
+  const int64_t pa = p_off[u] > p_begin ? p_off[u] : p_begin;
+  const int64_t pb = p_off[u + 1] < p_end ? p_off[u + 1] : p_end;
+  if (n0 >= ylen || pa >= pb) return;
   const int h = fft_size / 2;
   const int* pidx = pulse_idx + yb - p_off[u];        // pidx[p] = index of global pulse p
-  // first pulse with idx >= n - h
+  // pulses with n0 - h <= idx <= n0 + 255 + h - 1 (uniform)
   int64_t lo = pa, hi = pb;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if (pidx[mid] < n - h) lo = mid + 1; else hi = mid;
+    if (pidx[mid] < n0 - h) lo = mid + 1; else hi = mid;
   }
-  double acc = y[yb + n];
-  for (int64_t p = lo; p < pb; ++p) {
-    const int idx = pidx[p];
-    if (idx > n + h - 1) break;
-    acc += resp[(p - p_begin) * (int64_t)fft_size + (n - idx + h - 1)];
+  const int64_t first = lo;
+  hi = pb;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (pidx[mid] <= n0 + 255 + h - 1) lo = mid + 1; else hi = mid;
   }
-  y[yb + n] = acc;
+  const int64_t last = lo;                              // one past
+  const bool live = n < ylen;
+  double acc = live ? y[yb + n] : 0.0;
+  for (int64_t base = first; base < last; base += 256) {
+    const int cnt = (int)(last - base < 256 ? last - base : 256);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) sidx[threadIdx.x] = pidx[base + threadIdx.x];
+    __syncthreads();
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+      double r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        const int idx = sidx[j < cnt ? j : cnt - 1];
+        const int off = n - idx + h - 1;
+        const bool cover = live && j < cnt && off >= 0 && off < fft_size;
+        r[q] = cover ? resp[(base + j - p_begin) * (int64_t)fft_size + off] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc += r[q];
+    }
+  }
+  if (live) y[yb + n] = acc;
 }
 
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
