@@ -123,7 +123,7 @@ int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double*
  * Applies each stream's dynamic-feature windows and lays the results side by side per frame:
  *   out[frame] = [stream 0: window 0 (dim) | window 1 | ...][stream 1: ...]...      (float32)
  * streams[s]: device pointer, float32 [total_frames][dims[s]].  windows[s][i]: HOST pointer to the
- * window_sizes[s][i] coefficients of window i of stream s (the content of data/win/*.win<i> without the
+ * window_sizes[s][i] coefficients of window i of stream s (the content of data/win/NAME.win<i> without the
  * leading size).  Frames are clamped per utterance; -1e10 is the ignore value of unvoiced lf0.
  * Limits: 4 streams, 4 windows per stream, odd window sizes up to 15. */
 int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* streams, const int* dims,
