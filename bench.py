@@ -79,6 +79,8 @@ def main():
     fs, fp, utts = workload_spec(args)
     ncpu = os.cpu_count() or 1
     workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
+    if args.workers <= 0 and any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")):
+        workers = 1      # under rocprofv3 the preloaded tool has already initialised the GPU: do not fork
     xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"

@@ -177,36 +177,77 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bfr
 }
 
 // DetectOfficialF0Candidates (harvest.cpp:348-412): one thread per frame
-__global__ __launch_bounds__(256) void hv_detect_kernel(const int* __restrict__ bframe_utt, HvMeta m,
-                                                        const double* __restrict__ raw, int64_t tot_b,
-                                                        double* __restrict__ offc, int* __restrict__ cnt,
-                                                        int* __restrict__ ncand1) {
-  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (fr >= tot_b) return;
-  const double* row = raw + fr * m.nch;
-  double* out = offc + fr * m.cpf;
-  int k = 0;
-  int prev = 0, st = 0;                         // vuv[0] = 0
-  for (int j = 1; j < m.nch; ++j) {
-    const int v = (j == m.nch - 1) ? 0 : (row[j] > 0 ? 1 : 0);
-    const int d = v - prev;
-    if (d == 1) st = j;
-    if (d == -1) {
-      const int ed = j;
+// next set / clear bit at or after position p of a 192-bit mask (3 words), 192 if none
+__device__ __forceinline__ int hv_next_bit(const unsigned long long (&w)[3], int p, bool want_set) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (p < 64 * (i + 1)) {
+      const int sh = p > 64 * i ? p - 64 * i : 0;
+      unsigned long long x = want_set ? w[i] : ~w[i];
+      x = sh < 64 ? (x >> sh) << sh : 0ull;
+      if (x) return 64 * i + __ffsll((long long)x) - 1;
+    }
+  }
+  return 192;
+}
+
+// DetectOfficialF0Candidates (harvest.cpp:348-412): one wavefront per basic frame.  The channel row is
+// read once (coalesced), voiced channels become a bit mask by ballot, runs of >= 10 voiced channels are
+// walked on the mask, and each run's mean is accumulated in channel order (the reference's association).
+__global__ __launch_bounds__(64) void hv_detect_kernel(const int* __restrict__ bframe_utt, HvMeta m,
+                                                       const double* __restrict__ raw, int64_t tot_b,
+                                                       double* __restrict__ offc, int* __restrict__ cnt,
+                                                       int* __restrict__ ncand1) {
+  const int lane = threadIdx.x;
+  // a workgroup takes a contiguous range of frames, so that the per-utterance maximum of the candidate
+  // count needs one atomic per (workgroup, utterance) instead of one per frame (339 k atomics on 64
+  // addresses were the whole cost of this kernel)
+  const int64_t per = (tot_b + gridDim.x - 1) / gridDim.x;
+  const int64_t f_lo = blockIdx.x * per, f_hi = f_lo + per < tot_b ? f_lo + per : tot_b;
+  int cur_u = -1, cur_max = 0;
+  for (int64_t fr = f_lo; fr < f_hi; ++fr) {
+    const double* row = raw + fr * m.nch;
+    double* out = offc + fr * m.cpf;
+    double vals[3];
+    unsigned long long bits[3];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const int j = lane + 64 * w;
+      vals[w] = j < m.nch ? row[j] : 0.0;
+      // vuv[0] = 0 and vuv[nch - 1] = 0 by construction (:351-356)
+      bits[w] = __ballot(j >= 1 && j < m.nch - 1 && vals[w] > 0);
+    }
+    int k = 0;
+    int p = 1;
+    while (p < m.nch) {
+      const int st = hv_next_bit(bits, p, true);
+      if (st >= m.nch) break;
+      const int ed = hv_next_bit(bits, st, false);               // first unvoiced channel after the run
       if (ed - st >= 10) {
         double tmp = 0.0;
-        for (int q = st; q < ed; ++q) tmp += row[q];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {                              // channel order, word by word
+          const int lo = st > 64 * w ? st : 64 * w, hi = ed < 64 * w + 64 ? ed : 64 * w + 64;
+          for (int q = lo; q < hi; ++q) tmp += readlane_d(vals[w], q - 64 * w);   // uniform lane: v_readlane
+        }
         tmp /= (ed - st);
-        if (k < m.cpf) out[k] = tmp;
+        if (k < m.cpf && lane == 0) out[k] = tmp;
         ++k;
       }
+      p = ed;
     }
-    prev = v;
+    if (k > m.cpf) k = m.cpf;
+    for (int q = k + lane; q < m.cpf; q += 64) out[q] = 0.0;
+    if (lane == 0) cnt[fr] = k;
+    const int u = bframe_utt[fr];
+    if (u != cur_u) {
+      if (lane == 0 && cur_max > 0) atomicMax(&ncand1[cur_u], cur_max);
+      cur_u = u;
+      cur_max = 0;
+    }
+    cur_max = k > cur_max ? k : cur_max;
   }
-  if (k > m.cpf) k = m.cpf;
-  for (int q = k; q < m.cpf; ++q) out[q] = 0.0;
-  cnt[fr] = k;
-  if (k > 0) atomicMax(&ncand1[bframe_utt[fr]], k);
+  if (lane == 0 && cur_max > 0) atomicMax(&ncand1[cur_u], cur_max);
 }
 
 // RefineF0Candidates (harvest.cpp:622-631) over the overlapped candidate table that
@@ -398,22 +439,25 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
   const int nb1 = nb1_a[u];
   double c = rc[fr * m.maxc + s], sc = rs[fr * m.maxc + s];
   if (k >= 1 && k < nb1 - 1 && c != 0) {
-    double e[2];
+    // SelectBestF0 with allowed_range 1.0 on both neighbours (:652-688) only keeps the smaller relative
+    // error: min over q of fl(|c - v_q| / c), capped at 1.  Correctly rounded division by c > 0 is
+    // monotone, so that is fl(min |c - v_q| / c) -- one division instead of one per candidate.
+    double dmin = HUGE_VAL;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       const int nk = side == 0 ? k + 1 : k - 1;
       const bool zero_row = nk == 0 || nk == nb1 - 1;
       const double* row = rc + (fr + (side == 0 ? 1 : -1)) * m.maxc;
-      double best = 1.0;                                           // SelectBestF0 with allowed_range 1.0
-      for (int q = 0; q < nc; ++q) {
-        const double v = zero_row ? 0.0 : row[q];
-        const double er = fabs(c - v) / c;
-        if (er > best) continue;
-        best = er;
+      for (int q0 = 0; q0 < nc; q0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = zero_row ? 0.0 : row[imin(nc - 1, q0 + r)];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dmin = fmin(dmin, fabs(c - v[r]));
       }
-      e[side] = best;
     }
-    const double me = e[0] < e[1] ? e[0] : e[1];
+    const double er = dmin / c;
+    const double me = er > 1.0 ? 1.0 : er;
     if (!(me <= 0.05)) { c = 0; sc = 0; }
   }
   rc2[fr * m.maxc + s] = c;
@@ -1043,8 +1087,13 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.d_evoff, W.d_events, W.d_evcnt, W.tot_b, W.d_raw);
   }
   (void)hipMemsetAsync(W.d_ncand1, 0, sizeof(int) * (size_t)n_utt, st);
-  hipLaunchKernelGGL(hv_detect_kernel, dim3(gx), dim3(256), 0, st, W.d_bframe_utt, m, W.d_raw, W.tot_b, W.d_offc,
-                     W.d_cnt, W.d_ncand1);
+  if (m.nch > 192) return WM_ERR_UNSUPPORTED;                    // hv_detect_kernel: channel mask of 3 words
+  {
+    TimedScope ts_(b.ctx, "hv_detect_kernel");
+    const int64_t gd = W.tot_b < (int64_t)c.num_cu * 64 ? W.tot_b : (int64_t)c.num_cu * 64;
+    hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)gd), dim3(64), 0, st, W.d_bframe_utt, m, W.d_raw, W.tot_b,
+                       W.d_offc, W.d_cnt, W.d_ncand1);
+  }
   {
     TimedScope ts_(b.ctx, "hv_refine_kernel");
     const int lmax = 2 * (int)(1.5 * m.afs / b.p.f0_floor + 1.0) + 1;
