@@ -141,6 +141,13 @@ __global__ __launch_bounds__(256) void hv_band_compact_kernel(
 }
 
 // raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
+// GetF0CandidateContour(+Sub) (harvest.cpp:240-293).  A workgroup is 256 consecutive basic frames of
+// one channel: their query times span 256 ms, so the events they can touch are a short slice of each
+// of the four lists.  The slice is located once (two uniform searches per list), staged in LDS, and
+// every thread searches there -- same comparisons, same results, without 44 dependent global loads per
+// thread.  Workgroups that straddle two utterances, or whose slice exceeds the LDS tile, use the
+// global lists directly.
+constexpr int kRawStage = 384;
 __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bframe_utt,
                                                      const int64_t* __restrict__ boff,
                                                      const int* __restrict__ ylen_a, HvMeta m,
@@ -149,26 +156,65 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bfr
                                                      const double* __restrict__ events,
                                                      const int* __restrict__ evcnt, int64_t tot_b,
                                                      double* __restrict__ raw) {
+  __shared__ double le[4][kRawStage];
   const int ch = blockIdx.y;
-  const int64_t fr = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (fr >= tot_b) return;
-  const int u = bframe_utt[fr];
-  const int cap = ylen_a[u] / 2 + 2;
-  const int* cnt = evcnt + ((int64_t)u * m.nch + ch) * 4;
-  const double* ev = events + evoff[u] + (int64_t)ch * 4 * cap;
-  int nint[4];
+  const int64_t fr0 = (int64_t)blockIdx.x * 256;
+  const int64_t fr = fr0 + threadIdx.x;
+  const int64_t frl = fr0 + 255 < tot_b ? fr0 + 255 : tot_b - 1;
+  const int u0 = bframe_utt[fr0], ul = bframe_utt[frl];
+  bool staged = u0 == ul;
+  int A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, base[4] = {0, 0, 0, 0}, nint[4] = {0, 0, 0, 0};
   bool ok = true;
+  const int uu = fr < tot_b ? bframe_utt[fr] : u0;
+  const int cap = ylen_a[uu] / 2 + 2;
+  const int* cnt = evcnt + ((int64_t)uu * m.nch + ch) * 4;
+  const double* ev = events + evoff[uu] + (int64_t)ch * 4 * cap;
 #pragma unroll
   for (int ty = 0; ty < 4; ++ty) {
     nint[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;
     ok = ok && nint[ty] > 2;                                   // CheckEvent(n - 2), :263-266
   }
+  __shared__ int sAB[8];
+  if (staged && ok) {                                           // uniform: one utterance, same lists
+    // eight searches per workgroup (four lists, first and last query time), one lane each
+    if (threadIdx.x < 8) {
+      const int ty = threadIdx.x >> 1;
+      const int64_t fq = (threadIdx.x & 1) ? frl : fr0;
+      sAB[threadIdx.x] = zc_upper(ev + (int64_t)ty * cap, nint[ty], m.afs, (int)(fq - boff[u0]) * 1 / 1000.0);
+    }
+  }
+  __syncthreads();
+  if (staged && ok) {
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      A[ty] = sAB[2 * ty];
+      B[ty] = sAB[2 * ty + 1];
+      base[ty] = imax(0, imin(A[ty], nint[ty] - 1) - 1);
+      const int top = imin(nint[ty], imax(B[ty], 1) + 1);      // last index needed (k + 1 <= n)
+      if (top - base[ty] + 1 > kRawStage) staged = false;
+    }
+  }
+  staged = staged && ok;
+  if (staged) {
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      const double* e = ev + (int64_t)ty * cap;
+      const int top = imin(nint[ty], imax(B[ty], 1) + 1);
+      for (int i = base[ty] + threadIdx.x; i <= top; i += 256) le[ty][i - base[ty]] = e[i];
+    }
+  }
+  __syncthreads();
+  if (fr >= tot_b) return;
   double c = 0.0;
   if (ok) {
-    const double t = (int)(fr - boff[u]) * 1 / 1000.0;         // basic frame period 1 ms (:1174-1175)
+    const double t = (int)(fr - boff[uu]) * 1 / 1000.0;        // basic frame period 1 ms (:1174-1175)
     double v[4];
+    bool exact = false;
+    const double hmax = zc_hmax(m.afs, t, exact);
 #pragma unroll
-    for (int ty = 0; ty < 4; ++ty) v[ty] = zc_track(ev + (int64_t)ty * cap, nint[ty], m.afs, t);
+    for (int ty = 0; ty < 4; ++ty)
+      v[ty] = staged ? zc_track_staged(le[ty], base[ty], A[ty], B[ty], nint[ty], m.afs, t, hmax, exact)
+                     : zc_track(ev + (int64_t)ty * cap, nint[ty], m.afs, t);
     c = (v[0] + v[1] + v[2] + v[3]) / 4.0;
     const double b = bf[ch];
     if (c > b * 1.1 || c < b * 0.9 || c > f0_ceil || c < f0_floor) c = 0.0;   // :243-252

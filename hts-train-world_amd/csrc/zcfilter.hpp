@@ -238,14 +238,35 @@ __device__ __forceinline__ void zc_compact_tile(const double* __restrict__ slot,
   }
 }
 
+// largest half-sum h with fl(h / fs) <= t (the division is monotone in h); `exact` false if it could not be
+// pinned down within 4 ulps of t * fs (t == 0)
+__device__ __forceinline__ double zc_hmax(double fs, double t, bool& exact) {
+  double hmax = t * fs;
+  for (int it = 0; it < 4 && hmax / fs > t; ++it) hmax = nextafter(hmax, -HUGE_VAL);
+  for (int it = 0; it < 4 && nextafter(hmax, HUGE_VAL) / fs <= t; ++it) hmax = nextafter(hmax, HUGE_VAL);
+  exact = hmax / fs <= t && nextafter(hmax, HUGE_VAL) / fs > t;
+  return hmax;
+}
 // interp1 (matlabfunctions.cpp:136-182) over a zero-crossing track given by its fine edges:
 // locations[j] = (e[j] + e[j+1]) / 2 / fs, intervals[j] = fs / (e[j+1] - e[j]), j < n (dio.cpp:384-387)
 __device__ __forceinline__ double zc_track(const double* __restrict__ e, int n, double fs, double t) {
-  int lo = 0, hi = n;                         // upper_bound on locations
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
-    if (loc <= t) lo = mid + 1; else hi = mid;
+  // upper_bound on locations[j] = fl(fl((e[j] + e[j+1]) / 2) / fs) <= t.  The division is monotone in its
+  // numerator, so "location <= t" is "half-sum <= hmax" with hmax the largest double whose quotient by fs
+  // rounds to at most t: a few divisions per query instead of one per probe, same decisions bit for bit.
+  bool exact = false;
+  const double hmax = zc_hmax(fs, t, exact);
+  int lo = 0, hi = n;
+  if (exact) {
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((e[mid] + e[mid + 1]) / 2.0 <= hmax) lo = mid + 1; else hi = mid;
+    }
+  } else {                                     // not pinned down within 4 ulps (t == 0): the literal form
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
+      if (loc <= t) lo = mid + 1; else hi = mid;
+    }
   }
   const int k = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
   const double x0 = (e[k - 1] + e[k]) / 2.0 / fs, x1 = (e[k] + e[k + 1]) / 2.0 / fs;
@@ -255,5 +276,36 @@ __device__ __forceinline__ double zc_track(const double* __restrict__ e, int n, 
   return y0 + sfrac * (y1 - y0);
 }
 
+
+// ---- the same lookup for a block of queries with nearby times -------------------------------------
+// upper_bound index alone (the first part of zc_track), literal comparisons
+__device__ __forceinline__ int zc_upper(const double* __restrict__ e, int n, double fs, double t) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const double loc = (e[mid] + e[mid + 1]) / 2.0 / fs;
+    if (loc <= t) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// zc_track for a query whose upper_bound is known to lie in [A, B]; le[] holds e[base .. ] (LDS).
+// hmax / exact from zc_hmax(fs, t): the probes compare half-sums, no division (same decisions).
+__device__ __forceinline__ double zc_track_staged(const double* le, int base, int A, int B, int n, double fs,
+                                                  double t, double hmax, bool exact) {
+  int lo = A, hi = B;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const double half = (le[mid - base] + le[mid + 1 - base]) / 2.0;
+    const bool le_t = exact ? half <= hmax : half / fs <= t;
+    if (le_t) lo = mid + 1; else hi = mid;
+  }
+  const int k = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+  const double e0 = le[k - 1 - base], e1 = le[k - base], e2 = le[k + 1 - base];
+  const double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
+  const double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
+  const double h = x1 - x0;
+  const double sfrac = (t - x0) / h;
+  return y0 + sfrac * (y1 - y0);
+}
 
 }  // namespace wm
