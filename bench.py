@@ -40,7 +40,7 @@ FLOPS_PER_FRAME = 0.7e6
 D4C_BYTES_PER_FRAME = 80 * 8 + 8 + 8 + 8 + 513 * 8
 D4C_FLOPS_PER_VOICED_FRAME = 6 * 2.5 * 2048 * 11   # 6 real FFTs of 2048 (+ scans etc., not counted)
 # PMC FETCH_SIZE of d4c_kernel, separate --pmc pass on 64 utterances (67 884 frames): 1 123 828 KB
-# (profiles/r01_c_pmc_fetch_size_64utts.csv); 8 B/lane accesses, no gfx950 width correction applied.
+# (profiles/r01_e_pmc_fetch_size_64utts.csv); 8 B/lane accesses, no gfx950 width correction applied.
 # Read side only: the WRITE_SIZE pass does not complete under rocprofv3 on this pool.
 D4C_FETCH_BYTES_PER_FRAME = 1123828 * 1024 / 67884
 
@@ -153,7 +153,7 @@ def main():
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frames * D4C_BYTES_PER_FRAME / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if d4c_avg_s > 0 else None,
             "traffic": round(frames * D4C_FETCH_BYTES_PER_FRAME),
-            "traffic_note": "HBM-side read bytes per launch from PMC FETCH_SIZE (profiles/r01_c_pmc_fetch_size_64utts.csv, "
+            "traffic_note": "HBM-side read bytes per launch from PMC FETCH_SIZE (profiles/r01_e_pmc_fetch_size_64utts.csv, "
                             "per-frame figure x frames); write side not measured",
             "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": frames,
             "bytes_per_unit": D4C_BYTES_PER_FRAME,
