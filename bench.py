@@ -39,10 +39,10 @@ FLOPS_PER_FRAME = 0.7e6
 # d4c_kernel alone: reads its 80 new samples + t + f0 + ap0 (664 B), writes one ap row (4104 B)
 D4C_BYTES_PER_FRAME = 80 * 8 + 8 + 8 + 8 + 513 * 8
 D4C_FLOPS_PER_VOICED_FRAME = 6 * 2.5 * 2048 * 11   # 6 real FFTs of 2048 (+ scans etc., not counted)
-# PMC FETCH_SIZE of d4c_kernel, separate --pmc pass on 64 utterances (67 884 frames): 1 123 828 KB
+# PMC FETCH_SIZE of d4c_kernel, separate --pmc pass on 64 utterances (67 884 frames): 827 020 KB
 # (profiles/r01_e_pmc_fetch_size_64utts.csv); 8 B/lane accesses, no gfx950 width correction applied.
 # Read side only: the WRITE_SIZE pass does not complete under rocprofv3 on this pool.
-D4C_FETCH_BYTES_PER_FRAME = 1123828 * 1024 / 67884
+D4C_FETCH_BYTES_PER_FRAME = 827020.3125 * 1024 / 67884
 
 
 def parse():
@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--dur", type=float, nargs=2, default=(2.0, 8.0))
     ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl (= RCCL; the driver's launch) or gloo: rehearsal of the N > 1 control path with several "
+                         "ranks sharing one GPU, where RCCL refuses duplicate devices")
     ap.add_argument("--cpu-utts", type=int, default=48, help="utterances of the CPU baseline sample")
     ap.add_argument("--workers", type=int, default=0, help="processes for synthetic data generation (0 = auto)")
     ap.add_argument("--workload", choices=["analysis_synthesis", "harvest", "synthesis", "codec"], default="analysis_synthesis",
@@ -84,10 +87,15 @@ def main():
     xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     if args.workload != "analysis_synthesis":
         return side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts)
@@ -108,7 +116,10 @@ def main():
         batch.synthesize(f0, sp, ap, out=y)
         if args.gather and world > 1:
             # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
-            sh.gather_features([f0.float(), sp.float(), ap.float()], frame_counts, dst=0)
+            feats = [f0.float(), sp.float(), ap.float()]
+            if args.backend == "gloo":
+                feats = [v.cpu() for v in feats]
+            sh.gather_features(feats, frame_counts, dst=0)
 
     def barrier():
         if world > 1:
@@ -132,7 +143,7 @@ def main():
         kernel_ms[k] = (ms, n)
     ctx.timing_enable(False)
 
-    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -243,7 +254,7 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
     barrier()
     elapsed = time.perf_counter() - t0
     kms = {k: ctx.timing_query(k)[0] / args.steps for k in names}
-    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax, tsum = tt.clone(), tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
