@@ -79,6 +79,9 @@ struct Batch {
   int* d_rng_off2 = nullptr;         // [total_f] D4C LoveTrain offsets
   double* d_ap0 = nullptr;           // [total_f] D4C LoveTrain result
   double* d_f0_tmp = nullptr;        // [total_f] raw DIO f0 before StoneMask
+  int* d_perm = nullptr;             // [total_f] costly frames first (partition.hpp)
+  int* d_part_cnt = nullptr;         // [total_f / 1024 + 2]
+  int* d_part_n = nullptr;           // [4] number of listed frames
   // D4C tables
   double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
   int* d_utt_total = nullptr;        // [n_utt] LoveTrain randn totals
@@ -123,6 +126,7 @@ struct Batch {
   int* h_pulse_cnt = nullptr;        // pinned
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
   int64_t pulse_rec_cap = 0;
+  int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
   double* d_dc_remover = nullptr;    // [fft_size]
 
   int64_t rng_bound_cheaptrick() const;

@@ -166,6 +166,9 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
   rc = rc ? rc : dev_alloc(&b.d_rng_off2, (size_t)b.total_f);
   rc = rc ? rc : dev_alloc(&b.d_ap0, (size_t)b.total_f);
   rc = rc ? rc : dev_alloc(&b.d_f0_tmp, (size_t)b.total_f);
+  rc = rc ? rc : dev_alloc(&b.d_perm, (size_t)b.total_f);
+  rc = rc ? rc : dev_alloc(&b.d_part_cnt, (size_t)b.total_f / 1024 + 2);
+  rc = rc ? rc : dev_alloc(&b.d_part_n, 4);
   if (rc) { WorldMi355DestroyBatch(hb); return rc; }
   *out = hb;
   return WM_OK;

@@ -19,6 +19,7 @@
 #include "bfft.hpp"
 #include "common.hpp"
 #include "fft.hpp"
+#include "partition.hpp"
 #include "window.hpp"
 
 namespace wm {
@@ -33,6 +34,19 @@ __host__ __device__ inline int d4c_fft_size(int fs) {           // d4c.cpp:344-3
 __host__ __device__ inline int lovetrain_fft_size(int fs) {     // d4c.cpp:261-263
   return (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / kLog2));
 }
+
+// The frames that cost something, listed first (partition.hpp): LoveTrain works on f0 != 0
+// (d4c.cpp:231-233), the body on f0 != 0 && aperiodicity0 > threshold (d4c.cpp:380).
+struct VoicedPred {
+  const double* f0;
+  __device__ bool operator()(int i) const { return f0[i] != 0.0; }
+};
+struct D4cRunPred {
+  const double* f0;
+  const double* ap0;
+  double threshold;
+  __device__ bool operator()(int i) const { return f0[i] != 0.0 && ap0[i] > threshold; }
+};
 
 // MODE 0: LoveTrain consumption 2*round(1.5 fs/max(f0,40))+1 for frames with f0 != 0
 //         (d4c.cpp:231-233, :272-278); writes per-utterance totals to utt_total.
@@ -87,7 +101,7 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, int64_t total_frames,
-    double* __restrict__ ap0) {
+    const int* __restrict__ perm, const int* __restrict__ n_listed, double* __restrict__ ap0) {
   constexpr int N = FL / 2, M = N / 64;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems];
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -95,13 +109,12 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
   FftTw<N> tw;
   tw.init(lane0);
   const int b0 = (int)ceil(100.0 * FL / fs), b1 = (int)ceil(4000.0 * FL / fs), b2 = (int)ceil(7900.0 * FL / fs);
-  WM_FOR_EACH_FRAME(frame, total_frames) {
+  const int n_run = *n_listed;
+  for (int64_t i = n_run + blockIdx.x * 64 + lane0; i < total_frames; i += (int64_t)gridDim.x * 64)
+    ap0[perm[i]] = 0.0;                                     // f0 == 0 (d4c.cpp:231-233)
+  WM_FOR_EACH_LISTED(frame, perm, n_run) {
     const int lane = opaque_lane(lane0);
     const double f0v = f0[frame];
-    if (f0v == 0.0) {
-      if (lane == 0) ap0[frame] = 0.0;
-      continue;
-    }
     const int u = frame_utt[frame];
     const double cf0 = f0v > 40.0 ? f0v : 40.0;
     cpx v[M];
@@ -168,8 +181,8 @@ __global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
-    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap,
-    int dbg) {
+    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, const int* __restrict__ perm,
+    const int* __restrict__ n_listed, double* __restrict__ ap, int dbg) {
   constexpr int NW = 4, NT = 64 * NW;
   constexpr int N = FD / 2, H = FD / 2;
   constexpr int QB = (H + 1 + NT - 1) / NT;        // bins per thread
@@ -192,7 +205,12 @@ __global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
   bf.init(tid);
   const int out_bins = out_fft / 2 + 1;
 
-  WM_FOR_EACH_FRAME(frame, total_frames) {
+  const int n_run = *n_listed;
+  WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
+    double* row = ap + frame * (int64_t)out_bins;
+    for (int i = tid; i < out_bins; i += NT) row[i] = 1.0 - kSafe;
+  }
+  WM_FOR_EACH_LISTED(frame, perm, n_run) {
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];
     bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
@@ -499,8 +517,8 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
-    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, double* __restrict__ ap,
-    int dbg) {
+    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, const int* __restrict__ perm,
+    const int* __restrict__ n_listed, double* __restrict__ ap, int dbg) {
   constexpr int N = FD / 2, M = N / 64, H = FD / 2, MB = M + 1;
   constexpr int kA = H + 2;
   constexpr int kBMax = FD / 16;
@@ -517,7 +535,12 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
   tw.init(lane0);
   const int out_bins = out_fft / 2 + 1;
 
-  WM_FOR_EACH_FRAME(frame, total_frames) {
+  const int n_run = *n_listed;
+  WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
+    double* row = ap + frame * (int64_t)out_bins;
+    for (int i = lane0; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
+  }
+  WM_FOR_EACH_LISTED(frame, perm, n_run) {
     const int lane = opaque_lane(lane0);
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];
@@ -779,11 +802,13 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   hipLaunchKernelGGL(d4c_offsets_kernel<0>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)nullptr,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off2);
+  launch_partition(st, VoicedPred{d_f0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
 #define WM_LT_CASE(FF)                                                                                     \
   case FF: {                                                                                               \
     static const int per_ = persistent_grid(c, d4c_lovetrain_kernel<FF>, 64, (int64_t)1 << 40);            \
     hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,  \
-                       b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, b.d_ap0);       \
+                       b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf,                \
+                       (const int*)b.d_perm, (const int*)b.d_part_n, b.d_ap0);                             \
   } break;
   {
     TimedScope ts_(b.ctx, "d4c_lovetrain_kernel");
@@ -796,6 +821,7 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
 #undef WM_LT_CASE
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
+  launch_partition(st, D4cRunPred{d_f0, b.d_ap0, b.p.d4c_threshold}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
   // Variant choice: the one-wavefront kernel executes about half the instructions per FFT
   // (radix 16/8/8) and wins at fft 1024/2048 even at one wave per SIMD; at fft 4096 it spills and
   // the workgroup-cooperative kernel takes over.  WORLD_MI355_D4C_VARIANT=wave|block overrides.
@@ -807,12 +833,14 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     if (use_block) {                                                                                      \
       hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
                          b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
-                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);               \
+                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,     \
+                         (const int*)b.d_part_n, d_ap, dbg);                                              \
     } else {                                                                                              \
       static const int per_ = persistent_grid(c, d4c_wave_kernel<FF, 2>, 64, (int64_t)1 << 40);           \
       hipLaunchKernelGGL((d4c_wave_kernel<FF, 2>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,          \
                          b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,          \
-                         b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, d_ap, dbg);  \
+                         b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,              \
+                         (const int*)b.d_perm, (const int*)b.d_part_n, d_ap, dbg);                        \
     }                                                                                                     \
     break;
   {

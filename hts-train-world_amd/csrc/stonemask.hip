@@ -9,6 +9,7 @@
 #include "batch.hpp"
 #include "common.hpp"
 #include "fft.hpp"
+#include "partition.hpp"
 
 namespace wm {
 
@@ -93,22 +94,29 @@ __device__ __forceinline__ double sm_fix(const double (&pw)[NB], const double (&
   return numer / (denom + kSafe);
 }
 
+// frames that are refined at all (stonemask.cpp:186-187), listed first (partition.hpp)
+struct StoneMaskPred {
+  const double* f0;
+  double upper;
+  __device__ bool operator()(int i) const { return !(f0[i] <= kFloorF0StoneMask || f0[i] > upper); }
+};
+
 __global__ __launch_bounds__(64) void stonemask_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0, int fs,
-    int lmax, int64_t total_frames, double* __restrict__ out) {
+    int lmax, int64_t total_frames, const int* __restrict__ perm, const int* __restrict__ n_listed,
+    double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm_lds[];
   double* mw = sm_lds;                      // [lmax + 2] main window, then x * diff window
   double* xs = sm_lds + lmax + 2;           // [lmax + 2] samples, then x * main window
   const int lane0 = threadIdx.x;
   const double inv_fs = 1.0 / fs;
-  WM_FOR_EACH_FRAME(frame, total_frames) {
+  const int n_run = *n_listed;
+  for (int64_t i = n_run + blockIdx.x * 64 + lane0; i < total_frames; i += (int64_t)gridDim.x * 64)
+    out[perm[i]] = 0.0;                                            // stonemask.cpp:186-187
+  WM_FOR_EACH_LISTED(frame, perm, n_run) {
     const int lane = opaque_lane(lane0);
     const double f = f0[frame];
-    if (f <= kFloorF0StoneMask || f > fs / 12.0) {                 // stonemask.cpp:186-187
-      if (lane == 0) out[frame] = 0.0;
-      continue;
-    }
     const int u = frame_utt[frame];
     const double* xu = x + x_off[u];
     const int xl = x_len[u];
@@ -182,9 +190,10 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
     per_cu = 4;
   const int64_t resident = (int64_t)c.num_cu * per_cu;
   const int grid = (int)(tf < resident ? tf : resident);
+  launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
   TimedScope ts_(b.ctx, "stonemask_kernel");
   hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, d_out);
+                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, (const int*)b.d_perm, (const int*)b.d_part_n, d_out);
   return wm_check(hipGetLastError());
 }
 

@@ -18,6 +18,7 @@
 #include "batch.hpp"
 #include "common.hpp"
 #include "fft.hpp"
+#include "partition.hpp"
 
 namespace wm {
 
@@ -292,6 +293,11 @@ struct PulseRec {
   double cvuv;        // interpolated vuv at the pulse
 };
 
+struct PulseVoicedPred {                       // synthesis.cpp:197: the pulses that have a periodic response
+  const PulseRec* rec;
+  __device__ bool operator()(int i) const { return rec[i].cvuv > 0.5; }
+};
+
 __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
     const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
     const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift, const double* __restrict__ vuv,
@@ -318,7 +324,7 @@ template <int F>
 __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
-    int64_t p_end, double* __restrict__ resp) {
+    int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + H + 2];
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -327,7 +333,10 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
   FftTw<N> tw;
   tw.init(lane0);
 
-  for (int64_t p = p_begin + blockIdx.x; p < p_end; p += gridDim.x) {
+  // perm lists the chunk's voiced pulses (7 transforms) before its unvoiced ones (4): round-robin over the
+  // list gives every wave the same number of each (partition.hpp)
+  WM_FOR_EACH_LISTED(pi, perm, p_end - p_begin) {
+    const int64_t p = p_begin + pi;
     const int lane = opaque_lane(lane0);
     const PulseRec r = rec[p];                                      // wave-uniform
     const int nf = r.nf;
@@ -609,9 +618,14 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     if (b.d_pulse_rec) (void)hipFree(b.d_pulse_rec);
     b.d_pulse_rec = nullptr;
     b.pulse_rec_cap = 0;
-    rc = wm_check(hipMalloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)(total_p + total_p / 8 + 64)));
+    if (b.d_pulse_perm) (void)hipFree(b.d_pulse_perm);
+    b.d_pulse_perm = nullptr;
+    const int64_t cap = total_p + total_p / 8 + 64;
+    rc = wm_check(hipMalloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
     if (rc) return rc;
-    b.pulse_rec_cap = total_p + total_p / 8 + 64;
+    rc = wm_check(hipMalloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
+    if (rc) return rc;
+    b.pulse_rec_cap = cap;
   }
   {
     int max_np = 0;
@@ -625,11 +639,14 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
     const int64_t np = p1 - p0;
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
+    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
+                     b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm, b.d_pulse_perm + b.pulse_rec_cap);
 #define WM_SY_CASE(FF)                                                                                          \
   case FF: {                                                                                                    \
     static const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
     hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
-                       (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1, c.d_scratch);    \
+                       (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
+                       (const int*)b.d_pulse_perm, c.d_scratch);                                                \
   } break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
