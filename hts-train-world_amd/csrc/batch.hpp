@@ -28,6 +28,7 @@ struct Context {
   int frame_grid = 256 * 8;          // workgroups for grid-stride per-frame kernels
   uint32_t* d_rng = nullptr;         // universal randn table, uint32 sums
   int64_t rng_cap = 0;
+  uint32_t rng_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};   // matlabfunctions.cpp:247-250
   double* d_scratch = nullptr;       // growable scratch (synthesis responses)
   int64_t scratch_cap = 0;           // in doubles
   int ensure_rng(int64_t count);     // grow + (re)generate, returns error code

@@ -22,8 +22,9 @@ void set_error(const char* msg) { g_last_error = msg; }
 
 // xorshift128 stream of the reference's randn(), as uint32 sums of 12 draws
 // (matlabfunctions.cpp:247-277); index k = k-th sample after randn_reseed().
-static void fill_randn_u32(uint32_t* out, int64_t count) {
-  uint32_t x = 123456789u, y = 362436069u, z = 521288629u, w = 88675123u;
+// `st` carries the generator state from one call to the next, so a table can be extended.
+static void fill_randn_u32(uint32_t* out, int64_t count, uint32_t (&st)[4]) {
+  uint32_t x = st[0], y = st[1], z = st[2], w = st[3];
   for (int64_t k = 0; k < count; ++k) {
     uint32_t acc = 0;
     for (int j = 0; j < 12; ++j) {
@@ -34,22 +35,31 @@ static void fill_randn_u32(uint32_t* out, int64_t count) {
     }
     out[k] = acc;
   }
+  st[0] = x; st[1] = y; st[2] = z; st[3] = w;
 }
 
+// The table only ever grows: entries [0, rng_cap) stay, the tail continues the xorshift stream from
+// the saved state (a longer utterance after a shorter one costs its extra entries, not a new table).
 int Context::ensure_rng(int64_t count) {
   if (count <= rng_cap) return WM_OK;
   int64_t cap = count + count / 4 + 4096;
-  std::vector<uint32_t> host((size_t)cap);
-  fill_randn_u32(host.data(), cap);
+  if (cap < 2 * rng_cap) cap = 2 * rng_cap;
+  const int64_t add = cap - rng_cap;
+  std::vector<uint32_t> host((size_t)add);
+  fill_randn_u32(host.data(), add, rng_state);
   // the old table may still be read by kernels in flight on the stream
   int rc = wm_check(hipStreamSynchronize(stream));
   if (rc) return rc;
-  if (d_rng) hipFree(d_rng);
-  d_rng = nullptr;
-  rc = wm_check(hipMalloc((void**)&d_rng, sizeof(uint32_t) * (size_t)cap));
+  uint32_t* grown = nullptr;
+  rc = wm_check(hipMalloc((void**)&grown, sizeof(uint32_t) * (size_t)cap));
   if (rc) return rc;
-  rc = wm_check(hipMemcpy(d_rng, host.data(), sizeof(uint32_t) * (size_t)cap, hipMemcpyHostToDevice));
-  if (rc) return rc;
+  if (rng_cap > 0)
+    rc = wm_check(hipMemcpy(grown, d_rng, sizeof(uint32_t) * (size_t)rng_cap, hipMemcpyDeviceToDevice));
+  if (!rc)
+    rc = wm_check(hipMemcpy(grown + rng_cap, host.data(), sizeof(uint32_t) * (size_t)add, hipMemcpyHostToDevice));
+  if (rc) { (void)hipFree(grown); return rc; }
+  if (d_rng) (void)hipFree(d_rng);
+  d_rng = grown;
   rng_cap = cap;
   return WM_OK;
 }
