@@ -254,6 +254,16 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
     barrier()
     elapsed = time.perf_counter() - t0
     kms = {k: ctx.timing_query(k)[0] / args.steps for k in names}
+    if args.workload == "codec":
+        # the synth CLI's way back (WorldMi355RecipeDecode), outside the timed step: reported beside it
+        lf0, mgc, bap = batch.recipe_features(f0, sp, ap, 50, 25)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            batch.recipe_decode(lf0, mgc, bap)
+        torch.cuda.synchronize()
+        kms["recipe_decode_call_ms (not in value)"] = (time.perf_counter() - t1) * 1e3 / args.steps
+        kms["codec_bap_decode_kernel (not in value)"] = ctx.timing_query("codec_bap_decode_kernel")[0] / args.steps
     tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax, tsum = tt.clone(), tt.clone()

@@ -150,5 +150,7 @@ int launch_compose_cmp(Batch& b, int n_streams, const float* const* d_data, cons
                        const double* const* const* windows, const int* const* window_sizes, float* d_out);
 int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, int spec_dim,
                            int ap_dim, float* d_lf0, float* d_mgc, float* d_bap);
+int launch_recipe_decode(Batch& b, const float* d_lf0, const float* d_mgc, const float* d_bap, int spec_dim,
+                         int ap_dim, double* d_f0, double* d_sp, double* d_ap);
 
 }  // namespace wm

@@ -226,6 +226,10 @@ int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double*
                              int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap) {
   return launch_recipe_features(b->b, f0, sp, ap, spec_dim, ap_dim, lf0, mgc, bap);
 }
+int WorldMi355RecipeDecode(WorldMi355Batch* b, const float* lf0, const float* mgc, const float* bap, int spec_dim,
+                           int ap_dim, double* f0, double* sp, double* ap) {
+  return launch_recipe_decode(b->b, lf0, mgc, bap, spec_dim, ap_dim, f0, sp, ap);
+}
 int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* streams, const int* dims,
                          const int* n_windows, const double* const* const* windows,
                          const int* const* window_sizes, float* out) {

@@ -98,12 +98,17 @@ __global__ __launch_bounds__(64) void codec_code_sp_kernel(const double* __restr
   }
 }
 
-template <int F>
-__global__ __launch_bounds__(64) void codec_decode_sp_kernel(const double* __restrict__ coded, int ndim,
+struct DecodeOpts {          // synth.cpp:198-217 applied around DecodeSpectralEnvelope; identity by default
+  double c0_add;             // added to coefficient 0 before decoding
+  double post_div;           // decoded values divided by this (0 = leave them)
+};
+
+template <int F, class IN>
+__global__ __launch_bounds__(64) void codec_decode_sp_kernel(const IN* __restrict__ coded, int ndim,
                                                              const int* __restrict__ kidx,
                                                              const double* __restrict__ sfrac,
-                                                             const cpx* __restrict__ weight, int64_t total_frames,
-                                                             double* __restrict__ sp) {
+                                                             const cpx* __restrict__ weight, DecodeOpts o,
+                                                             int64_t total_frames, double* __restrict__ sp) {
   constexpr int MD = F / 2, BINS = F / 2 + 1, N = MD, M = N / 64;
   __shared__ __attribute__((aligned(16))) cpx img[FftLds<N>::kElems];
   __shared__ __attribute__((aligned(16))) double knots[MD + 2];
@@ -113,14 +118,15 @@ __global__ __launch_bounds__(64) void codec_decode_sp_kernel(const double* __res
   const double norm = sqrt((double)MD), inv_md = 1.0 / MD;
   for (int64_t frame = blockIdx.x; frame < total_frames; frame += gridDim.x) {
     const int lane = opaque_lane(lane0);
-    const double* crow = coded + frame * (int64_t)ndim;
+    const IN* crow = coded + frame * (int64_t)ndim;
     cpx v[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {                                   // IDCTForCodec :96-106
       const int i = lane + 64 * m;
       v[m] = make_double2(0.0, 0.0);
       if (i < ndim) {
-        const double c = crow[i];
+        double c = (double)crow[i];
+        if (i == 0) c += o.c0_add;
         const cpx w = weight[i];
         v[m] = make_double2(c * w.x * norm, -c * w.y * norm);
       }
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(64) void codec_decode_sp_kernel(const double* __res
     for (int b = lane; b < BINS; b += 64) {
       const int k = kidx[b];
       const double y0 = knots[k - 1];
-      orow[b] = exp((y0 + sfrac[b] * (knots[k] - y0)) * inv_md);
+      const double e = exp((y0 + sfrac[b] * (knots[k] - y0)) * inv_md);
+      orow[b] = o.post_div != 0.0 ? e / o.post_div : e;
     }
     wave_sync();
   }
@@ -320,7 +327,8 @@ int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double
   return code_sp<double>(b, d_sp, ndim, o, d_coded, "codec_code_sp_kernel");
 }
 
-int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp) {
+template <class IN>
+static int decode_sp(Batch& b, const IN* d_coded, int ndim, DecodeOpts o, double* d_sp) {
   const int F = b.p.fft_size;
   if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
   if (ndim < 1 || ndim > F / 2) return WM_ERR_BAD_ARG;
@@ -333,9 +341,9 @@ int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, d
   TimedScope ts_(b.ctx, "codec_decode_sp_kernel");
 #define WM_DEC_CASE(FF)                                                                                      \
   case FF: {                                                                                                 \
-    static const int per_ = persistent_grid(*b.ctx, codec_decode_sp_kernel<FF>, 64, (int64_t)1 << 40);       \
-    hipLaunchKernelGGL(codec_decode_sp_kernel<FF>, dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st,      \
-                       d_coded, ndim, T.d_dec_k, T.d_dec_s, T.d_dec_w, tf, d_sp);                            \
+    static const int per_ = persistent_grid(*b.ctx, codec_decode_sp_kernel<FF, IN>, 64, (int64_t)1 << 40);   \
+    hipLaunchKernelGGL((codec_decode_sp_kernel<FF, IN>), dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st, \
+                       d_coded, ndim, T.d_dec_k, T.d_dec_s, T.d_dec_w, o, tf, d_sp);                         \
   } break;
   switch (F) {
     WM_DEC_CASE(1024)
@@ -343,6 +351,10 @@ int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, d
   }
 #undef WM_DEC_CASE
   return wm_check(hipGetLastError());
+}
+
+int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp) {
+  return decode_sp<double>(b, d_coded, ndim, DecodeOpts{0.0, 0.0}, d_sp);
 }
 
 int launch_code_aperiodicity(Batch& b, const double* d_ap, double* d_coded) {
@@ -383,6 +395,128 @@ int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, con
   if (b.total_f > 0)
     hipLaunchKernelGGL(codec_lf0_kernel, dim3((unsigned)((b.total_f + 255) / 256)), dim3(256), 0, b.ctx->stream, d_f0,
                        b.total_f, d_lf0);
+  return wm_check(hipGetLastError());
+}
+
+// ---- decode side of the synth CLI's coded features (test/synth.cpp:151-256) ------------------------
+// bap rows go through the CLI's SPTK port (test/sptkfunctions.cpp): mgc2sp = freqt (:596-631) from
+// `order` to F/2 coefficients with a = -0.55, c0 -> log(exp(c0)) (gnorm / ignorm with gamma 0, :331-365),
+// then the real part of the F-point DFT of the zero-padded cepstrum (c2sp :256-274); the CLI keeps
+// exp(x[j]) / 1e4 for j < order only (synth.cpp:242-245) and leaves the other bins of the row
+// uninitialised -- they are written as 0.0 here (flagged in INTEGRATION.md).
+//
+// freqt is a two-dimensional recurrence, g_s[j] = g_{s-1}[j-1] + a (g_{s-1}[j] - g_s[j-1]), sequential in
+// both the input step s and the output index j.  It runs as a systolic pipeline: lane s owns input step s
+// and computes its row along j, one element per time step, reading the element lane s-1 produced in the
+// previous time step with a one-lane DPP shift.  Every element is computed by the reference's expression in
+// the reference's order (no FMA contraction; the three cases of :620-625 are one `A + a * B` with selected
+// operands, x - 0.0 being exact), so the cepstrum is bit-identical.  W lanes serve a frame: with
+// order < 32 a wavefront carries two frames side by side.
+// The DFT is wanted at `order` bins only: per bin k the lanes split the coefficients, cos(2 pi k n / F)
+// advances by a rotation per step of W coefficients, and a half- or full-wave sum finishes the bin.
+template <int W>
+__global__ __launch_bounds__(64) void codec_bap_decode_kernel(const float* __restrict__ bap, int ap_dim, int order,
+                                                              int F, double alpha, int64_t total_frames,
+                                                              double* __restrict__ ap) {
+#pragma clang fp contract(off)
+  constexpr int FP = 64 / W;       // frames per wavefront
+  extern __shared__ __attribute__((aligned(16))) double bd_lds[];
+  const int h = F / 2, bins = h + 1;
+  double* ct = bd_lds;                                   // [F] cos(2 pi n / F)
+  const int lane = threadIdx.x, sub = lane / W, s = lane % W;
+  double* c = bd_lds + F + sub * (h + 2);                // [h + 2] transformed cepstrum of this lane's frame
+  for (int n = lane; n < F; n += 64) ct[n] = cospi(2.0 * n / F);
+  const double a = (0.0 - alpha) / (1 - alpha * 0.0);          // mgc2mgc :241 with a2 = 0
+  const double b = 1 - a * a;
+  for (int64_t f0_ = (int64_t)blockIdx.x * FP; f0_ < total_frames; f0_ += (int64_t)gridDim.x * FP) {
+    const int64_t frame = f0_ + sub;
+    const bool live = frame < total_frames;
+    wave_sync();
+    // lane s feeds coefficient order - s (the reference walks c1[order] .. c1[0]); the row holds ap_dim
+    // values, mgc2sp reads order + 1 (one past an even ap_dim: taken as 0)
+    const int ci = order - s;
+    double cin = 0.0;
+    if (live && ci >= 0 && ci < ap_dim) cin = (double)bap[frame * (int64_t)ap_dim + ci];
+    if (ci == 0) cin += 9.210340;                              // synth.cpp:241
+    double last = 0.0, prev_up = 0.0, own_prev = 0.0;
+    const bool row_live = live && s <= order;
+    for (int t = 0; t <= h + order; ++t) {
+      double up = dpp_get<0x138, 0xf, 0xf>(last);              // wave_shr:1 -- lane s reads lane s-1, lane 0 reads 0
+      if (W < 64 && s == 0) up = 0.0;                          // g_{-1} = 0 between two packed frames too
+      const int j = t - s;
+      const double B = up - (j >= 2 ? own_prev : 0.0);
+      const double A = j == 0 ? cin : prev_up * (j == 1 ? b : 1.0);
+      const double val = A + a * B;
+      // a row that has not started (j < 0) or is finished (j > h) computes values nobody reads: its right
+      // neighbour is one step behind it, and j = 0 takes nothing from the row's own state
+      prev_up = up;
+      own_prev = val;
+      last = val;
+      if (row_live && s == order && j >= 0 && j <= h) c[j] = val;
+    }
+    wave_sync();
+    if (live && s == 0) c[0] = log(exp(c[0]));
+    wave_sync();
+    double* row = ap + frame * (int64_t)bins;
+    for (int k = 0; k < order; ++k) {
+      // cos / sin of 2 pi k n / F at n = s, then steps of W coefficients
+      const unsigned m0 = (unsigned)(k * s) & (unsigned)(F - 1), mw = (unsigned)(k * W) & (unsigned)(F - 1);
+      double cc = ct[m0], ss = ct[(m0 + 3u * (unsigned)F / 4u) & (unsigned)(F - 1)];
+      const double cw = ct[mw], sw = ct[(mw + 3u * (unsigned)F / 4u) & (unsigned)(F - 1)];
+      double acc = 0.0;
+      for (int n = s; n <= h; n += W) {
+        acc += c[n] * cc;
+        const double nc = cc * cw - ss * sw;
+        ss = ss * cw + cc * sw;
+        cc = nc;
+      }
+      acc += dpp_get<0x111, 0xf, 0xf>(acc);      // row_shr:1
+      acc += dpp_get<0x112, 0xf, 0xf>(acc);      // row_shr:2
+      acc += dpp_get<0x114, 0xf, 0xf>(acc);      // row_shr:4
+      acc += dpp_get<0x118, 0xf, 0xf>(acc);      // row_shr:8
+      acc += dpp_get<0x142, 0xa, 0xf>(acc);      // row_bcast:15 -> rows 1, 3: lanes 31 / 63 hold their half
+      if (W == 64) acc += dpp_get<0x143, 0xc, 0xf>(acc);   // row_bcast:31 -> lane 63 holds the wave
+      if (live && s == W - 1) row[k] = exp(acc) / 1e4;         // synth.cpp:243-245
+    }
+    if (live)
+      for (int j = order + s; j < bins; j += W) row[j] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void codec_f0_from_lf0_kernel(const float* __restrict__ lf0, int64_t n,
+                                                                double* __restrict__ f0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double l = (double)lf0[i];
+  f0[i] = l != 0 ? exp(l) : 0;                                 // ToF0, synth.cpp:80-88
+}
+
+int launch_recipe_decode(Batch& b, const float* d_lf0, const float* d_mgc, const float* d_bap, int spec_dim,
+                         int ap_dim, double* d_f0, double* d_sp, double* d_ap) {
+  const int F = b.p.fft_size;
+  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  const int order = (ap_dim % 2 == 1) ? ap_dim - 1 : ap_dim;   // synth.cpp:233-235
+  if (ap_dim < 1 || order < 1 || order > 63) return WM_ERR_BAD_ARG;
+  int rc = decode_sp<float>(b, d_mgc, spec_dim, DecodeOpts{-12.0, 1e4}, d_sp);
+  if (rc) return rc;
+  const int64_t tf = b.total_f;
+  if (tf <= 0) return WM_OK;
+  hipStream_t st = b.ctx->stream;
+  {
+    TimedScope ts_(b.ctx, "codec_bap_decode_kernel");
+    const int64_t cap = (int64_t)b.ctx->num_cu * 16;
+    if (order < 32) {
+      const size_t lds = sizeof(double) * (size_t)(F + 2 * (F / 2 + 2));
+      const int64_t pairs = (tf + 1) / 2;
+      hipLaunchKernelGGL(codec_bap_decode_kernel<32>, dim3((unsigned)(pairs < cap ? pairs : cap)), dim3(64), lds, st,
+                         d_bap, ap_dim, order, F, 0.55, tf, d_ap);
+    } else {
+      const size_t lds = sizeof(double) * (size_t)(F + F / 2 + 2);
+      hipLaunchKernelGGL(codec_bap_decode_kernel<64>, dim3((unsigned)(tf < cap ? tf : cap)), dim3(64), lds, st, d_bap,
+                         ap_dim, order, F, 0.55, tf, d_ap);
+    }
+  }
+  hipLaunchKernelGGL(codec_f0_from_lf0_kernel, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, st, d_lf0, tf, d_f0);
   return wm_check(hipGetLastError());
 }
 

@@ -79,6 +79,7 @@ def load_library():
     L.WorldMi355CodeAperiodicity.argtypes = [vp, vp, vp]
     L.WorldMi355DecodeAperiodicity.argtypes = [vp, vp, vp]
     L.WorldMi355RecipeFeatures.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.WorldMi355RecipeDecode.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.WorldMi355ComposeCmp.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.WorldMi355HtkHeader.restype = None
     L.WorldMi355HtkHeader.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -260,6 +261,20 @@ class WorldBatch:
                                                        ap_dim, C.c_void_p(lf0.data_ptr()), C.c_void_p(mgc.data_ptr()),
                                                        C.c_void_p(bap.data_ptr())), "RecipeFeatures")
         return lf0, mgc, bap
+
+    def recipe_decode(self, lf0, mgc, bap):
+        """f0 / sp / ap from the recipe's float32 lf0 / mgc / bap, as the synth CLI rebuilds them
+        (test/synth.cpp:151-256); ap bins beyond the coding order are 0 (uninitialised in the reference)."""
+        import torch
+        for v in (lf0, mgc, bap):
+            assert v.dtype == torch.float32 and v.is_cuda and v.is_contiguous()
+        f0 = torch.empty(self.total_frames, dtype=torch.float64, device="cuda")
+        sp = torch.empty(self.total_frames, self.bins, dtype=torch.float64, device="cuda")
+        ap = torch.empty(self.total_frames, self.bins, dtype=torch.float64, device="cuda")
+        _check(load_library().WorldMi355RecipeDecode(self.handle, C.c_void_p(lf0.data_ptr()), C.c_void_p(mgc.data_ptr()),
+                                                     C.c_void_p(bap.data_ptr()), mgc.shape[1], bap.shape[1],
+                                                     self._p(f0), self._p(sp), self._p(ap)), "RecipeDecode")
+        return f0, sp, ap
 
     def compose_cmp(self, streams):
         """streams: list of (float32 cuda tensor [total_frames][dim], list of window coefficient lists).

@@ -118,6 +118,15 @@ int WorldMi355DecodeAperiodicity(WorldMi355Batch* b, const double* coded, double
  * bap[total_frames][ap_dim] from resident f0 / sp / ap. */
 int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
                              int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap);
+/* The way back, as the synth CLI does it before Synthesis (test/synth.cpp:151-256):
+ *   f0 = exp(lf0), 0 stays 0;  sp = DecodeSpectralEnvelope(mgc with c0 - 12.0) / 1e4;
+ *   ap[.][j] = exp(mgc2sp(bap with c0 + 9.210340, order, alpha 0.55, gamma 0)[j]) / 1e4 for j < order,
+ *   order = ap_dim (minus one when odd), mgc2sp being the CLI's SPTK port (test/sptkfunctions.cpp:186-274,
+ *   :596-631).  The reference leaves bins >= order of every ap row uninitialised (synth.cpp:240-245); they
+ *   are written as 0.0 here.  An even ap_dim makes mgc2sp read one coefficient past the row; it is taken as 0.
+ *   ap_dim <= 64. */
+int WorldMi355RecipeDecode(WorldMi355Batch* b, const float* lf0, const float* mgc, const float* bap, int spec_dim,
+                           int ap_dim, double* f0, double* sp, double* ap);
 
 /* ---- `cmp` composition (data/scripts/window.pl:45-146, addhtkheader.pl:45-82), SURVEY.md section 8(f) rank 3 ----
  * Applies each stream's dynamic-feature windows and lays the results side by side per frame:

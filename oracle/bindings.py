@@ -126,6 +126,35 @@ class Oracle:
                                               _p(out))
         return out
 
+    def freqt(self, c1, m2, a):
+        c1 = _c(c1)
+        out = np.zeros(m2 + 1)
+        self.lib.orc_freqt.argtypes = [_dp, C.c_int, _dp, C.c_int, C.c_double]
+        self.lib.orc_freqt(_p(c1), len(c1) - 1, _p(out), int(m2), float(a))
+        return out
+
+    def mgc2sp(self, mgc, alpha, fft_size, nbins=None):
+        """log-amplitude spectrum (the x output of the CLI's mgc2sp with gamma 0); len(mgc) = order + 1"""
+        mgc = _c(mgc)
+        nbins = fft_size if nbins is None else nbins
+        out = np.zeros(nbins)
+        self.lib.orc_mgc2sp.argtypes = [_dp, C.c_int, C.c_double, C.c_int, C.c_int, _dp]
+        self.lib.orc_mgc2sp(_p(mgc), len(mgc) - 1, float(alpha), int(fft_size), int(nbins), _p(out))
+        return out
+
+    def recipe_decode(self, lf0, mgc, bap, fs, fft_size):
+        """test/synth.cpp:151-256: float32 lf0 / mgc / bap -> f0, sp, ap (ap bins >= order defined as 0)"""
+        lf0 = np.ascontiguousarray(lf0, dtype=np.float32)
+        mgc = np.ascontiguousarray(mgc, dtype=np.float32)
+        bap = np.ascontiguousarray(bap, dtype=np.float32)
+        nf, w = len(lf0), fft_size // 2 + 1
+        f0, sp, ap = np.zeros(nf), np.zeros((nf, w)), np.zeros((nf, w))
+        fp_ = C.POINTER(C.c_float)
+        self.lib.orc_recipe_decode.argtypes = [fp_, fp_, fp_, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+        self.lib.orc_recipe_decode(lf0.ctypes.data_as(fp_), mgc.ctypes.data_as(fp_), bap.ctypes.data_as(fp_), nf,
+                                   int(fs), int(fft_size), mgc.shape[1], bap.shape[1], _p(f0), _p(sp), _p(ap))
+        return f0, sp, ap
+
     def cheaptrick_fft_size(self, fs, f0_floor=71.0):
         return self.lib.orc_cheaptrick_fft_size(fs, f0_floor)
 
@@ -449,3 +478,32 @@ class Reference(WorldCApi):
         out = np.zeros(fft_size // 2 + 1)
         self.lib.LinearSmoothing(_p(spec), width, fs, fft_size, _p(out))
         return out
+
+
+class SptkReference:
+    """The CLIs' SPTK port (test/sptkfunctions.cpp) compiled as it is: mgc2sp / freqt, C++-mangled names."""
+
+    PATH = os.path.join(HERE, "_ref", "libsptk_ref.so")
+
+    @classmethod
+    def available(cls) -> bool:
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        self.lib = L = C.CDLL(self.PATH)
+        self._mgc2sp = L._Z6mgc2spPdiddS_S_i           # void mgc2sp(double*, int, double, double, double*, double*, int)
+        self._mgc2sp.argtypes = [_dp, C.c_int, C.c_double, C.c_double, _dp, _dp, C.c_int]
+        self._freqt = L._Z5freqtPdiS_id                # void freqt(double*, int, double*, int, double)
+        self._freqt.argtypes = [_dp, C.c_int, _dp, C.c_int, C.c_double]
+
+    def freqt(self, c1, m2, a):
+        c1 = _c(c1).copy()
+        out = np.zeros(m2 + 1)
+        self._freqt(_p(c1), len(c1) - 1, _p(out), int(m2), float(a))
+        return out
+
+    def mgc2sp(self, mgc, alpha, fft_size):
+        mgc = _c(mgc).copy()
+        x, y = np.zeros(fft_size), np.zeros(fft_size)
+        self._mgc2sp(_p(mgc), len(mgc) - 1, float(alpha), 0.0, _p(x), _p(y), int(fft_size))
+        return x

@@ -93,6 +93,11 @@ void orc_decode_spectral_envelope(const double *coded, int nf, int fs, int fft_s
 /* ---- cmp composition (data/scripts/window.pl, addhtkheader.pl), world_oracle_codec.c ---- */
 void orc_window_stream(const float *in, int T, int dim, int nwin, const double *const *win,
                        float *out);                                        /* window.pl:45-146 */
+/* decode side of the synth CLI's coded features (test/synth.cpp:151-256, test/sptkfunctions.cpp) */
+void orc_freqt(const double *c1, int m1, double *c2, int m2, double a);            /* sptkfunctions.cpp:596-631 */
+void orc_mgc2sp(const double *mgc, int m, double alpha, int fft_size, int nbins, double *x); /* :186-219, :256-274 */
+void orc_recipe_decode(const float *lf0, const float *mgc, const float *bap, int nf, int fs, int fft_size,
+                       int spec_dim, int ap_dim, double *f0, double *sp, double *ap);
 void orc_htk_header(int nframes, int samprate, int frameshift, int bytes_per_frame, int type,
                     unsigned char *out12);                                 /* addhtkheader.pl:45-82 */
 

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "world_oracle.h"
 
@@ -224,4 +225,80 @@ void orc_htk_header(int nframes, int samprate, int frameshift, int bytes_per_fra
   for (int i = 0; i < 4; ++i) p[4 + i] = ((unsigned char *)&b)[i];
   for (int i = 0; i < 2; ++i) p[8 + i] = ((unsigned char *)&c)[i];
   for (int i = 0; i < 2; ++i) p[10 + i] = ((unsigned char *)&d)[i];
+}
+
+/* ---- decode side of the synth CLI's coded-feature form -----------------------
+ * test/synth.cpp:151-256 turns the recipe's lf0 / mgc / bap back into f0 / sp / ap before Synthesis:
+ *   f0  = exp(lf0), 0 stays 0                                   (ToF0, synth.cpp:80-88, :168-173)
+ *   sp  = DecodeSpectralEnvelope(mgc with c0 - 12.0) / 1e4      (:198-217)
+ *   ap  = exp(mgc2sp(bap with c0 + 9.210340, order, 0.55, 0)) / 1e4, bins 0 .. order-1 ONLY (:231-246),
+ *         order = ap_dim, minus one when ap_dim is odd (:233-235).
+ * The reference leaves bins >= order of every ap row uninitialised (new[] without a fill, :240); that is
+ * a defect of the caller, not something a restatement can reproduce.  Here those bins are defined as 0.0
+ * and flagged in DESIGN.md / INTEGRATION.md.
+ * mgc2sp is the CLI's SPTK port (test/sptkfunctions.cpp:186-219): freqt (:596-631) from `order` to F/2
+ * with a = -0.55, gnorm / gc2gc / ignorm with both gammas 0 (c0 -> log(exp(c0)), :331-365, the rest copied),
+ * then c2sp (:256-274): real part of the F-point DFT of the cepstrum zero-padded to F.               */
+
+void orc_freqt(const double *c1, int m1, double *c2, int m2, double a) {      /* sptkfunctions.cpp:596-631 */
+  double *g = (double *)calloc((size_t)m2 + 1, sizeof(double));
+  double *d = (double *)calloc((size_t)m2 + 1, sizeof(double));
+  const double b = 1 - a * a;
+  for (int i = m1; i >= 0; --i) {           /* the reference counts i = -m1 .. 0 and reads c1[-i] */
+    d[0] = g[0];
+    g[0] = c1[i] + a * d[0];
+    if (m2 >= 1) {
+      d[1] = g[1];
+      g[1] = b * d[0] + a * d[1];
+    }
+    for (int j = 2; j <= m2; ++j) {
+      d[j] = g[j];
+      g[j] = d[j - 1] + a * (d[j] - g[j - 1]);
+    }
+  }
+  memcpy(c2, g, sizeof(double) * ((size_t)m2 + 1));
+  free(g);
+  free(d);
+}
+
+/* log-amplitude spectrum x[0 .. nbins) of a mel-generalised cepstrum with gamma 0 (mgc2sp's x output) */
+void orc_mgc2sp(const double *mgc, int m, double alpha, int fft_size, int nbins, double *x) {
+  const int h = fft_size / 2;
+  double *c = (double *)calloc((size_t)fft_size, sizeof(double));
+  double *re = (double *)malloc(sizeof(double) * ((size_t)h + 1));
+  double *im = (double *)malloc(sizeof(double) * ((size_t)h + 1));
+  orc_freqt(mgc, m, c, h, (0.0 - alpha) / (1 - alpha * 0.0));                 /* mgc2mgc :229-254, a2 = 0 */
+  c[0] = log(exp(c[0]));                                                      /* gnorm + ignorm, gamma 0  */
+  orc_fft_r2c(c, fft_size, re, im);                                           /* c2sp: zero-padded, fftr  */
+  for (int k = 0; k < nbins; ++k) x[k] = k <= h ? re[k] : re[fft_size - k];
+  free(c);
+  free(re);
+  free(im);
+}
+
+void orc_recipe_decode(const float *lf0, const float *mgc, const float *bap, int nf, int fs, int fft_size,
+                       int spec_dim, int ap_dim, double *f0, double *sp, double *ap) {
+  const int w = fft_size / 2 + 1;
+  const int order = (ap_dim % 2 == 1) ? ap_dim - 1 : ap_dim;
+  double *cs = (double *)malloc(sizeof(double) * (size_t)nf * (size_t)spec_dim);
+  double *row = (double *)malloc(sizeof(double) * ((size_t)order + 1));
+  for (int i = 0; i < nf; ++i) {
+    const double l = (double)lf0[i];
+    f0[i] = l != 0 ? exp(l) : 0;
+    for (int j = 0; j < spec_dim; ++j) cs[(size_t)i * spec_dim + j] = (double)mgc[(size_t)i * spec_dim + j];
+    cs[(size_t)i * spec_dim] -= 12.0;
+  }
+  orc_decode_spectral_envelope(cs, nf, fs, fft_size, spec_dim, sp);
+  for (size_t k = 0; k < (size_t)nf * (size_t)w; ++k) sp[k] /= 1e4;
+  for (int i = 0; i < nf; ++i) {
+    /* mgc2sp reads order + 1 coefficients; the row holds ap_dim of them (the CLI's row buffers are longer) */
+    for (int j = 0; j <= order; ++j) row[j] = j < ap_dim ? (double)bap[(size_t)i * ap_dim + j] : 0.0;
+    row[0] += 9.210340;
+    double *out = ap + (size_t)i * w;
+    orc_mgc2sp(row, order, 0.55, fft_size, order, out);
+    for (int j = 0; j < order; ++j) out[j] = exp(out[j]) / 1e4;
+    for (int j = order; j < w; ++j) out[j] = 0.0;                 /* uninitialised in the reference */
+  }
+  free(cs);
+  free(row);
 }

@@ -125,3 +125,27 @@ def test_cmp_windows_vs_reference_scripts(oracle):
         np.testing.assert_array_equal(w.view(np.uint32), g[name + "_windowed"].view(np.uint32))
     sr, shift, byte, kind = (int(v) for v in g["htk_args"])
     assert oracle.htk_header(37, sr, shift, byte, kind) == bytes(g["htk_header"])
+
+
+def test_sptk_mgc2sp_vs_reference_vectors(oracle):
+    """The synth CLI's bap decode (synth.cpp:231-246; sptkfunctions.cpp mgc2sp / freqt): outputs of the CLI's
+    SPTK port, compiled as it is, on the reference's own coded bap rows (oracle/gen_golden_sptk.py)."""
+    g = np.load(os.path.join(GOLDEN, "sptk_mgc2sp.npz"))
+    for name in ("codec_16k", "codec_48k"):
+        F, rows, x = int(g[name + "_fft_size"]), g[name + "_rows"], g[name + "_x"]
+        order = rows.shape[1] - 1
+        np.testing.assert_array_equal(oracle.freqt(rows[len(rows) // 2], F // 2, -0.55), g[name + "_freqt"])
+        got = np.stack([oracle.mgc2sp(r, 0.55, F, order) for r in rows])
+        np.testing.assert_allclose(got, x, atol=1e-12, rtol=0)
+        # and through the whole decode of the float32 feature files
+        c = np.load(os.path.join(GOLDEN, name + ".npz"))
+        f0, sp, ap = oracle.recipe_decode(c["lf0"], c["mgc"], c["bap"], int(c["fs"]), F)
+        np.testing.assert_allclose(ap[::8, :order], np.exp(x) / 1e4, rtol=1e-12, atol=0)
+        assert (ap[:, order:] == 0).all()
+        voiced = c["f0"] > 0
+        assert ((f0 > 0) == voiced).all()
+        np.testing.assert_allclose(f0[voiced], c["f0"][voiced], rtol=1e-6)     # float32 log f0 and back
+        # sp: the reference's DecodeSpectralEnvelope of its own mgc (c0 - 12), / 1e4
+        mg = c["mgc"].astype(np.float64)
+        mg[:, 0] -= 12.0
+        np.testing.assert_allclose(sp, oracle.decode_spectral_envelope(mg, int(c["fs"]), F) / 1e4, rtol=1e-14)

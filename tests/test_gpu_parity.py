@@ -444,3 +444,33 @@ def test_cmp_composition(gpu, pkg, oracle):
     ref = np.concatenate([oracle.window_stream(p, CMP_WINDOWS) for p in parts])
     np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,ap_dim", [(16000, 25), (48000, 25), (16000, 24), (48000, 9), (16000, 41)])
+def test_recipe_decode_against_oracle(gpu, oracle, fs, ap_dim):
+    """The synth CLI's way back from float32 lf0 / mgc / bap (synth.cpp:151-256):
+    exp(lf0), DecodeSpectralEnvelope with the c0 offset and 1e-4 scale, mgc2sp of the CLI's SPTK port for bap."""
+    torch, W, ctx = gpu
+    from test_golden import recipe_pack
+    xs = [sd.make_utterance(i, fs, duration=d) for i, d in ((31, 0.6), (32, 0.9))]
+    rs = [oracle_chain(oracle, x, fs) for x in xs]
+    F = rs[0]["F"]
+    sp, ap, f0 = cat(rs, "sp"), cat(rs, "ap"), cat(rs, "f0")
+    lf0, mgc, bap = recipe_pack(oracle, f0, sp, ap, fs, F, 50, ap_dim)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    g_f0, g_sp, g_ap = (v.cpu().numpy() for v in b.recipe_decode(dev(lf0), dev(mgc), dev(bap)))
+    o_f0, o_sp, o_ap = oracle.recipe_decode(lf0, mgc, bap, fs, F)
+    order = ap_dim - 1 if ap_dim % 2 else ap_dim
+    assert ((g_f0 > 0) == (o_f0 > 0)).all()
+    np.testing.assert_allclose(g_f0, o_f0, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(g_sp, o_sp, rtol=1e-10, atol=0)
+    np.testing.assert_allclose(g_ap[:, :order], o_ap[:, :order], rtol=1e-11, atol=0)
+    assert (g_ap[:, order:] == 0).all() and (o_ap[:, order:] == 0).all()
+    # the decoded set drives Synthesis like any other (bins beyond the order are clamped to 0.001 there)
+    y = b.synthesize(dev(g_f0), dev(g_sp), dev(g_ap)).cpu().numpy()
+    yo = np.concatenate([oracle.synthesis(o_f0[a:e], o_sp[a:e], o_ap[a:e], F, 5.0, fs)
+                         for a, e in zip(b.frame_offsets[:-1], b.frame_offsets[1:])])
+    np.testing.assert_allclose(y, yo, atol=1e-8, rtol=0)
+    b.close()

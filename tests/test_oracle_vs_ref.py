@@ -99,3 +99,18 @@ def test_codec(oracle, reference, fs, F, nd):
     ar2[::2] = -0.1                                             # CheckVUV: mean > -0.5 keeps the default row
     np.testing.assert_allclose(oracle.decode_aperiodicity(ar2, fs, F), reference.decode_aperiodicity(ar2, fs, F),
                                atol=1e-13, rtol=0)
+
+
+def test_sptk_mgc2sp(oracle):
+    """orc_freqt / orc_mgc2sp against the CLI's SPTK port compiled as it is (oracle/_ref/libsptk_ref.so)."""
+    from oracle.bindings import SptkReference
+    if not SptkReference.available():
+        pytest.skip("oracle/_ref/libsptk_ref.so not built")
+    ref = SptkReference()
+    rng = np.random.default_rng(5)
+    for F in (2048, 1024):
+        for m in (24, 10, 34):
+            c = rng.standard_normal(m + 1) * 0.4
+            c[0] = rng.uniform(-4, 9)
+            np.testing.assert_array_equal(oracle.freqt(c, F // 2, -0.55), ref.freqt(c, F // 2, -0.55))
+            np.testing.assert_allclose(oracle.mgc2sp(c, 0.55, F), ref.mgc2sp(c, 0.55, F), atol=1e-13, rtol=0)
