@@ -474,3 +474,27 @@ def test_recipe_decode_against_oracle(gpu, oracle, fs, ap_dim):
                          for a, e in zip(b.frame_offsets[:-1], b.frame_offsets[1:])])
     np.testing.assert_allclose(y, yo, atol=1e-8, rtol=0)
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["zeros", "tiny", "clipped", "long40s"])
+def test_unusual_inputs(gpu, oracle, name):
+    """Digital silence, a 1e-6 amplitude, hard clipping, and a 40 s utterance (DIO's reference FFT size 2^20,
+    8001 frames): whole chain against the oracle, all outputs finite."""
+    torch, W, ctx = gpu
+    fs = 16000
+    x = {"zeros": lambda: np.zeros(8000), "tiny": lambda: sd.make_utterance(3, fs, duration=0.5) * 1e-6,
+         "clipped": lambda: np.clip(sd.make_utterance(6, fs, duration=1.0) * 10, -1, 1),
+         "long40s": lambda: sd.make_utterance(5, fs, duration=40.0)}[name]()
+    r = oracle_chain(oracle, x, fs)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    t, f0, sp, ap = b.analyze(torch.from_numpy(np.ascontiguousarray(x)).cuda())
+    y = b.synthesize(f0, sp, ap)
+    f0, sp, ap, y = (v.cpu().numpy() for v in (f0, sp, ap, y))
+    assert all(np.isfinite(v).all() for v in (f0, sp, ap, y))
+    assert ((f0 > 0) == (r["f0"] > 0)).all()
+    np.testing.assert_allclose(f0, r["f0"], atol=F0_TOL, rtol=0)
+    sp_close(sp, r["sp"])
+    np.testing.assert_allclose(ap, r["ap"], atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y, r["y"], atol=Y_TOL, rtol=0)
+    b.close()

@@ -114,3 +114,22 @@ def test_sptk_mgc2sp(oracle):
             c[0] = rng.uniform(-4, 9)
             np.testing.assert_array_equal(oracle.freqt(c, F // 2, -0.55), ref.freqt(c, F // 2, -0.55))
             np.testing.assert_allclose(oracle.mgc2sp(c, 0.55, F), ref.mgc2sp(c, 0.55, F), atol=1e-13, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["zeros", "tiny", "clipped"])
+def test_unusual_inputs(oracle, reference, name):
+    fs = 16000
+    x = {"zeros": lambda: np.zeros(8000), "tiny": lambda: sd.make_utterance(3, fs, duration=0.5) * 1e-6,
+         "clipped": lambda: np.clip(sd.make_utterance(6, fs, duration=1.0) * 10, -1, 1)}[name]()
+    outs = []
+    for o in (oracle, reference):
+        t, f0 = o.dio(x, fs)
+        f0 = o.stonemask(x, fs, t, f0)
+        sp = o.cheaptrick(x, fs, t, f0)
+        ap = o.d4c(x, fs, t, f0, 1024, 0.0)
+        outs.append((f0, sp, ap, o.synthesis(f0, sp, ap, 1024, 5.0, fs)))
+    for a, b, tol in zip(outs[0], outs[1], (1e-9, None, 1e-10, 1e-10)):
+        if tol is None:
+            np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-300)
+        else:
+            np.testing.assert_allclose(a, b, atol=tol, rtol=0)
