@@ -8,5 +8,5 @@ device-resident ``WorldBatch``.  All compute happens in ``libworld_mi355.so``
 (device memory, streams, torch.distributed).  There is no CPU fallback: if the
 library or a GPU is missing the calls raise.
 """
-from . import world, synth_data, sharding, capi  # noqa: F401
+from . import world, synth_data, sharding, capi, recipe  # noqa: F401
 from .world import WorldBatch, WorldParams, load_library  # noqa: F401

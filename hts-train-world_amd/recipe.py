@@ -1,0 +1,223 @@
+"""Batched stand-in for the recipe's per-utterance loops around the two CLIs.
+
+The reference runs one process per utterance (data/Makefile.in:206-216):
+
+    analysis  WAV  LF0  MGC  BAP  [frame_period [fft_size [spec_dim [ap_dim]]]]   (test/analysis.cpp:243-390)
+    synth     LF0  MGC  BAP  WAV  frame_period fft_size fs [spec_dim [ap_dim]]    (test/synth.cpp:124-262)
+
+Here a whole file list is read, packed into HBM-resident batches, analysed or synthesised in one set of
+launches per batch, and written back in the CLIs' own file formats (SURVEY.md 8(b) "File contract"):
+
+    wav in      16-bit mono PCM, x = s / 2^(nbit-1)                       (test/audioio.cpp:236-249)
+    f0 / lf0    float32 [T]            Hz, or log Hz with 0 for unvoiced when spec_dim != 0
+    sp / mgc    float32 [T][F/2+1]     or [T][spec_dim] coded
+    ap / bap    float32 [T][F/2+1]     or [T][ap_dim] coded
+    wav out     16-bit mono PCM, s = clip(int(y * 32767))                 (test/audioio.cpp:160-167)
+
+Settings are the CLI's: Dio(71-800 Hz, speed 1, allowed_range 0.1) + StoneMask, CheapTrick(q1 -0.15),
+D4C(threshold 0) (analysis.cpp:93-203).  With several ranks (torch.distributed initialised, or WORLD_SIZE in
+the environment) the list is sharded by frame count (sharding.lpt_shards) and every rank writes its own files.
+
+    python -m hts-train-world_amd.recipe analysis --scp jobs.txt --frame-period 5 --fft-size 2048 \\
+           --spec-dim 50 --ap-dim 25          # jobs.txt: one "wav f0 sp ap" per line
+    python -m hts-train-world_amd.recipe synth --scp jobs.txt --frame-period 5 --fft-size 2048 --fs 48000 \\
+           --spec-dim 50 --ap-dim 25          # jobs.txt: one "f0 sp ap wav" per line
+
+There is no CPU path: without a HIP device the library call fails.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import struct
+import sys
+import wave
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import capi, sharding, world as W
+
+MAX_BATCH_FRAMES = 1_500_000          # about 12.3 GB of fp64 sp + ap at F = 1024; far inside 288 GB
+
+
+# ---- file formats -----------------------------------------------------------------------------------------
+def read_wav(path):
+    """x in [-1, 1) and fs, as test/audioio.cpp wavread() hands them over (little-endian two's complement
+    of nbit bits over 2^(nbit-1); the first channel layout is taken as it is: the CLIs assume mono)."""
+    with wave.open(str(path), "rb") as w:
+        nbytes, fs, n = w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if nbytes == 2:
+        s = np.frombuffer(raw, dtype="<i2").astype(np.float64)
+    else:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, nbytes).astype(np.int64)
+        s = sum(b[:, k] << (8 * k) for k in range(nbytes))
+        s = np.where(s >= 1 << (8 * nbytes - 1), s - (1 << (8 * nbytes)), s).astype(np.float64)
+    return s / float(1 << (8 * nbytes - 1)), fs
+
+
+def write_wav(path, y, fs):
+    """test/audioio.cpp wavwrite(): 44-byte header, int16 = clip(trunc(y * 32767))."""
+    s = np.clip(np.trunc(np.asarray(y, dtype=np.float64) * 32767.0), -32768, 32767).astype("<i2")
+    n = len(s)
+    head = b"RIFF" + struct.pack("<I", 36 + n * 2) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, fs, fs * 2, 2, 16)
+    with open(path, "wb") as f:
+        f.write(head + b"data" + struct.pack("<I", n * 2))
+        f.write(s.tobytes())
+
+
+def _f32(path, cols=None):
+    a = np.fromfile(path, dtype=np.float32)
+    return a if cols is None else a.reshape(-1, cols)
+
+
+# ---- batching ---------------------------------------------------------------------------------------------
+def _my_share(costs):
+    """Indices of this rank's jobs (all of them on a single process)."""
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    if world == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world == 1:
+        return list(range(len(costs)))
+    return sharding.lpt_shards(costs, world)[rank]
+
+
+def _batches(order, frames, limit):
+    cur, tot = [], 0
+    for i in order:
+        if cur and tot + frames[i] > limit:
+            yield cur
+            cur, tot = [], 0
+        cur.append(i)
+        tot += frames[i]
+    if cur:
+        yield cur
+
+
+def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ctx=None,
+                   max_batch_frames=MAX_BATCH_FRAMES, io_threads=8):
+    """jobs: [(wav, f0_out, sp_out, ap_out)].  Writes what `analysis wav f0 sp ap frame_period fft_size
+    [spec_dim [ap_dim]]` writes for every job; returns the number of frames analysed by this rank."""
+    import torch
+    jobs = list(jobs)
+    with ThreadPoolExecutor(io_threads) as pool:
+        loaded = list(pool.map(lambda j: read_wav(j[0]), jobs))
+        frames = [sharding.frame_count(len(x), fs, frame_period) for x, fs in loaded]
+        mine = _my_share(frames)
+        own_ctx = ctx is None
+        ctx = ctx or W.Context()
+        done = 0
+        writes = []
+        for fs in sorted({loaded[i][1] for i in mine}):
+            params = W.default_params(fs, frame_period)
+            own_size = capi.cheaptrick_fft_size(fs)                    # GetFFTSizeForCheapTrick at the 71 Hz floor
+            if fft_size not in (0, own_size):
+                # analysis.cpp:157-179 sizes the rows by argv[6] but CheapTrick still runs at its own default
+                # size for fs: any other value makes the reference write past or short of its rows
+                raise ValueError("fft_size %d is not CheapTrick's size for %d Hz (%d)" % (fft_size, fs, own_size))
+            idx = sorted((i for i in mine if loaded[i][1] == fs), key=lambda i: -frames[i])
+            for group in _batches(idx, frames, max_batch_frames):
+                xs = [loaded[i][0] for i in group]
+                b = W.WorldBatch(ctx, params, x_lengths=[len(x) for x in xs])
+                x = torch.from_numpy(np.concatenate(xs)).pin_memory().cuda(non_blocking=True)
+                t, f0, sp, ap = b.analyze(x)
+                if spec_dim:
+                    f0o, spo, apo = b.recipe_features(f0, sp, ap, spec_dim, ap_dim)         # analysis.cpp:292-366
+                else:
+                    f0o, spo, apo = f0.float(), sp.float(), ap.float()                      # :360-390
+                f0h, sph, aph = (v.cpu().numpy() for v in (f0o, spo, apo))
+                fo = b.frame_offsets
+                for k, i in enumerate(group):
+                    a, e = fo[k], fo[k + 1]
+                    for path, arr in zip(jobs[i][1:], (f0h[a:e], sph[a:e], aph[a:e])):
+                        writes.append(pool.submit(np.ascontiguousarray(arr).tofile, path))
+                done += int(b.total_frames)
+                b.close()
+        for w_ in writes:
+            w_.result()
+        if own_ctx:
+            ctx.close()
+    return done
+
+
+def synth_files(jobs, frame_period, fft_size, fs, spec_dim=0, ap_dim=24, ctx=None,
+                max_batch_frames=MAX_BATCH_FRAMES, io_threads=8):
+    """jobs: [(f0_in, sp_in, ap_in, wav_out)].  Writes what `synth f0 sp ap wav frame_period fft_size fs
+    [spec_dim [ap_dim]]` writes.  In the coded form the ap bins beyond the coding order, which the reference
+    leaves uninitialised (synth.cpp:240-245), are 0."""
+    import torch
+    jobs = list(jobs)
+    w = fft_size // 2 + 1
+    frames = [os.path.getsize(j[0]) // 4 for j in jobs]                                     # synth.cpp:151-158
+    mine = _my_share(frames)
+    own_ctx = ctx is None
+    ctx = ctx or W.Context()
+    params = W.default_params(fs, frame_period, fft_size=fft_size)
+    done = 0
+    with ThreadPoolExecutor(io_threads) as pool:
+        writes = []
+        for group in _batches(sorted(mine, key=lambda i: -frames[i]), frames, max_batch_frames):
+            T = [frames[i] for i in group]
+            ylen = [int((t - 1) * frame_period / 1000.0 * fs) + 1 for t in T]              # synth.cpp:259
+            b = W.WorldBatch(ctx, params, f0_lengths=T, y_lengths=ylen)
+            cols = (spec_dim, ap_dim) if spec_dim else (w, w)
+            f0s, sps, aps = zip(*pool.map(lambda i: (_f32(jobs[i][0]), _f32(jobs[i][1], cols[0]),
+                                                     _f32(jobs[i][2], cols[1])), group))
+            dev = lambda parts: torch.from_numpy(np.ascontiguousarray(np.concatenate(parts))).cuda()
+            if spec_dim:
+                f0, sp, ap = b.recipe_decode(dev(f0s), dev(sps), dev(aps))                  # synth.cpp:168-256
+            else:
+                f0, sp, ap = dev(f0s).double(), dev(sps).double(), dev(aps).double()
+            y = b.synthesize(f0, sp, ap).cpu().numpy()
+            yo = b.out_offsets
+            for k, i in enumerate(group):
+                writes.append(pool.submit(write_wav, jobs[i][3], y[yo[k]:yo[k + 1]], fs))
+            done += int(b.total_frames)
+            b.close()
+        for w_ in writes:
+            w_.result()
+    if own_ctx:
+        ctx.close()
+    return done
+
+
+def _read_scp(path):
+    with open(path) as f:
+        rows = [ln.split() for ln in f if ln.strip() and not ln.startswith("#")]
+    bad = [r for r in rows if len(r) != 4]
+    if bad:
+        raise SystemExit("every line needs four paths: %r" % (bad[0],))
+    return [tuple(r) for r in rows]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m hts-train-world_amd.recipe", description=__doc__.split("\n\n")[0])
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name in ("analysis", "synth"):
+        p = sub.add_parser(name)
+        p.add_argument("--scp", required=True, help="job list, four paths per line in the CLI's argument order")
+        p.add_argument("--frame-period", type=float, default=5.0)
+        p.add_argument("--fft-size", type=int, default=0 if name == "analysis" else None, required=name == "synth")
+        p.add_argument("--spec-dim", type=int, default=0, help="0: uncompressed files")
+        p.add_argument("--ap-dim", type=int, default=24)
+        if name == "synth":
+            p.add_argument("--fs", type=int, required=True)
+    a = ap.parse_args(argv)
+    jobs = _read_scp(a.scp)
+    if a.cmd == "analysis":
+        n = analysis_files(jobs, a.frame_period, a.fft_size, a.spec_dim, a.ap_dim)
+    else:
+        n = synth_files(jobs, a.frame_period, a.fft_size, a.fs, a.spec_dim, a.ap_dim)
+    print("complete. %d frames" % n)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,109 @@
+"""The batched file driver (hts-train-world_amd/recipe.py) against the reference's own CLIs run per utterance
+(oracle/_ref/cli/analysis_ref, synth_ref: the recipe's loop, data/Makefile.in:206-216) -- file for file."""
+import importlib
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pkg = importlib.import_module("hts-train-world_amd")
+sd, recipe = pkg.synth_data, pkg.recipe
+from test_cli_relink import cli, run, write_wav as write_wav_py  # noqa: E402
+
+
+def test_wav_formats(tmp_path):
+    """test/audioio.cpp: wavwrite truncates y * 32767 toward zero and clips; wavread divides by 2^(nbit-1)."""
+    y = np.array([0.0, 0.5, -0.5, 0.99999, -0.99999, 1.5, -1.5, 3.05e-5, -3.05e-5, 6.2e-5])
+    recipe.write_wav(tmp_path / "a.wav", y, 16000)
+    raw = open(tmp_path / "a.wav", "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data" and len(raw) == 44 + 2 * len(y)
+    assert struct.unpack("<IHHIIHH", raw[16:36]) == (16, 1, 1, 16000, 32000, 2, 16)
+    s = np.frombuffer(raw[44:], dtype="<i2")
+    np.testing.assert_array_equal(s, [0, 16383, -16383, 32766, -32766, 32767, -32768, 0, 0, 2])
+    x, fs = recipe.read_wav(tmp_path / "a.wav")
+    assert fs == 16000
+    np.testing.assert_array_equal(x, s / 32768.0)
+    # 24-bit PCM
+    vals = np.array([0, 1, -1, 8388607, -8388608, 123456], dtype=np.int64)
+    body = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in vals)
+    head = b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 24000, 3, 24)
+    open(tmp_path / "b.wav", "wb").write(head + b"data" + struct.pack("<I", len(body)) + body)
+    x, fs = recipe.read_wav(tmp_path / "b.wav")
+    np.testing.assert_array_equal(x, vals / 8388608.0)
+
+
+def test_sharing_of_jobs(monkeypatch):
+    costs = [50, 10, 40, 30, 20, 60]
+    assert recipe._my_share(costs) == list(range(6))
+    seen = []
+    for r in range(2):
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("RANK", str(r))
+        seen.append(recipe._my_share(costs))
+    assert sorted(seen[0] + seen[1]) == list(range(6))
+    assert abs(sum(costs[i] for i in seen[0]) - sum(costs[i] for i in seen[1])) <= 10
+    groups = list(recipe._batches([5, 0, 2, 3, 4, 1], costs, 100))
+    assert [i for g in groups for i in g] == [5, 0, 2, 3, 4, 1] and all(sum(costs[i] for i in g) <= 100 for g in groups)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coded", [False, True])
+def test_driver_writes_the_clis_files(gpu, tmp_path, coded):
+    a_ref, s_ref = cli("analysis_ref"), cli("synth_ref")
+    specs = [(16000, 41, 0.9), (16000, 42, 1.7), (48000, 43, 0.8), (16000, 44, 0.25)]
+    extra = (50, 25) if coded else ()
+    jobs, refs = [], []
+    for k, (fs, idx, dur) in enumerate(specs):
+        wav = tmp_path / f"u{k}.wav"
+        write_wav_py(wav, sd.make_utterance(idx, fs, duration=dur), fs)
+        jobs.append((wav, tmp_path / f"u{k}.f0", tmp_path / f"u{k}.sp", tmp_path / f"u{k}.ap"))
+        refs.append((tmp_path / f"r{k}.f0", tmp_path / f"r{k}.sp", tmp_path / f"r{k}.ap"))
+        run(a_ref, wav, *refs[-1], 5, 0, *extra)                       # fft size 0: CheapTrick's own
+    # tiny batches on purpose: several launches, mixed sampling rates
+    n = recipe.analysis_files(jobs, 5.0, 0, *(extra or (0,)), ctx=gpu[2], max_batch_frames=250)
+    assert n == sum(os.path.getsize(r[0]) // 4 for r in refs)
+    for job, ref in zip(jobs, refs):
+        for got, want, tol in zip(job[1:], ref, (1e-6, 2e-6, 2e-6) if coded else (0.0, 0.0, 0.0)):
+            g, w = np.fromfile(got, dtype=np.float32), np.fromfile(want, dtype=np.float32)
+            assert g.shape == w.shape
+            if coded:
+                np.testing.assert_allclose(g, w, atol=tol, rtol=0)
+            else:
+                assert (g != w).mean() < 1e-2                              # one float32 ulp at rounding boundaries
+                np.testing.assert_allclose(g, w, rtol=3e-7, atol=1e-12)
+    if coded:
+        return            # the reference's coded synth reads uninitialised ap bins: nothing to compare file-wise
+    # synth from the reference's files, per sampling rate (one call of the CLI fixes fs and fft size)
+    for fs, F in ((16000, 1024), (48000, 2048)):
+        sel = [k for k, s in enumerate(specs) if s[0] == fs]
+        sj = [(*refs[k], tmp_path / f"u{k}_y.wav") for k in sel]
+        recipe.synth_files(sj, 5.0, F, fs, ctx=gpu[2], max_batch_frames=250)
+        for k, j in zip(sel, sj):
+            run(s_ref, *refs[k], tmp_path / f"r{k}_y.wav", 5, F, fs)
+            a, b = open(j[3], "rb").read(), open(tmp_path / f"r{k}_y.wav", "rb").read()
+            assert a[:44] == b[:44] and len(a) == len(b)
+            ya, yb = np.frombuffer(a[44:], dtype="<i2").astype(int), np.frombuffer(b[44:], dtype="<i2").astype(int)
+            assert np.abs(ya - yb).max() <= 1 and (ya != yb).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_driver_coded_synthesis(gpu, oracle, tmp_path):
+    """synth in the recipe's coded form against the oracle's restatement of synth.cpp:151-256 + Synthesis."""
+    fs, F = 16000, 1024
+    wav = tmp_path / "in.wav"
+    write_wav_py(wav, sd.make_utterance(45, fs, duration=1.2), fs)
+    job = (wav, tmp_path / "a.lf0", tmp_path / "a.mgc", tmp_path / "a.bap")
+    recipe.analysis_files([job], 5.0, F, 50, 25, ctx=gpu[2])
+    recipe.synth_files([(*job[1:], tmp_path / "y.wav")], 5.0, F, fs, 50, 25, ctx=gpu[2])
+    lf0 = np.fromfile(job[1], dtype=np.float32)
+    mgc = np.fromfile(job[2], dtype=np.float32).reshape(-1, 50)
+    bap = np.fromfile(job[3], dtype=np.float32).reshape(-1, 25)
+    f0, sp, ap = oracle.recipe_decode(lf0, mgc, bap, fs, F)
+    y = oracle.synthesis(f0, sp, ap, F, 5.0, fs)
+    want = np.clip(np.trunc(y * 32767.0), -32768, 32767).astype(int)
+    got, gfs = recipe.read_wav(tmp_path / "y.wav")
+    got = np.round(got * 32768).astype(int)
+    assert gfs == fs and got.shape == want.shape
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 1e-3
