@@ -8,5 +8,13 @@ device-resident ``WorldBatch``.  All compute happens in ``libworld_mi355.so``
 (device memory, streams, torch.distributed).  There is no CPU fallback: if the
 library or a GPU is missing the calls raise.
 """
-from . import world, synth_data, sharding, capi, recipe  # noqa: F401
+from . import world, synth_data, sharding, capi  # noqa: F401
 from .world import WorldBatch, WorldParams, load_library  # noqa: F401
+
+
+def __getattr__(name):
+    # `recipe` is also a command (python -m hts-train-world_amd.recipe): imported on first use, not with the package
+    if name == "recipe":
+        import importlib
+        return importlib.import_module(__name__ + ".recipe")
+    raise AttributeError(name)
