@@ -23,6 +23,8 @@ the environment) the list is sharded by frame count (sharding.lpt_shards) and ev
     python -m hts-train-world_amd.recipe synth --scp jobs.txt --frame-period 5 --fft-size 2048 --fs 48000 \\
            --spec-dim 50 --ap-dim 25          # jobs.txt: one "f0 sp ap wav" per line
 
+cmp_files() is the stage after it (data/Makefile.in:244-323: window.pl per stream, merge, addhtkheader.pl).
+
 There is no CPU path: without a HIP device the library call fails.
 """
 from __future__ import annotations
@@ -179,6 +181,64 @@ def synth_files(jobs, frame_period, fft_size, fs, spec_dim=0, ap_dim=24, ctx=Non
             yo = b.out_offsets
             for k, i in enumerate(group):
                 writes.append(pool.submit(write_wav, jobs[i][3], y[yo[k]:yo[k + 1]], fs))
+            done += int(b.total_frames)
+            b.close()
+        for w_ in writes:
+            w_.result()
+    if own_ctx:
+        ctx.close()
+    return done
+
+
+def read_window(path):
+    """data/win/NAME.winK: one line, the number of coefficients then the coefficients (window.pl:70-75)."""
+    with open(path) as f:
+        tok = f.readline().split()
+    n = int(tok[0])
+    return [float(v) for v in tok[1:1 + n]]
+
+
+def cmp_files(jobs, streams, sampling_rate, frame_shift, htk_type=9, ctx=None, max_batch_frames=MAX_BATCH_FRAMES,
+              io_threads=8):
+    """The recipe's `cmp` stage (data/Makefile.in:244-323): window.pl on every stream, the SPTK merge chain, and
+    addhtkheader.pl, for a whole list.
+
+    jobs:    [(stream_file_0, ..., stream_file_k, cmp_out)] -- float32 files [T][dim_s] in the order the recipe
+             merges them (mgc, lf0, bap, vib); the four must have the same T
+    streams: [(dim_s, [window files or coefficient lists])] per stream
+    sampling_rate, frame_shift: addhtkheader.pl's SAMPFREQ and FRAMESHIFT (samples)"""
+    import torch
+    jobs = list(jobs)
+    ns = len(streams)
+    dims = [int(d) for d, _ in streams]
+    wins = [[read_window(w) if isinstance(w, (str, os.PathLike)) else [float(v) for v in w] for w in ws] for _, ws in streams]
+    cols = sum(d * len(w) for d, w in zip(dims, wins))
+    frames = [os.path.getsize(j[0]) // (4 * dims[0]) for j in jobs]
+    mine = _my_share(frames)
+    own_ctx = ctx is None
+    ctx = ctx or W.Context()
+    done = 0
+    with ThreadPoolExecutor(io_threads) as pool:
+        writes = []
+        for group in _batches(sorted(mine, key=lambda i: -frames[i]), frames, max_batch_frames):
+            T = [frames[i] for i in group]
+            b = W.WorldBatch(ctx, W.default_params(sampling_rate, 5.0), f0_lengths=T)
+            dev = []
+            for s_ in range(ns):
+                parts = list(pool.map(lambda i: _f32(jobs[i][s_], dims[s_]), group))
+                for i, a in zip(group, parts):
+                    if len(a) != frames[i]:
+                        raise ValueError("%s has %d frames, %s has %d" % (jobs[i][s_], len(a), jobs[i][0], frames[i]))
+                dev.append((torch.from_numpy(np.ascontiguousarray(np.concatenate(parts))).cuda(), wins[s_]))
+            out = b.compose_cmp(dev).cpu().numpy()
+            fo = b.frame_offsets
+
+            def put(path, rows):
+                with open(path, "wb") as f:
+                    f.write(W.htk_header(len(rows), sampling_rate, frame_shift, 4 * cols, htk_type))
+                    f.write(np.ascontiguousarray(rows).tobytes())
+            for k, i in enumerate(group):
+                writes.append(pool.submit(put, jobs[i][ns], out[fo[k]:fo[k + 1]]))
             done += int(b.total_frames)
             b.close()
         for w_ in writes:

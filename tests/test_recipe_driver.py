@@ -107,3 +107,25 @@ def test_driver_coded_synthesis(gpu, oracle, tmp_path):
     got = np.round(got * 32768).astype(int)
     assert gfs == fs and got.shape == want.shape
     assert np.abs(got - want).max() <= 1 and (got != want).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_driver_cmp_files(gpu, tmp_path):
+    """cmp stage for a file list against the Perl scripts' own outputs (tests/golden/cmp_windows.npz)."""
+    from test_golden import CMP_WINDOWS, GOLDEN, cmp_stream
+    g = np.load(os.path.join(GOLDEN, "cmp_windows.npz"))
+    names = ("mgc", "lf0", "bap")
+    T = int(g["mgc_shape"][0])
+    for k in range(2):                                     # the same utterance twice: two jobs, one batch
+        for n in names:
+            cmp_stream(int(g[n + "_seed"]), T, int(g[n + "_shape"][1]), bool(g[n + "_holes"])).tofile(tmp_path / f"{k}.{n}")
+    for n, w in zip(names, CMP_WINDOWS):                   # window files in the recipe's text form (data/win)
+        for i, c in enumerate(CMP_WINDOWS, 1):
+            open(tmp_path / f"{n}.win{i}", "w").write("%d %s\n" % (len(c), " ".join(repr(v) for v in c)))
+    jobs = [tuple(tmp_path / f"{k}.{n}" for n in names) + (tmp_path / f"{k}.cmp",) for k in range(2)]
+    streams = [(int(g[n + "_shape"][1]), [tmp_path / f"{n}.win{i}" for i in (1, 2, 3)]) for n in names]
+    sr, shift, byte, kind = (int(v) for v in g["htk_args"])
+    assert recipe.cmp_files(jobs, streams, sr, shift, kind, ctx=gpu[2]) == 2 * T
+    want = bytes(g["htk_header"]) + np.concatenate([g[n + "_windowed"] for n in names], axis=1).tobytes()
+    for k in range(2):
+        assert open(tmp_path / f"{k}.cmp", "rb").read() == want
