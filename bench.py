@@ -39,10 +39,12 @@ FLOPS_PER_FRAME = 0.7e6
 # d4c_kernel alone: reads its 80 new samples + t + f0 + ap0 (664 B), writes one ap row (4104 B)
 D4C_BYTES_PER_FRAME = 80 * 8 + 8 + 8 + 8 + 513 * 8
 D4C_FLOPS_PER_VOICED_FRAME = 6 * 2.5 * 2048 * 11   # 6 real FFTs of 2048 (+ scans etc., not counted)
-# PMC FETCH_SIZE of d4c_kernel, separate --pmc pass on 64 utterances (67 884 frames): 827 020 KB
-# (profiles/r01_e_pmc_fetch_size_64utts.csv); 8 B/lane accesses, no gfx950 width correction applied.
-# Read side only: the WRITE_SIZE pass does not complete under rocprofv3 on this pool.
-D4C_FETCH_BYTES_PER_FRAME = 827020.3125 * 1024 / 67884
+# HBM-side bytes of d4c_kernel from the PMC counters, separate --pmc passes (tools/pmc_hbm.sh) on 64 utterances
+# (67 884 frames): FETCH_SIZE 825 078 KB, WRITE_SIZE 1 239 844 KB (profiles/r01_f_pmc_{fetch,write}_size_64utts.csv).
+# WRITE_SIZE is exact for this access width (cheaptrick_kernel in the same pass: 4104 B/frame = 513 doubles);
+# FETCH_SIZE is taken as reported (8 B/lane reads; the guide's x2 correction is for 16 B/lane streaming reads).
+# 14.6 KB/frame of the writes and most of the reads are the kernel's 79 spilled VGPRs going through scratch.
+D4C_HBM_BYTES_PER_FRAME = (825078.0 + 1239844.0) * 1024 / 67884
 
 
 def parse():
@@ -163,9 +165,10 @@ def main():
             "achieved": round(frames * D4C_BYTES_PER_FRAME / d4c_avg_s / 1e9, 3) if d4c_avg_s > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frames * D4C_BYTES_PER_FRAME / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if d4c_avg_s > 0 else None,
-            "traffic": round(frames * D4C_FETCH_BYTES_PER_FRAME),
-            "traffic_note": "HBM-side read bytes per launch from PMC FETCH_SIZE (profiles/r01_e_pmc_fetch_size_64utts.csv, "
-                            "per-frame figure x frames); write side not measured",
+            "traffic": round(frames * D4C_HBM_BYTES_PER_FRAME),
+            "traffic_note": "HBM-side read + write bytes per launch from PMC FETCH_SIZE / WRITE_SIZE (separate passes, "
+                            "profiles/r01_f_pmc_*_size_64utts.csv, per-frame figure x frames); above the algorithmic "
+                            "bytes because 79 spilled VGPRs travel through scratch",
             "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": frames,
             "bytes_per_unit": D4C_BYTES_PER_FRAME,
             "note": "FP64-FFT/LDS bound, not HBM bound (SURVEY.md 8d); fp64 figures beside it",
