@@ -66,6 +66,7 @@ struct HarvestWs {
   double* d_md = nullptr;                      // banded multi-channel contours
   int* d_sec = nullptr;                        // [3][tot_b/4 ...] section descriptors (lo, hi, off)
   double* d_sm = nullptr;                      // smoothing scratch
+  cpx* d_twid = nullptr;                       // [kHvTwid] exp(-2 pi i k / kHvTwid), the refinement's twiddles
   std::vector<void*> owned;
 };
 
@@ -296,6 +297,14 @@ __global__ __launch_bounds__(64) void hv_detect_kernel(const int* __restrict__ b
   if (lane == 0 && cur_max > 0) atomicMax(&ncand1[cur_u], cur_max);
 }
 
+// exp(-2 pi i k / kHvTwid) with the function (and the argument: k / 2^n is exact) the kernels used to call
+// per element, so a lookup returns the same bits
+constexpr int kHvTwid = 2048;
+__global__ __launch_bounds__(256) void hv_twiddle_kernel(cpx* __restrict__ tw) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < kHvTwid) tw[k] = cis_neg2pi((double)k / (double)kHvTwid);
+}
+
 // RefineF0Candidates (harvest.cpp:622-631) over the overlapped candidate table that
 // OverlapF0Candidates (:417-429) would build: slot s = j + ncand1 * blk reads frame k - blk
 // (blk = 1..3) or k + blk - 3 (blk = 4..6); out-of-range or unwritten entries are zero.
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
                                                        const double* __restrict__ offc,
                                                        const int* __restrict__ ncand1_a, double f0_floor,
                                                        double f0_ceil, int lmax, int64_t tot_b,
-                                                       double* __restrict__ rc, double* __restrict__ rs) {
+                                                       const cpx* __restrict__ twid, double* __restrict__ rc,
+                                                       double* __restrict__ rs) {
   extern __shared__ __attribute__((aligned(16))) double mw_all[];   // [4][lmax + 2]
   const int lane0 = threadIdx.x;
   for (int64_t fr = blockIdx.x; fr < tot_b; fr += gridDim.x) {
@@ -384,12 +394,19 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
 #pragma unroll
         for (int sh = 32; sh >= 16; sh >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, sh, 64));
         wave_sync();
-        for (int i0 = 0; i0 < Lmax; i0 += 16) {                     // GetMainWindow :446-456
-          const int i = i0 + l16;
-          if (i < L) {
-            const double tm = ((basic + i) - 1.0) * inv_fs - pos;
-            const double c1 = cospi(2.0 * tm * inv_wlen);           // cos(2 pi tm / wlen); cos(4 pi ..) = 2 c^2 - 1
-            mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+        {
+          // GetMainWindow :446-456.  cos(2 pi tm / wlen) at tm = (basic + i - 1) / fs - pos is evaluated once
+          // per lane (i = l16) and advanced by a rotation per 16 samples (at most 22 steps); cos(4 pi ..) =
+          // 2 c^2 - 1
+          double c1, s1, cd, sd;
+          sincospi(2.0 * (((basic + l16) - 1.0) * inv_fs - pos) * inv_wlen, &s1, &c1);
+          sincospi(2.0 * 16.0 * inv_fs * inv_wlen, &sd, &cd);
+          for (int i0 = 0; i0 < Lmax; i0 += 16) {
+            const int i = i0 + l16;
+            if (i < L) mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+            const double nc = c1 * cd - s1 * sd;
+            s1 = s1 * cd + c1 * sd;
+            c1 = nc;
           }
         }
         wave_sync();
@@ -401,11 +418,16 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
           bin[h] = matlab_round(f0 * fftn / fs * (h + 1));          // FixF0 :515
           mainv[h] = make_double2(0.0, 0.0);
           diffv[h] = make_double2(0.0, 0.0);
-          w[h] = cis_neg2pi((double)((bin[h] * l16) & (fftn - 1)) * inv_fftn);
-          // the step of 16 samples is the twiddle of the row's lane 8, squared
-          const int src8 = (lane & 48) | 8;
-          const cpx hh = make_double2(__shfl(w[h].x, src8, 64), __shfl(w[h].y, src8, 64));
-          st[h] = cmul(hh, hh);
+          // exp(-2 pi i bin i / fftn) at i = l16 and its step of 16 samples: table entries (fftn is a power of
+          // two up to kHvTwid for every f0 above 24 Hz at the decimated rate; a longer transform computes them)
+          if (fftn <= kHvTwid) {
+            const int sc_ = kHvTwid / fftn;
+            w[h] = twid[((bin[h] * l16) & (fftn - 1)) * sc_];
+            st[h] = twid[((bin[h] * 16) & (fftn - 1)) * sc_];
+          } else {
+            w[h] = cis_neg2pi((double)((bin[h] * l16) & (fftn - 1)) * inv_fftn);
+            st[h] = cis_neg2pi((double)((bin[h] * 16) & (fftn - 1)) * inv_fftn);
+          }
         }
         // windowed DFT bins (GetSpectra / GetMainWindow / GetDiffWindow :462-568), four trips per round
         for (int i0 = 0; i0 < Lmax; i0 += 64) {
@@ -1081,6 +1103,11 @@ static int hv_setup(Batch& b) {
   al((void**)&W->d_md, sizeof(double) * (size_t)W->tot_md);
   al((void**)&W->d_sec, sizeof(int) * 3 * ((size_t)W->tot_b / 4 + 8 * (size_t)n_utt + 8));
   al((void**)&W->d_sm, sizeof(double) * (size_t)W->tot_sm);
+  al((void**)&W->d_twid, sizeof(cpx) * (size_t)kHvTwid);
+  if (!rc) {
+    hipLaunchKernelGGL(hv_twiddle_kernel, dim3(kHvTwid / 256), dim3(256), 0, b.ctx->stream, W->d_twid);
+    rc = wm_check(hipGetLastError());
+  }
   return rc;
 }
 
@@ -1147,7 +1174,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     const int grid = (int)(W.tot_b < (int64_t)c.frame_grid ? W.tot_b : (int64_t)c.frame_grid);
     hipLaunchKernelGGL(hv_refine_kernel, dim3(grid), dim3(64), lds, st, W.d_bframe_utt, W.d_boff, W.d_nb1, m,
                        W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, lmax, W.tot_b,
-                       W.d_rc, W.d_rs);
+                       (const cpx*)W.d_twid, W.d_rc, W.d_rs);
   }
   {
     const int64_t items = W.tot_b * m.maxc;
