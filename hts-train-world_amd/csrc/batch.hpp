@@ -83,6 +83,7 @@ struct Batch {
   int* d_perm = nullptr;             // [total_f] costly frames first (partition.hpp)
   int* d_part_cnt = nullptr;         // [total_f / 1024 + 2]
   int* d_part_n = nullptr;           // [4] number of listed frames
+  void* d_sm_twid = nullptr;         // StoneMask's DFT twiddle table (stonemask.hip)
   // D4C tables
   double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
   int* d_utt_total = nullptr;        // [n_utt] LoveTrain randn totals

@@ -18,21 +18,34 @@ constexpr double kFloorF0StoneMask = 40.0;   // constantnumbers.h
 // Sum_i a_i e^{-j 2 pi k i / n} for NB bins k[], both windows at once.  The windowed samples
 // am[i] = x_i * main_window[i], ad[i] = x_i * diff_window[i] are read from LDS (FIRST = false) or
 // produced on the way from the window mw[] and the samples xs[] and left in their place (FIRST).
+// exp(-2 pi i k / kSmTwid), written once per batch with the function the kernel would otherwise call per bin
+// (k / 2^n is exact, so a lookup returns the same bits)
+constexpr int kSmTwid = 8192;
+__global__ __launch_bounds__(256) void sm_twiddle_kernel(cpx* __restrict__ tw) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < kSmTwid) tw[k] = cis_neg2pi((double)k / (double)kSmTwid);
+}
+
 template <int NB, bool FIRST>
 __device__ __forceinline__ void sm_bins(double* ad_mw, double* am_xs, int L, const int (&bin)[NB], int fftn,
-                                        int lane, double (&pw)[NB], double (&num)[NB]) {
+                                        int lane, const cpx* __restrict__ twid, double (&pw)[NB],
+                                        double (&num)[NB]) {
   cpx mainv[NB], diffv[NB], w[NB], st[NB];
   const double inv_fftn = 1.0 / fftn;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     mainv[b] = make_double2(0.0, 0.0);
     diffv[b] = make_double2(0.0, 0.0);
-    // fftn is a power of two: the modulo is a mask and the division an exact multiplication
-    w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
-    // the step of 64 samples is lane 32's twiddle squared (a broadcast and one complex product
-    // instead of a second sincospi evaluated identically by all lanes)
-    const cpx h = make_double2(__shfl(w[b].x, 32, 64), __shfl(w[b].y, 32, 64));
-    st[b] = cmul(h, h);
+    // fftn is a power of two: the modulo is a mask; the twiddle at sample `lane` and its step of 64 samples
+    // are table entries (transforms longer than the table compute them)
+    if (fftn <= kSmTwid) {
+      const int sc = kSmTwid / fftn;
+      w[b] = twid[((bin[b] * lane) & (fftn - 1)) * sc];
+      st[b] = twid[((bin[b] * 64) & (fftn - 1)) * sc];
+    } else {
+      w[b] = cis_neg2pi((double)((bin[b] * lane) & (fftn - 1)) * inv_fftn);
+      st[b] = cis_neg2pi((double)((bin[b] * 64) & (fftn - 1)) * inv_fftn);
+    }
   }
   double carry = 0.0;                                 // mw of the previous trip's last lane
   for (int i = lane; i < ((L + 63) & ~63); i += 64) {
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0, int fs,
     int lmax, int64_t total_frames, const int* __restrict__ perm, const int* __restrict__ n_listed,
-    double* __restrict__ out) {
+    const cpx* __restrict__ twid, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm_lds[];
   double* mw = sm_lds;                      // [lmax + 2] main window, then x * diff window
   double* xs = sm_lds + lmax + 2;           // [lmax + 2] samples, then x * main window
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     double pw2[2], num2[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) bin2[h] = matlab_round(f * fftn / fs * (h + 1));   // :102
-    sm_bins<2, true>(mw, xs, L, bin2, fftn, lane, pw2, num2);
+    sm_bins<2, true>(mw, xs, L, bin2, fftn, lane, twid, pw2, num2);
     const double tent = sm_fix<2>(pw2, num2, bin2, fftn, fs);      // GetTentativeF0 :122-131
     double mean = 0.0;
     if (!(tent <= 0.0 || tent > f * 2)) {
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 #pragma unroll
       for (int h = 0; h < 6; ++h) bin6[h] = matlab_round(tent * fftn / fs * (h + 1));
       wave_sync();
-      sm_bins<6, false>(mw, xs, L, bin6, fftn, lane, pw6, num6);
+      sm_bins<6, false>(mw, xs, L, bin6, fftn, lane, twid, pw6, num6);
       mean = sm_fix<6>(pw6, num6, bin6, fftn, fs);
     }
     if (fabs(mean - f) / f > 0.2) mean = f;                        // :202
@@ -190,10 +203,16 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
     per_cu = 4;
   const int64_t resident = (int64_t)c.num_cu * per_cu;
   const int grid = (int)(tf < resident ? tf : resident);
+  if (!b.d_sm_twid) {
+    int rc = wm_check(hipMalloc(&b.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
+    if (rc) return rc;
+    hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)b.d_sm_twid);
+  }
   launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
   TimedScope ts_(b.ctx, "stonemask_kernel");
   hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, (const int*)b.d_perm, (const int*)b.d_part_n, d_out);
+                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, (const int*)b.d_perm, (const int*)b.d_part_n,
+                     (const cpx*)b.d_sm_twid, d_out);
   return wm_check(hipGetLastError());
 }
 
