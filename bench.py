@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--dur", type=float, nargs=2, default=(2.0, 8.0))
     ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="WorldMi355Analyze then WorldMi355Synthesis instead of WorldMi355AnalyzeSynthesize")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl (= RCCL; the driver's launch) or gloo: rehearsal of the N > 1 control path with several "
                          "ranks sharing one GPU, where RCCL refuses duplicate devices")
@@ -114,8 +116,12 @@ def main():
     frame_counts = np.diff(batch.frame_offsets).tolist()
 
     def step():
-        t, f0, sp, ap = batch.analyze(x, out=outs)
-        batch.synthesize(f0, sp, ap, out=y)
+        if args.separate_calls:
+            t, f0, sp, ap = batch.analyze(x, out=outs)
+            batch.synthesize(f0, sp, ap, out=y)
+        else:
+            # the same launches as one call: Synthesis' f0-only first part runs beside CheapTrick / D4C
+            t, f0, sp, ap, _ = batch.analyze_synthesize(x, out=outs, y=y)
         if args.gather and world > 1:
             # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
             feats = [f0.float(), sp.float(), ap.float()]
@@ -191,8 +197,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: batch of %d synthetic 16 kHz utterances (%g-%g s) per GPU, "
-                                   "Dio+StoneMask+CheapTrick+D4C then Synthesis, fp64, features resident in HBM"
-                                   % (args.utts, args.dur[0], args.dur[1]),
+                                   "Dio+StoneMask+CheapTrick+D4C then Synthesis (%s), fp64, features resident in HBM"
+                                   % (args.utts, args.dur[0], args.dur[1],
+                                      "two calls" if args.separate_calls else
+                                      "one call: Synthesis' f0-only part on a second stream beside CheapTrick/D4C"),
                        "fs": fs, "frame_period_ms": fp, "fft_size": batch.fft_size,
                        "utterances_per_gpu": args.utts, "frames_per_gpu": frames,
                        "parallelism": "utterance-sharded x%d%s" % (world, "+gather" if args.gather else "")},

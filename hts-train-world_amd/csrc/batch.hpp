@@ -33,6 +33,9 @@ struct Context {
   int64_t scratch_cap = 0;           // in doubles
   int ensure_rng(int64_t count);     // grow + (re)generate, returns error code
   int ensure_scratch(int64_t doubles);
+  // second stream + events of launch_analyze_synthesize (created on first use)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_f0 = nullptr, ev_prep = nullptr;
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
   bool timing = false;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> timed;
@@ -130,6 +133,7 @@ struct Batch {
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
   double* d_dc_remover = nullptr;    // [fft_size]
+  int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per response chunk
 
   int64_t rng_bound_cheaptrick() const;
   int64_t rng_bound_d4c() const;
@@ -142,6 +146,10 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
 int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp);
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
+int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);
+int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y);
+int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
+                              double* d_y);
 int codec_num_aperiodicities(int fs);
 int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded);
 int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);

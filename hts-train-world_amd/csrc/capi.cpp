@@ -100,6 +100,9 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.d_rng) hipFree(c.d_rng);
   if (c.d_scratch) hipFree(c.d_scratch);
   if (c.own_stream) hipStreamDestroy(c.stream);
+  if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
+  if (c.ev_f0) hipEventDestroy(c.ev_f0);
+  if (c.ev_prep) hipEventDestroy(c.ev_prep);
   delete h;
 }
 
@@ -255,6 +258,10 @@ int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f
   rc = rc ? rc : launch_cheaptrick(b, x, t, f0, sp);
   rc = rc ? rc : launch_d4c(b, x, t, f0, ap);
   return rc;
+}
+int WorldMi355AnalyzeSynthesize(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
+                                double* ap, double* y) {
+  return launch_analyze_synthesize(hb->b, x, t, f0, sp, ap, y);
 }
 int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
   Context& c = h->c;

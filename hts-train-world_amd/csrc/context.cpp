@@ -77,6 +77,43 @@ int Context::ensure_scratch(int64_t doubles) {
   return WM_OK;
 }
 
+// Analysis followed by Synthesis of the same features (BASELINE.json's metric), as one call.  Identical
+// launches and results; the only difference is where the f0-only first part of Synthesis runs: on a second
+// stream, as soon as StoneMask has produced f0, beside CheapTrick and D4C.  Its kernels are latency chains on
+// one wavefront per utterance (the phase accumulation) plus a host round trip for the pulse count, which would
+// otherwise sit between D4C and the pulse kernel with the machine idle.
+int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
+                              double* d_y) {
+  Context& c = *b.ctx;
+  if (!c.side) {
+    int rc = wm_check(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_f0, hipEventDisableTiming));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_prep, hipEventDisableTiming));
+    if (rc) return rc;
+  }
+  // the randn table may be reallocated when it grows: settle its size before two streams read it
+  int64_t need = b.rng_bound_cheaptrick();
+  if (b.rng_bound_d4c() > need) need = b.rng_bound_d4c();
+  if (b.rng_bound_synthesis() > need) need = b.rng_bound_synthesis();
+  int rc = c.ensure_rng(need);
+  rc = rc ? rc : launch_dio(b, d_x, d_t, b.d_f0_tmp);
+  rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0);
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_f0, c.stream));
+  rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
+  rc = rc ? rc : launch_d4c(b, d_x, d_t, d_f0, d_ap);
+  if (rc) return rc;
+  hipStream_t main_stream = c.stream;
+  rc = wm_check(hipStreamWaitEvent(c.side, c.ev_f0, 0));
+  if (!rc) {
+    c.stream = c.side;                       // the launchers take the context's stream
+    rc = synthesis_prepare(b, d_f0, d_y);
+    if (!rc) rc = wm_check(hipEventRecord(c.ev_prep, c.side));
+    c.stream = main_stream;
+  }
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(main_stream, c.ev_prep, 0));
+  return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
+}
+
 void Context::timing_clear() {
   for (auto& kv : timed)
     for (auto& pr : kv.second) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -551,7 +551,12 @@ __global__ __launch_bounds__(256) void synth_ola_kernel(const int64_t* __restric
   if (live) y[yb + n] = acc;
 }
 
-int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
+// Synthesis in two parts.  synthesis_prepare() is everything that depends on f0 only: sample-rate f0 / vuv,
+// the time base, the pulse list and its per-pulse records; it ends with the one host round trip of the path
+// (the pulse count sizes the response scratch).  synthesis_render() turns sp / ap into responses and overlap-adds
+// them.  launch_synthesis() runs them back to back on the context's stream; launch_analyze_synthesize()
+// (context.cpp) runs the first part on a side stream while CheapTrick and D4C occupy the main one.
+int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int F = b.p.fft_size, fs = b.p.fs;
@@ -606,6 +611,8 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   if (rc) return rc;
   rc = wm_check(hipStreamSynchronize(st));                // poff is a local
   if (rc) return rc;
+  b.syn_total_p = total_p;
+  b.syn_chunk = 0;
   if (total_p == 0) return WM_OK;
   int64_t cap_mb = 4096;
   if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
@@ -634,6 +641,17 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
                        b.d_f_off, b.d_y_off, b.d_pulse_off, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,
                        (PulseRec*)b.d_pulse_rec);
   }
+  b.syn_chunk = chunk;
+  return wm_check(hipGetLastError());
+}
+
+int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int F = b.p.fft_size, fs = b.p.fs;
+  const double fp = b.p.frame_period / 1000.0;
+  const int64_t total_p = b.syn_total_p, chunk = b.syn_chunk;
+  if (total_p == 0) return WM_OK;
   const int ola_tiles = (b.max_y_len + 255) / 256;
   for (int64_t p0 = 0; p0 < total_p; p0 += chunk) {
     const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
@@ -661,6 +679,11 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
                        b.d_pulse_idx, F, p0, p1, c.d_scratch, d_y);
   }
   return wm_check(hipGetLastError());
+}
+
+int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
+  int rc = synthesis_prepare(b, d_f0, d_y);
+  return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
 }
 
 }  // namespace wm

@@ -73,6 +73,7 @@ def load_library():
     L.WorldMi355D4C.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.WorldMi355AnalyzeSynthesize.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.WorldMi355GetNumberOfAperiodicities.argtypes = [C.c_int]
     L.WorldMi355CodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
     L.WorldMi355DecodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
@@ -215,6 +216,18 @@ class WorldBatch:
         _check(load_library().WorldMi355Analyze(self.handle, self._p(x), self._p(t), self._p(f0), self._p(sp),
                                                 self._p(ap)), "Analyze")
         return t, f0, sp, ap
+
+    def analyze_synthesize(self, x, out=None, y=None):
+        """analyze() then synthesize() of its own features as one call: the f0-only part of Synthesis overlaps
+        CheapTrick and D4C on a second stream.  Returns (t, f0, sp, ap, y), bit-identical to the two calls."""
+        if out is None:
+            out = (self._new(self.total_frames), self._new(self.total_frames),
+                   self._new(self.total_frames, self.bins), self._new(self.total_frames, self.bins))
+        t, f0, sp, ap = out
+        y = y if y is not None else self._new(self.total_out)
+        _check(load_library().WorldMi355AnalyzeSynthesize(self.handle, self._p(x), self._p(t), self._p(f0),
+                                                          self._p(sp), self._p(ap), self._p(y)), "AnalyzeSynthesize")
+        return t, f0, sp, ap, y
 
     def synthesize(self, f0, sp, ap, out=None):
         y = out if out is not None else self._new(self.total_out)

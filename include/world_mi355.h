@@ -100,6 +100,12 @@ int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0
 /* Dio -> StoneMask -> CheapTrick -> D4C, as test/analysis.cpp:243-390 chains them. */
 int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
                       double* ap);
+/* Analyze followed by Synthesis of the features it produced -- the round trip BASELINE.json's metric times
+ * (test/analysis.cpp then test/synth.cpp on the same utterances).  Same kernels, same results as the two
+ * calls; the f0-only first part of Synthesis (time base, pulse list, the host round trip for the pulse
+ * count) runs on a second stream beside CheapTrick and D4C instead of after them. */
+int WorldMi355AnalyzeSynthesize(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
+                                double* ap, double* y);
 
 /* ---- Feature codec (externs/WORLD_v2/src/codec.cpp), SURVEY.md section 8(f) ---------------------------
  * All arrays are device pointers over the batch's frames (row-major, frame order of the batch).

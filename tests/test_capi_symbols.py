@@ -31,7 +31,7 @@ def test_headers_declare_the_world_api():
                  "GetNumberOfAperiodicities", "CodeAperiodicity", "DecodeAperiodicity", "CodeSpectralEnvelope",
                  "DecodeSpectralEnvelope", "WorldMi355CodeSpectralEnvelope", "WorldMi355RecipeFeatures", "WorldMi355RecipeDecode",
                  "WorldMi355ComposeCmp", "WorldMi355HtkHeader",
-                 "WorldMi355Analyze", "WorldMi355Synthesis", "WorldMi355CreateBatch"):
+                 "WorldMi355Analyze", "WorldMi355AnalyzeSynthesize", "WorldMi355Synthesis", "WorldMi355CreateBatch"):
         assert want in names, want
 
 

@@ -249,6 +249,10 @@ def test_full_size_properties(gpu, oracle):
     assert np.all(spn > 0) and np.all(np.isfinite(spn))
     assert np.all((apn > 0) & (apn <= 1.0))
     assert np.all(np.isfinite(yn)) and np.abs(yn).max() < 2.0
+    # the fused call (Synthesis' first part on a second stream) gives the same bits as the two calls
+    t2, f02, sp2, ap2, y2 = b.analyze_synthesize(xc)
+    for a, c in zip(r1, (f02, sp2, ap2, y2)):
+        assert torch.equal(a, c)
     # batch invariance: an utterance analysed alone gives the same bits as inside the batch
     u = 17
     b1 = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(xs[u])])
