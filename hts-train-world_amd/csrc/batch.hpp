@@ -134,6 +134,7 @@ struct Batch {
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
   double* d_dc_remover = nullptr;    // [fft_size]
   int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per response chunk
+  bool syn_warm = false;                    // launch_analyze_synthesize has run once on this batch
 
   int64_t rng_bound_cheaptrick() const;
   int64_t rng_bound_d4c() const;
