@@ -143,7 +143,8 @@ struct Batch {
 
 // kernel launchers (one translation unit each)
 int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0);
-int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_out);
+int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_out,
+                     double f0_lower = 0.0);
 int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp);
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);

@@ -254,7 +254,7 @@ int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f
                       double* ap) {
   Batch& b = hb->b;
   int rc = launch_dio(b, x, t, b.d_f0_tmp);
-  rc = rc ? rc : launch_stonemask(b, x, t, b.d_f0_tmp, f0);
+  rc = rc ? rc : launch_stonemask(b, x, t, b.d_f0_tmp, f0, b.p.f0_floor);
   rc = rc ? rc : launch_cheaptrick(b, x, t, f0, sp);
   rc = rc ? rc : launch_d4c(b, x, t, f0, ap);
   return rc;

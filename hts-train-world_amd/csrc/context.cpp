@@ -101,13 +101,13 @@ int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* 
     // hipMalloc of gigabytes stalls kernels running beside it -- take the plain order once
     b.syn_warm = true;
     rc = launch_dio(b, d_x, d_t, b.d_f0_tmp);
-    rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0);
+    rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0, b.p.f0_floor);
     rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
     rc = rc ? rc : launch_d4c(b, d_x, d_t, d_f0, d_ap);
     return rc ? rc : launch_synthesis(b, d_f0, d_sp, d_ap, d_y);
   }
   rc = rc ? rc : launch_dio(b, d_x, d_t, b.d_f0_tmp);
-  rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0);
+  rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0, b.p.f0_floor);
   rc = rc ? rc : wm_check(hipEventRecord(c.ev_f0, c.stream));
   rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
   rc = rc ? rc : launch_d4c(b, d_x, d_t, d_f0, d_ap);

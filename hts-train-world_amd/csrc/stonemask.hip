@@ -111,7 +111,10 @@ __device__ __forceinline__ double sm_fix(const double (&pw)[NB], const double (&
 struct StoneMaskPred {
   const double* f0;
   double upper;
-  __device__ bool operator()(int i) const { return !(f0[i] <= kFloorF0StoneMask || f0[i] > upper); }
+  double lower;        // kFloorF0StoneMask, or the caller's tighter guarantee (frames below it are not expected)
+  __device__ bool operator()(int i) const {
+    return !(f0[i] <= kFloorF0StoneMask || f0[i] > upper) && f0[i] >= lower * (1.0 - 1e-9);
+  }
 };
 
 __global__ __launch_bounds__(64) void stonemask_kernel(
@@ -189,10 +192,17 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
   }
 }
 
-int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_out) {
+// f0_lower: the caller's guarantee that every non-zero f0 is at least this (StoneMask itself accepts anything
+// above 40 Hz, stonemask.cpp:186).  The window scratch is sized for it: behind Dio, whose candidates are
+// confined to [f0_floor, f0_ceil] (dio.cpp:441-452), the windows are at most 3 periods of f0_floor instead of
+// 3 periods of 40 Hz, and twice as many wavefronts fit a CU.
+int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_out,
+                     double f0_lower) {
   Context& c = *b.ctx;
   const int fs = b.p.fs;
-  const int lmax = 2 * (int)(1.5 * fs / kFloorF0StoneMask + 1.0) + 1;
+  const double f_low = f0_lower > kFloorF0StoneMask ? f0_lower : kFloorF0StoneMask;
+  // one bin of slack below the guarantee: hw is a floor of 1.5 fs / f0 + 1
+  const int lmax = 2 * (int)(1.5 * fs / (f_low * (1.0 - 1e-9)) + 1.0) + 1;
   const size_t lds = sizeof(double) * 2 * (size_t)(lmax + 2);
   if (lds > 64 * 1024) return WM_ERR_UNSUPPORTED;
   const int64_t tf = b.total_f;
@@ -208,7 +218,7 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
     if (rc) return rc;
     hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)b.d_sm_twid);
   }
-  launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
+  launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0, f_low > kFloorF0StoneMask ? f_low : 0.0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
   TimedScope ts_(b.ctx, "stonemask_kernel");
   hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
                      b.d_frame_utt, d_t, d_f0, fs, lmax, tf, (const int*)b.d_perm, (const int*)b.d_part_n,
