@@ -134,8 +134,14 @@ __device__ __forceinline__ void filter_tile_events(const double* __restrict__ si
   }
   __syncthreads();
   // ---- zero crossings (ZeroCrossingEngine, dio.cpp:357-393; kinds :402-435) ----
+  // Events are sparse (a few per hundred samples), so their fine positions -- a division each -- are not
+  // computed where they are found (one divergent pass per row and kind, 32 of them, nearly all taken by some
+  // lane).  Each wavefront lists the sample indices of its 512 samples per kind, in order (an event kind
+  // cannot fire on two consecutive samples: at most 256 entries); the transposed tile is dead after the
+  // barrier above and holds the 16 lists.  They are then worked off densely in list order.
+  static_assert(16 * 256 * (int)sizeof(int) <= kBandK * STRIDE * (int)sizeof(double), "event lists fit the tile");
+  int* evl = reinterpret_cast<int*>(zt);                        // [kind][wave][256]
   int cnt[4] = {0, 0, 0, 0};
-  unsigned fbits = 0;
 #pragma unroll
   for (int row = 0; row < 8; ++row) {
     const int li = wv * 512 + row * 64 + lane;
@@ -154,8 +160,9 @@ __device__ __forceinline__ void filter_tile_events(const double* __restrict__ si
     }
 #pragma unroll
     for (int ty = 0; ty < 4; ++ty) {
-      cnt[ty] += __popcll(__ballot(f[ty]));
-      fbits |= (f[ty] ? 1u : 0u) << (4 * row + ty);
+      const unsigned long long bal = __ballot(f[ty]);
+      if (f[ty]) evl[(ty * 4 + wv) * 256 + cnt[ty] + __popcll(bal & ((1ull << lane) - 1ull))] = li;
+      cnt[ty] += __popcll(bal);
     }
   }
   if (lane == 0) {
@@ -166,34 +173,25 @@ __device__ __forceinline__ void filter_tile_events(const double* __restrict__ si
   if (threadIdx.x < 4)
     tile_cnt4[threadIdx.x] = wave_cnt[threadIdx.x][0] + wave_cnt[threadIdx.x][1] + wave_cnt[threadIdx.x][2] +
                              wave_cnt[threadIdx.x][3];
-  int base[4];
 #pragma unroll
   for (int ty = 0; ty < 4; ++ty) {
-    base[ty] = tile * kZcSlot;
-    for (int q = 0; q < wv; ++q) base[ty] += wave_cnt[ty][q];
-  }
-#pragma unroll
-  for (int row = 0; row < 8; ++row) {
-    const int li = wv * 512 + row * 64 + lane;
-    const int i = n0 + li;
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-      const bool f = (fbits >> (4 * row + ty)) & 1u;
-      const unsigned long long bal = __ballot(f);
-      if (f) {
-        const double x0 = s[li], x1 = s[li + 1];
-        double fine;
-        if (ty < 2) {
-          fine = (i + 1) - x0 / (x1 - x0);                      // :378-382
-        } else {
-          const double x2 = s[li + 2];
-          const double p0 = x1 - x0, p1 = x2 - x1;
-          fine = (i + 1) - p0 / (p1 - p0);
-        }
-        const int dst = base[ty] + __popcll(bal & ((1ull << lane) - 1ull));
-        slot[(int64_t)ty * slot_cap + dst] = fine;
+    const int e1 = wave_cnt[ty][0], e2 = e1 + wave_cnt[ty][1], e3 = e2 + wave_cnt[ty][2];
+    const int total = e3 + wave_cnt[ty][3];
+    for (int j = threadIdx.x; j < total; j += 256) {
+      const int q = (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
+      const int first = q == 0 ? 0 : (q == 1 ? e1 : (q == 2 ? e2 : e3));
+      const int li = evl[(ty * 4 + q) * 256 + (j - first)];
+      const int i = n0 + li;
+      const double x0 = s[li], x1 = s[li + 1];
+      double fine;
+      if (ty < 2) {
+        fine = (i + 1) - x0 / (x1 - x0);                        // :378-382
+      } else {
+        const double x2 = s[li + 2];
+        const double p0 = x1 - x0, p1 = x2 - x1;
+        fine = (i + 1) - p0 / (p1 - p0);
       }
-      base[ty] += __popcll(bal);
+      slot[(int64_t)ty * slot_cap + tile * kZcSlot + j] = fine;
     }
   }
 }
