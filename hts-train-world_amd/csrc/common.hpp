@@ -124,6 +124,15 @@ __device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, doubl
   d = readlane_d(r, 48);
 }
 
+// sum over the 16 lanes of a DPP row, returned to every lane of the row
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_get<0x128, 0xf, 0xf>(v);              // row_ror:8
+  v += dpp_get<0x124, 0xf, 0xf>(v);              // row_ror:4
+  v += dpp_get<0x122, 0xf, 0xf>(v);              // row_ror:2
+  v += dpp_get<0x121, 0xf, 0xf>(v);              // row_ror:1
+  return v;
+}
+
 // maximum of NON-NEGATIVE values (lanes without a DPP source contribute 0)
 __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_get<0x111, 0xf, 0xf>(v));

@@ -309,14 +309,6 @@ __global__ __launch_bounds__(256) void hv_twiddle_kernel(cpx* __restrict__ tw) {
 // OverlapF0Candidates (:417-429) would build: slot s = j + ncand1 * blk reads frame k - blk
 // (blk = 1..3) or k + blk - 3 (blk = 4..6); out-of-range or unwritten entries are zero.
 
-// sum over the 16 lanes of a DPP row, returned to every lane of the row
-__device__ __forceinline__ double row_sum16(double v) {
-  v += dpp_get<0x128, 0xf, 0xf>(v);              // row_ror:8
-  v += dpp_get<0x124, 0xf, 0xf>(v);              // row_ror:4
-  v += dpp_get<0x122, 0xf, 0xf>(v);              // row_ror:2
-  v += dpp_get<0x121, 0xf, 0xf>(v);              // row_ror:1
-  return v;
-}
 
 // RefineF0Candidates / GetRefinedF0 (harvest.cpp:434-617).  One wavefront per basic frame.  The
 // candidates of all slots are fetched side by side (lane = slot), empty slots are answered at once,
@@ -458,22 +450,31 @@ __global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ b
             }
           }
         }
-        double numer = 0.0, denom = 0.0, sc = 0.0;
+        // FixF0 :505-528 per harmonic.  The row sums land in every lane of the row; lane h of the row then does
+        // harmonic h's divisions and square root (they used to be done for all six by all lanes), and three
+        // row sums over the harmonics finish the candidate.
+        double mr_h = 0.0, mi_h = 0.0, dr_h = 0.0, di_h = 0.0;
+        int bin_h = 0;
 #pragma unroll
         for (int h = 0; h < 6; ++h) {
           const double mr = row_sum16(mainv[h].x), mi = row_sum16(mainv[h].y);
           const double dr = row_sum16(diffv[h].x), di = row_sum16(diffv[h].y);
-          if (h < nh) {
-            const double num = mr * di - mi * dr;                   // :565-566
-            const double pwv = mr * mr + mi * mi;                   // :567-568
-            const double p = bin[h] <= fftn / 2 ? pwv : 0.0;
-            const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * inv_fftn + num / p * fs / 2.0 / kPi;
-            const double amp = sqrt(p);
-            numer += amp * inst;
-            denom += amp * (h + 1.0);
-            sc += fabs((inst / (h + 1.0) - f0) / f0);
-          }
+          if (l16 == h) { mr_h = mr; mi_h = mi; dr_h = dr; di_h = di; bin_h = bin[h]; }
         }
+        double numer = 0.0, denom = 0.0, sc = 0.0;
+        if (l16 < nh) {
+          const double num = mr_h * di_h - mi_h * dr_h;             // :565-566
+          const double pwv = mr_h * mr_h + mi_h * mi_h;             // :567-568
+          const double p = bin_h <= fftn / 2 ? pwv : 0.0;
+          const double inst = p == 0.0 ? 0.0 : (double)bin_h * fs * inv_fftn + num / p * fs / 2.0 / kPi;
+          const double amp = sqrt(p);
+          numer = amp * inst;
+          denom = amp * (l16 + 1.0);
+          sc = fabs((inst / (l16 + 1.0) - f0) / f0);
+        }
+        numer = row_sum16(numer);
+        denom = row_sum16(denom);
+        sc = row_sum16(sc);
         double rf0 = numer / (denom + kSafe);
         double rscore = 1.0 / (sc / nh + kSafe);
         if (rf0 < f0_floor || rf0 > f0_ceil || rscore < 2.5) { rf0 = 0.0; rscore = 0.0; }   // :610-614

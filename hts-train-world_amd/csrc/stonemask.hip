@@ -87,23 +87,31 @@ __device__ __forceinline__ void sm_bins(double* ad_mw, double* am_xs, int L, con
   }
 }
 
-// FixF0, stonemask.cpp:96-117, from already-evaluated bins.
+// FixF0, stonemask.cpp:96-117, from already-evaluated bins (wave-uniform values).  Lane h does harmonic h's
+// division and square root -- done for every harmonic by every lane they are a fifth of the kernel -- and two
+// row sums over the first NB lanes finish it.
 template <int NB>
 __device__ __forceinline__ double sm_fix(const double (&pw)[NB], const double (&num)[NB], const int (&bin)[NB],
-                                         int fftn, int fs) {
-  double numer = 0.0, denom = 0.0;
+                                         int fftn, int fs, int lane) {
+  static_assert(NB <= 16, "one harmonic per lane of the first row");
   const double inv_fftn = 1.0 / fftn;                 // power of two: exact
   const double fs_over_2pi = fs / 2.0 / kPi;
+  double pw_h = 0.0, num_h = 0.0;
+  int bin_h = 0;
 #pragma unroll
-  for (int h = 0; h < NB; ++h) {
+  for (int h = 0; h < NB; ++h)
+    if (lane == h) { pw_h = pw[h]; num_h = num[h]; bin_h = bin[h]; }
+  double numer = 0.0, denom = 0.0;
+  if (lane < NB) {
     // bins above fftn/2 are an out-of-bounds read in the reference; they count as zero power here
-    const bool ok = bin[h] <= fftn / 2;
-    const double p = ok ? pw[h] : 0.0;
-    const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * inv_fftn + num[h] / p * fs_over_2pi;
+    const double p = bin_h <= fftn / 2 ? pw_h : 0.0;
+    const double inst = p == 0.0 ? 0.0 : (double)bin_h * fs * inv_fftn + num_h / p * fs_over_2pi;
     const double amp = sqrt(p);
-    numer += amp * inst;
-    denom += amp * (h + 1);
+    numer = amp * inst;
+    denom = amp * (lane + 1);
   }
+  numer = readlane_d(row_sum16(numer), 0);
+  denom = readlane_d(row_sum16(denom), 0);
   return numer / (denom + kSafe);
 }
 
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) bin2[h] = matlab_round(f * fftn / fs * (h + 1));   // :102
     sm_bins<2, true>(mw, xs, L, bin2, fftn, lane, twid, pw2, num2);
-    const double tent = sm_fix<2>(pw2, num2, bin2, fftn, fs);      // GetTentativeF0 :122-131
+    const double tent = sm_fix<2>(pw2, num2, bin2, fftn, fs, lane);      // GetTentativeF0 :122-131
     double mean = 0.0;
     if (!(tent <= 0.0 || tent > f * 2)) {
       int bin6[6];
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
       for (int h = 0; h < 6; ++h) bin6[h] = matlab_round(tent * fftn / fs * (h + 1));
       wave_sync();
       sm_bins<6, false>(mw, xs, L, bin6, fftn, lane, twid, pw6, num6);
-      mean = sm_fix<6>(pw6, num6, bin6, fftn, fs);
+      mean = sm_fix<6>(pw6, num6, bin6, fftn, fs, lane);
     }
     if (fabs(mean - f) / f > 0.2) mean = f;                        // :202
     if (lane == 0) out[frame] = mean;
