@@ -89,6 +89,10 @@ def main():
     if args.workers <= 0 and any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")):
         workers = 1      # under rocprofv3 the preloaded tool has already initialised the GPU: do not fork
     xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
+    # the CPU path on all host cores of this process' share, also before the GPU is touched
+    cpu_all = None
+    if (world == 1 and workers > 1 and not args.no_cpu_baseline and args.workload == "analysis_synthesis"):
+        cpu_all = cpu_all_cores(xs, fs, fp, workers, 6 * workers)
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     if args.backend == "gloo":
@@ -207,6 +211,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if cpu_all:
+            line["cpu_baseline_all_cores"] = cpu_all
         if parity:
             line["parity"] = parity
         print(json.dumps(line), flush=True)
@@ -344,6 +350,49 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_CPU_XS = None
+
+
+def _cpu_chain(job):
+    """Worker of cpu_all_cores(): the CPU chain on a slice of the parent's utterances (forked: shared pages)."""
+    lo, hi, fs, fp = job
+    from oracle.bindings import Oracle, Reference
+    lib = Reference() if Reference.available() else Oracle()
+    F = lib.cheaptrick_fft_size(fs)
+    frames = 0
+    t0 = time.perf_counter()
+    for x in _CPU_XS[lo:hi]:
+        t, f0 = lib.dio(x, fs, fp)
+        f0 = lib.stonemask(x, fs, t, f0)
+        sp = lib.cheaptrick(x, fs, t, f0, -0.15, F)
+        ap = lib.d4c(x, fs, t, f0, F, 0.0)
+        lib.synthesis(f0, sp, ap, F, fp, fs)
+        frames += len(f0)
+    return frames, time.perf_counter() - t0, lib.kind
+
+
+def cpu_all_cores(xs, fs, fp, cores, n_utts):
+    """The same CPU chain with one worker process per host core of this box's share, each on its own slice of
+    the first n_utts utterances (the reference is single-threaded: one process per utterance is how the recipe
+    itself would use more cores).  Reported beside the single-thread baseline, not instead of it."""
+    global _CPU_XS
+    import multiprocessing as mp
+    n_utts = min(n_utts, len(xs))
+    per = max(1, n_utts // cores)
+    jobs = [(k * per, min(n_utts, (k + 1) * per), fs, fp) for k in range(cores) if k * per < n_utts]
+    _CPU_XS = xs
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        res = pool.map(_cpu_chain, jobs)
+    wall = time.perf_counter() - t0
+    _CPU_XS = None
+    frames = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {"value": round(frames / slowest, 1), "unit": "frames/s", "cores": len(jobs), "kind": res[0][2],
+            "sample": "%d utterances of the same batch (%d frames) over %d worker processes, slowest worker %.1f s "
+                      "(%.1f s wall with start-up)" % (jobs[-1][1], frames, len(jobs), slowest, wall)}
 
 
 def cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, n_cpu):
