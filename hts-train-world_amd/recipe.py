@@ -91,6 +91,16 @@ def _my_share(costs):
     return sharding.lpt_shards(costs, world)[rank]
 
 
+def _own_context():
+    """A context on this rank's GPU (LOCAL_RANK of a torchrun launch, else the current device)."""
+    import torch
+    local = os.environ.get("LOCAL_RANK")
+    if local is not None:
+        torch.cuda.set_device(int(local))
+        return W.Context(device=int(local))
+    return W.Context()
+
+
 def _batches(order, frames, limit):
     cur, tot = [], 0
     for i in order:
@@ -114,7 +124,7 @@ def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ct
         frames = [sharding.frame_count(len(x), fs, frame_period) for x, fs in loaded]
         mine = _my_share(frames)
         own_ctx = ctx is None
-        ctx = ctx or W.Context()
+        ctx = ctx or _own_context()
         done = 0
         writes = []
         for fs in sorted({loaded[i][1] for i in mine}):
@@ -160,7 +170,7 @@ def synth_files(jobs, frame_period, fft_size, fs, spec_dim=0, ap_dim=24, ctx=Non
     frames = [os.path.getsize(j[0]) // 4 for j in jobs]                                     # synth.cpp:151-158
     mine = _my_share(frames)
     own_ctx = ctx is None
-    ctx = ctx or W.Context()
+    ctx = ctx or _own_context()
     params = W.default_params(fs, frame_period, fft_size=fft_size)
     done = 0
     with ThreadPoolExecutor(io_threads) as pool:
@@ -216,7 +226,7 @@ def cmp_files(jobs, streams, sampling_rate, frame_shift, htk_type=9, ctx=None, m
     frames = [os.path.getsize(j[0]) // (4 * dims[0]) for j in jobs]
     mine = _my_share(frames)
     own_ctx = ctx is None
-    ctx = ctx or W.Context()
+    ctx = ctx or _own_context()
     done = 0
     with ThreadPoolExecutor(io_threads) as pool:
         writes = []
