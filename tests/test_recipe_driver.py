@@ -129,3 +129,32 @@ def test_driver_cmp_files(gpu, tmp_path):
     want = bytes(g["htk_header"]) + np.concatenate([g[n + "_windowed"] for n in names], axis=1).tobytes()
     for k in range(2):
         assert open(tmp_path / f"{k}.cmp", "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_driver_command_line(gpu, tmp_path):
+    """python -m hts-train-world_amd.recipe analysis / synth over a job list, as the recipe would call it."""
+    import sys
+    fs, F = 16000, 1024
+    lines_a, lines_s = [], []
+    for k, dur in enumerate((0.5, 0.8)):
+        wav = tmp_path / f"c{k}.wav"
+        write_wav_py(wav, sd.make_utterance(50 + k, fs, duration=dur), fs)
+        lines_a.append(f"{wav} {tmp_path}/c{k}.lf0 {tmp_path}/c{k}.mgc {tmp_path}/c{k}.bap")
+        lines_s.append(f"{tmp_path}/c{k}.lf0 {tmp_path}/c{k}.mgc {tmp_path}/c{k}.bap {tmp_path}/c{k}_y.wav")
+    (tmp_path / "a.scp").write_text("\n".join(lines_a) + "\n")
+    (tmp_path / "s.scp").write_text("# comment\n" + "\n".join(lines_s) + "\n")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    base = [sys.executable, "-m", "hts-train-world_amd.recipe"]
+    r = subprocess.run(base + ["analysis", "--scp", str(tmp_path / "a.scp"), "--frame-period", "5", "--fft-size", str(F),
+                               "--spec-dim", "50", "--ap-dim", "25"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "complete." in r.stdout, r.stdout + r.stderr
+    r = subprocess.run(base + ["synth", "--scp", str(tmp_path / "s.scp"), "--frame-period", "5", "--fft-size", str(F),
+                               "--fs", str(fs), "--spec-dim", "50", "--ap-dim", "25"], cwd=root, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "complete." in r.stdout, r.stdout + r.stderr
+    for k, dur in enumerate((0.5, 0.8)):
+        T = os.path.getsize(tmp_path / f"c{k}.lf0") // 4
+        assert os.path.getsize(tmp_path / f"c{k}.mgc") == T * 50 * 4 and os.path.getsize(tmp_path / f"c{k}.bap") == T * 25 * 4
+        y, yfs = recipe.read_wav(tmp_path / f"c{k}_y.wav")
+        assert yfs == fs and len(y) == int((T - 1) * 5.0 / 1000.0 * fs) + 1 and np.abs(y).max() > 0.01
