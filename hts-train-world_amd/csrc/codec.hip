@@ -409,23 +409,26 @@ int launch_recipe_features(Batch& b, const double* d_f0, const double* d_sp, con
 // both the input step s and the output index j.  It runs as a systolic pipeline: lane s owns input step s
 // and computes its row along j, one element per time step, reading the element lane s-1 produced in the
 // previous time step with a one-lane DPP shift.  Every element is computed by the reference's expression in
-// the reference's order (no FMA contraction; the three cases of :620-625 are one `A + a * B` with selected
-// operands, x - 0.0 being exact), so the cepstrum is bit-identical.  W lanes serve a frame: with
-// order < 32 a wavefront carries two frames side by side.
-// The DFT is wanted at `order` bins only: per bin k the lanes split the coefficients, cos(2 pi k n / F)
-// advances by a rotation per step of W coefficients, and a half- or full-wave sum finishes the bin.
-template <int W>
+// the reference's order (no FMA contraction), so the cepstrum is bit-identical.  W lanes serve a frame: with
+// order < 32 a wavefront carries two frames side by side.  The loop is issue-bound, so it is split into the
+// start-up steps, where some row is still at one of its two special first elements, and a steady phase of
+// ten instructions per step without selects or exec-mask branches.
+// The spectrum is one real FFT of the zero-padded cepstrum per frame on the whole wavefront (fft.hpp).
+template <int W, int F>
 __global__ __launch_bounds__(64) void codec_bap_decode_kernel(const float* __restrict__ bap, int ap_dim, int order,
-                                                              int F, double alpha, int64_t total_frames,
+                                                              double alpha, int64_t total_frames,
                                                               double* __restrict__ ap) {
 #pragma clang fp contract(off)
   constexpr int FP = 64 / W;       // frames per wavefront
-  extern __shared__ __attribute__((aligned(16))) double bd_lds[];
-  const int h = F / 2, bins = h + 1;
-  double* ct = bd_lds;                                   // [F] cos(2 pi n / F)
+  constexpr int N = F / 2, M = N / 64, h = F / 2, bins = h + 1;
+  constexpr int kC = h + 2 + 64;   // one cepstrum plus 64 dummy slots (see the store in the steady loop)
+  __shared__ __attribute__((aligned(16))) double bd_lds[2 * FftLds<N>::kElems + FP * kC];
+  cpx* img = reinterpret_cast<cpx*>(bd_lds);             // FFT image / spectrum
   const int lane = threadIdx.x, sub = lane / W, s = lane % W;
-  double* c = bd_lds + F + sub * (h + 2);                // [h + 2] transformed cepstrum of this lane's frame
-  for (int n = lane; n < F; n += 64) ct[n] = cospi(2.0 * n / F);
+  double* c_all = bd_lds + 2 * FftLds<N>::kElems;
+  double* c = c_all + sub * kC;                          // [h + 2] transformed cepstrum of this lane's frame
+  FftTw<N> tw;
+  tw.init(lane);
   const double a = (0.0 - alpha) / (1 - alpha * 0.0);          // mgc2mgc :241 with a2 = 0
   const double b = 1 - a * a;
   for (int64_t f0_ = (int64_t)blockIdx.x * FP; f0_ < total_frames; f0_ += (int64_t)gridDim.x * FP) {
@@ -439,45 +442,62 @@ __global__ __launch_bounds__(64) void codec_bap_decode_kernel(const float* __res
     if (live && ci >= 0 && ci < ap_dim) cin = (double)bap[frame * (int64_t)ap_dim + ci];
     if (ci == 0) cin += 9.210340;                              // synth.cpp:241
     double last = 0.0, prev_up = 0.0, own_prev = 0.0;
-    const bool row_live = live && s <= order;
-    for (int t = 0; t <= h + order; ++t) {
+    const bool store_lane = live && s == order;
+    // start-up: until step order + 1 some row is still at its first (j = 0) or second (j = 1) element, which
+    // have their own expressions (:620-623)
+    for (int t = 0; t <= order + 1; ++t) {
       double up = dpp_get<0x138, 0xf, 0xf>(last);              // wave_shr:1 -- lane s reads lane s-1, lane 0 reads 0
       if (W < 64 && s == 0) up = 0.0;                          // g_{-1} = 0 between two packed frames too
       const int j = t - s;
       const double B = up - (j >= 2 ? own_prev : 0.0);
       const double A = j == 0 ? cin : prev_up * (j == 1 ? b : 1.0);
       const double val = A + a * B;
-      // a row that has not started (j < 0) or is finished (j > h) computes values nobody reads: its right
-      // neighbour is one step behind it, and j = 0 takes nothing from the row's own state
+      // a row that has not started (j < 0) computes values nobody reads: its right neighbour is one step
+      // behind it, and j = 0 takes nothing from the row's own state
       prev_up = up;
       own_prev = val;
       last = val;
-      if (row_live && s == order && j >= 0 && j <= h) c[j] = val;
+      if (store_lane && j >= 0) c[j] = val;
+    }
+    // steady state: every row is at j >= 2, the general element g[j] = d[j-1] + a (d[j] - g[j-1]) (:624-625).
+    // A row that is finished (j > h) again computes values nobody reads.  Every lane stores every step -- the
+    // row that carries the result into the cepstrum, the others into a slot of their own -- so the loop has
+    // no exec-mask branch.
+    {
+      double* dst = store_lane ? c + 2 : c_all + sub * kC + (h + 2) + s;
+      const int adv = store_lane ? 1 : 0;
+      for (int t = order + 2; t <= h + order; ++t) {
+        double up = dpp_get<0x138, 0xf, 0xf>(last);
+        if (W < 64 && s == 0) up = 0.0;
+        const double val = prev_up + a * (up - own_prev);
+        prev_up = up;
+        own_prev = val;
+        last = val;
+        *dst = val;
+        dst += adv;
+      }
     }
     wave_sync();
     if (live && s == 0) c[0] = log(exp(c[0]));
     wave_sync();
-    double* row = ap + frame * (int64_t)bins;
-    for (int k = 0; k < order; ++k) {
-      // cos / sin of 2 pi k n / F at n = s, then steps of W coefficients
-      const unsigned m0 = (unsigned)(k * s) & (unsigned)(F - 1), mw = (unsigned)(k * W) & (unsigned)(F - 1);
-      double cc = ct[m0], ss = ct[(m0 + 3u * (unsigned)F / 4u) & (unsigned)(F - 1)];
-      const double cw = ct[mw], sw = ct[(mw + 3u * (unsigned)F / 4u) & (unsigned)(F - 1)];
-      double acc = 0.0;
-      for (int n = s; n <= h; n += W) {
-        acc += c[n] * cc;
-        const double nc = cc * cw - ss * sw;
-        ss = ss * cw + cc * sw;
-        cc = nc;
+    // c2sp (:256-274): the real part of the F-point transform of the cepstrum zero-padded to F, wanted at the
+    // first `order` bins; one real transform per frame on the whole wavefront
+    double mine = 0.0;                                         // bin s of this lane's frame
+#pragma unroll 1
+    for (int q = 0; q < FP; ++q) {
+      const double* cq = c_all + q * kC;
+      cpx v[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        v[m] = make_double2(i0 <= h ? cq[i0] : 0.0, i0 + 1 <= h ? cq[i0 + 1] : 0.0);
       }
-      acc += dpp_get<0x111, 0xf, 0xf>(acc);      // row_shr:1
-      acc += dpp_get<0x112, 0xf, 0xf>(acc);      // row_shr:2
-      acc += dpp_get<0x114, 0xf, 0xf>(acc);      // row_shr:4
-      acc += dpp_get<0x118, 0xf, 0xf>(acc);      // row_shr:8
-      acc += dpp_get<0x142, 0xa, 0xf>(acc);      // row_bcast:15 -> rows 1, 3: lanes 31 / 63 hold their half
-      if (W == 64) acc += dpp_get<0x143, 0xc, 0xf>(acc);   // row_bcast:31 -> lane 63 holds the wave
-      if (live && s == W - 1) row[k] = exp(acc) / 1e4;         // synth.cpp:243-245
+      rfft_forward<N>(v, img, img, tw, lane);
+      if (sub == q && s < order) mine = img[s].x;
+      wave_sync();
     }
+    double* row = ap + frame * (int64_t)bins;
+    if (live && s < order) row[s] = exp(mine) / 1e4;             // synth.cpp:243-245
     if (live)
       for (int j = order + s; j < bins; j += W) row[j] = 0.0;
   }
@@ -505,16 +525,16 @@ int launch_recipe_decode(Batch& b, const float* d_lf0, const float* d_mgc, const
   {
     TimedScope ts_(b.ctx, "codec_bap_decode_kernel");
     const int64_t cap = (int64_t)b.ctx->num_cu * 16;
+    const int64_t units = order < 32 ? (tf + 1) / 2 : tf;
+    const dim3 grid((unsigned)(units < cap ? units : cap));
+#define WM_BAP_CASE(WW, FF)                                                                                   \
+  hipLaunchKernelGGL((codec_bap_decode_kernel<WW, FF>), grid, dim3(64), 0, st, d_bap, ap_dim, order, 0.55, tf, d_ap)
     if (order < 32) {
-      const size_t lds = sizeof(double) * (size_t)(F + 2 * (F / 2 + 2));
-      const int64_t pairs = (tf + 1) / 2;
-      hipLaunchKernelGGL(codec_bap_decode_kernel<32>, dim3((unsigned)(pairs < cap ? pairs : cap)), dim3(64), lds, st,
-                         d_bap, ap_dim, order, F, 0.55, tf, d_ap);
+      if (F == 1024) WM_BAP_CASE(32, 1024); else WM_BAP_CASE(32, 2048);
     } else {
-      const size_t lds = sizeof(double) * (size_t)(F + F / 2 + 2);
-      hipLaunchKernelGGL(codec_bap_decode_kernel<64>, dim3((unsigned)(tf < cap ? tf : cap)), dim3(64), lds, st, d_bap,
-                         ap_dim, order, F, 0.55, tf, d_ap);
+      if (F == 1024) WM_BAP_CASE(64, 1024); else WM_BAP_CASE(64, 2048);
     }
+#undef WM_BAP_CASE
   }
   hipLaunchKernelGGL(codec_f0_from_lf0_kernel, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, st, d_lf0, tf, d_f0);
   return wm_check(hipGetLastError());
