@@ -822,13 +822,14 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
   launch_partition(st, D4cRunPred{d_f0, b.d_ap0, b.p.d4c_threshold}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
-  // Variant choice: the one-wavefront kernel executes about half the instructions per FFT
-  // (radix 16/8/8) and wins at fft 1024/2048 even at one wave per SIMD; at fft 4096 it spills and
-  // the workgroup-cooperative kernel takes over.  WORLD_MI355_D4C_VARIANT=wave|block overrides.
+  // Variant choice: the one-wavefront kernel executes about half the instructions per FFT (radix 16/8/8 or
+  // 16/16/8 in registers) and wins at every size -- at fft 4096 (48 kHz) it runs one wave per SIMD on 512
+  // registers and still spills, but takes 11.8 ms where the workgroup-cooperative kernel takes 31.7 ms
+  // (64 utterances, tools/rate_48k.py).  WORLD_MI355_D4C_VARIANT=wave|block overrides.
   static const int dbg = getenv("WORLD_MI355_D4C_DBG") ? atoi(getenv("WORLD_MI355_D4C_DBG")) : 0;
   static const char* var = getenv("WORLD_MI355_D4C_VARIANT");
-  const bool use_block = var ? (var[0] == 'b') : (FD >= 4096);
-#define WM_D4C_CASE(FF)                                                                                   \
+  const bool use_block = var ? (var[0] == 'b') : false;
+#define WM_D4C_CASE(FF, WV)                                                                               \
   case FF:                                                                                                \
     if (use_block) {                                                                                      \
       hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
@@ -836,8 +837,8 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
                          c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,     \
                          (const int*)b.d_part_n, d_ap, dbg);                                              \
     } else {                                                                                              \
-      static const int per_ = persistent_grid(c, d4c_wave_kernel<FF, 2>, 64, (int64_t)1 << 40);           \
-      hipLaunchKernelGGL((d4c_wave_kernel<FF, 2>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,          \
+      static const int per_ = persistent_grid(c, d4c_wave_kernel<FF, WV>, 64, (int64_t)1 << 40);          \
+      hipLaunchKernelGGL((d4c_wave_kernel<FF, WV>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,         \
                          b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,          \
                          b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,              \
                          (const int*)b.d_perm, (const int*)b.d_part_n, d_ap, dbg);                        \
@@ -846,9 +847,9 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
     switch (FD) {
-      WM_D4C_CASE(1024)
-      WM_D4C_CASE(2048)
-      WM_D4C_CASE(4096)
+      WM_D4C_CASE(1024, 2)
+      WM_D4C_CASE(2048, 2)
+      WM_D4C_CASE(4096, 1)      // 32 complex values per lane and operand: one wave per SIMD, 512 registers
     }
   }
 #undef WM_D4C_CASE
