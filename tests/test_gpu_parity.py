@@ -511,3 +511,30 @@ def test_unusual_inputs(gpu, oracle, name):
     np.testing.assert_allclose(ap, r["ap"], atol=AP_TOL, rtol=0)
     np.testing.assert_allclose(y, r["y"], atol=Y_TOL, rtol=0)
     b.close()
+
+
+@pytest.mark.gpu
+def test_errors_are_reported_not_swallowed(gpu):
+    """Unsupported sizes and bad arguments come back as error codes (raised by the Python mirror), never as a
+    silent fallback or a wrong answer."""
+    torch, W, ctx = gpu
+    fs = 16000
+    n = 8000
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    # CheapTrick / Synthesis sizes outside {1024, 2048}
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, fft_size=512), x_lengths=[n])
+    t, f0 = b.dio(x)
+    with pytest.raises(RuntimeError):
+        b.cheaptrick(x, t, f0)
+    b.close()
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[n])
+    T = b.total_frames
+    lf0 = torch.zeros(T, dtype=torch.float32, device="cuda")
+    mgc = torch.zeros(T, 50, dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError):                      # mgc2sp order beyond one wavefront
+        b.recipe_decode(lf0, mgc, torch.zeros(T, 70, dtype=torch.float32, device="cuda"))
+    with pytest.raises(RuntimeError):                      # more coefficients than mel points
+        b.code_spectral_envelope(torch.ones(T, b.bins, dtype=torch.float64, device="cuda"), 600)
+    with pytest.raises(AssertionError):                    # host-side type check of the mirror
+        b.analyze(x.float())
+    b.close()
