@@ -829,9 +829,21 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   static const int dbg = getenv("WORLD_MI355_D4C_DBG") ? atoi(getenv("WORLD_MI355_D4C_DBG")) : 0;
   static const char* var = getenv("WORLD_MI355_D4C_VARIANT");
   const bool use_block = var ? (var[0] == 'b') : false;
+  const int block_waves = (var && var[0] == 'b' && var[5] >= '1' && var[5] <= '3') ? var[5] - '0' : 3;   // block1|block2|block3
 #define WM_D4C_CASE(FF, WV)                                                                               \
   case FF:                                                                                                \
     if (use_block) {                                                                                      \
+      if (block_waves == 1)                                                                               \
+        hipLaunchKernelGGL((d4c_block_kernel<FF, 1>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,       \
+                           b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,      \
+                           c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,   \
+                           (const int*)b.d_part_n, d_ap, dbg);                                            \
+      else if (block_waves == 2)                                                                          \
+        hipLaunchKernelGGL((d4c_block_kernel<FF, 2>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,       \
+                           b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,      \
+                           c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,   \
+                           (const int*)b.d_part_n, d_ap, dbg);                                            \
+      else                                                                                                \
       hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
                          b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
                          c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,     \

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
 
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
+__global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
     int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
