@@ -538,3 +538,20 @@ def test_errors_are_reported_not_swallowed(gpu):
     with pytest.raises(AssertionError):                    # host-side type check of the mirror
         b.analyze(x.float())
     b.close()
+
+
+@pytest.mark.gpu
+def test_synthesis_in_response_chunks(gpu, monkeypatch):
+    """The per-pulse responses go through a scratch buffer of bounded size; a batch whose pulses do not fit is
+    rendered chunk by chunk.  Same bits whatever the chunk size."""
+    torch, W, ctx = gpu
+    fs = 16000
+    xs = [sd.make_utterance(i, fs, duration=d) for i, d in ((61, 1.3), (62, 0.7), (63, 2.1))]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    t, f0, sp, ap = b.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
+    y_ref = b.synthesize(f0, sp, ap).clone()
+    for mb in ("1", "3"):                                  # 128 and 384 pulses per chunk
+        monkeypatch.setenv("WORLD_MI355_SCRATCH_MB", mb)
+        assert torch.equal(b.synthesize(f0, sp, ap), y_ref)
+        assert torch.equal(b.analyze_synthesize(torch.from_numpy(np.concatenate(xs)).cuda())[4], y_ref)
+    b.close()
