@@ -16,7 +16,9 @@ launches per batch, and written back in the CLIs' own file formats (SURVEY.md 8(
 
 Settings are the CLI's: Dio(71-800 Hz, speed 1, allowed_range 0.1) + StoneMask, CheapTrick(q1 -0.15),
 D4C(threshold 0) (analysis.cpp:93-203).  With several ranks (torch.distributed initialised, or WORLD_SIZE in
-the environment) the list is sharded by frame count (sharding.lpt_shards) and every rank writes its own files.
+the environment) the list is sharded by frame count (sharding.lpt_shards; the counts come from the wav headers, a rank decodes only
+its own utterances) and every rank writes its own files, or -- `--gather`, BASELINE.json configs[3] -- the float32
+features travel to rank 0, which writes them all.
 
     python -m hts-train-world_amd.recipe analysis --scp jobs.txt --frame-period 5 --fft-size 2048 \\
            --spec-dim 50 --ap-dim 25          # jobs.txt: one "wav f0 sp ap" per line
@@ -77,15 +79,7 @@ def _f32(path, cols=None):
 # ---- batching ---------------------------------------------------------------------------------------------
 def _my_share(costs):
     """Indices of this rank's jobs (all of them on a single process)."""
-    rank, world = 0, 1
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            rank, world = dist.get_rank(), dist.get_world_size()
-    except ImportError:
-        pass
-    if world == 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rank, world = _rank_world()
     if world == 1:
         return list(range(len(costs)))
     return sharding.lpt_shards(costs, world)[rank]
@@ -113,32 +107,49 @@ def _batches(order, frames, limit):
         yield cur
 
 
+def wav_header(path):
+    """(sample count, sampling rate) from the header alone: what the partition needs (no samples are decoded)."""
+    with wave.open(str(path), "rb") as w:
+        return w.getnframes(), w.getframerate()
+
+
 def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ctx=None,
-                   max_batch_frames=MAX_BATCH_FRAMES, io_threads=8):
+                   max_batch_frames=MAX_BATCH_FRAMES, io_threads=8, gather=False):
     """jobs: [(wav, f0_out, sp_out, ap_out)].  Writes what `analysis wav f0 sp ap frame_period fft_size
-    [spec_dim [ap_dim]]` writes for every job; returns the number of frames analysed by this rank."""
+    [spec_dim [ap_dim]]` writes for every job; returns the number of frames analysed by this rank.
+
+    Every rank reads the wav HEADERS of the whole list (the partition needs the frame counts), but decodes only the
+    utterances of its own shard, one batch at a time.  gather=False: every rank writes the files of its shard.
+    gather=True (BASELINE.json configs[3]): the float32 slabs go to rank 0 (sweep.ShardedSweep), which writes all files."""
     import torch
     jobs = list(jobs)
     with ThreadPoolExecutor(io_threads) as pool:
-        loaded = list(pool.map(lambda j: read_wav(j[0]), jobs))
-        frames = [sharding.frame_count(len(x), fs, frame_period) for x, fs in loaded]
-        mine = _my_share(frames)
-        own_ctx = ctx is None
-        ctx = ctx or _own_context()
-        done = 0
-        writes = []
-        for fs in sorted({loaded[i][1] for i in mine}):
-            params = W.default_params(fs, frame_period)
+        heads = list(pool.map(lambda j: wav_header(j[0]), jobs))
+        frames = [sharding.frame_count(n, fs, frame_period) for n, fs in heads]
+        for fs in sorted({h[1] for h in heads}):
             own_size = capi.cheaptrick_fft_size(fs)                    # GetFFTSizeForCheapTrick at the 71 Hz floor
             if fft_size not in (0, own_size):
                 # analysis.cpp:157-179 sizes the rows by argv[6] but CheapTrick still runs at its own default
                 # size for fs: any other value makes the reference write past or short of its rows
                 raise ValueError("fft_size %d is not CheapTrick's size for %d Hz (%d)" % (fft_size, fs, own_size))
-            idx = sorted((i for i in mine if loaded[i][1] == fs), key=lambda i: -frames[i])
+        own_ctx = ctx is None
+        ctx = ctx or _own_context()
+        if gather:
+            done = _analysis_gathered(jobs, heads, frame_period, spec_dim, ap_dim, ctx, max_batch_frames, io_threads)
+            if own_ctx:
+                ctx.close()
+            return done
+        mine = _my_share(frames)
+        done = 0
+        writes = []
+        for fs in sorted({heads[i][1] for i in mine}):
+            params = W.default_params(fs, frame_period)
+            idx = sorted((i for i in mine if heads[i][1] == fs), key=lambda i: -frames[i])
             for group in _batches(idx, frames, max_batch_frames):
-                xs = [loaded[i][0] for i in group]
+                xs = [x for x, _ in pool.map(lambda i: read_wav(jobs[i][0]), group)]   # this batch only, dropped after it
                 b = W.WorldBatch(ctx, params, x_lengths=[len(x) for x in xs])
                 x = torch.from_numpy(np.concatenate(xs)).pin_memory().cuda(non_blocking=True)
+                del xs
                 t, f0, sp, ap = b.analyze(x)
                 if spec_dim:
                     f0o, spo, apo = b.recipe_features(f0, sp, ap, spec_dim, ap_dim)         # analysis.cpp:292-366
@@ -156,6 +167,40 @@ def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ct
             w_.result()
         if own_ctx:
             ctx.close()
+    return done
+
+
+def _rank_world():
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    return rank, world
+
+
+def _analysis_gathered(jobs, heads, frame_period, spec_dim, ap_dim, ctx, max_batch_frames, io_threads):
+    """configs[3]'s flow for a file list: shard, analyse, gather-v to rank 0, rank 0 writes (needs an initialised
+    process group when there is more than one rank)."""
+    import torch.distributed as dist
+    from . import sweep
+    rank, world = _rank_world()
+    if world > 1 and not dist.is_initialized():
+        raise RuntimeError("gather=True with WORLD_SIZE > 1 needs torch.distributed to be initialised")
+    backend = dist.get_backend() if world > 1 else "nccl"
+    done = 0
+    for fs in sorted({h[1] for h in heads}):
+        sel = [i for i, h in enumerate(heads) if h[1] == fs]
+        sw = sweep.ShardedSweep(ctx, fs, frame_period, [heads[i][0] for i in sel], rank, world, spec_dim, ap_dim,
+                                max_batch_frames, backend)
+        sw.load(lambda k: read_wav(jobs[sel[k]][0])[0], io_threads)
+        sw.run(sweep.file_sink([jobs[i][1:4] for i in sel]) if rank == 0 else None, io_threads)
+        done += sw.my_frames
+        sw.close()
     return done
 
 
@@ -277,12 +322,20 @@ def main(argv=None):
         p.add_argument("--fft-size", type=int, default=0 if name == "analysis" else None, required=name == "synth")
         p.add_argument("--spec-dim", type=int, default=0, help="0: uncompressed files")
         p.add_argument("--ap-dim", type=int, default=24)
+        if name == "analysis":
+            p.add_argument("--gather", action="store_true",
+                           help="several ranks (torchrun): gather the features to rank 0, which writes every file")
         if name == "synth":
             p.add_argument("--fs", type=int, required=True)
     a = ap.parse_args(argv)
     jobs = _read_scp(a.scp)
     if a.cmd == "analysis":
-        n = analysis_files(jobs, a.frame_period, a.fft_size, a.spec_dim, a.ap_dim)
+        if a.gather and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+            dist.init_process_group(os.environ.get("WM_BACKEND", "nccl"))
+        n = analysis_files(jobs, a.frame_period, a.fft_size, a.spec_dim, a.ap_dim, gather=a.gather)
     else:
         n = synth_files(jobs, a.frame_period, a.fft_size, a.fs, a.spec_dim, a.ap_dim)
     print("complete. %d frames" % n)

@@ -33,12 +33,14 @@ def lpt_shards(costs, world_size: int) -> list[list[int]]:
     return shards
 
 
-def gather_features(tensors, frame_counts, dst: int = 0, group=None):
+def gather_features(tensors, frame_counts, dst: int = 0, group=None, all_counts=None):
     """Gather-v of per-rank feature slabs to ``dst``.
 
     tensors: list of torch tensors whose first dimension is this rank's total frame count
              (e.g. [f0 (T,), sp (T, bins), ap (T, bins)]).
     frame_counts: this rank's per-utterance frame counts (python ints).
+    all_counts: every rank's frame_counts when the caller already knows them (a deterministic plan): skips the
+             all_gather_object, which is a pickled host collective.
     Returns on dst: (list of gathered tensors in rank order, list of per-rank frame-count
     lists); elsewhere None.
     """
@@ -46,8 +48,12 @@ def gather_features(tensors, frame_counts, dst: int = 0, group=None):
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    counts = [None] * world
-    dist.all_gather_object(counts, [int(c) for c in frame_counts], group=group)
+    if all_counts is not None:
+        counts = [[int(c) for c in cs] for cs in all_counts]
+        assert counts[rank] == [int(c) for c in frame_counts]
+    else:
+        counts = [None] * world
+        dist.all_gather_object(counts, [int(c) for c in frame_counts], group=group)
     totals = [sum(c) for c in counts]
     if world == 1:
         return [t for t in tensors], counts

@@ -1,0 +1,198 @@
+"""The recipe's feature-extraction sweep over a corpus, sharded across the GPUs of one node (BASELINE.json configs[3]).
+
+The reference walks the corpus in a shell loop, one `analysis` process per utterance (data/Makefile.in:125-242,
+call site :214).  Utterances are independent, so here
+
+  1. every rank derives the same longest-processing-time partition of the utterance list from the frame counts
+     alone (sharding.lpt_shards; a frame count needs the sample count only -- the wav header, not the samples);
+  2. a rank loads and analyses ITS utterances only, in HBM-resident batches (Dio -> StoneMask -> CheapTrick -> D4C),
+     and turns the features into the on-disk float32 form of the CLI (test/analysis.cpp:360-390 raw f0 / sp / ap,
+     or :292-366 coded lf0 / mgc / bap when spec_dim is given);
+  3. the only exchange: a gather-v of those float32 slabs to rank 0 (grouped send/recv: RCCL over xGMI with the
+     "nccl" backend, every peer on its own link to rank 0; gloo on CPU in the tests);
+  4. rank 0 copies them to pinned host memory and writes the files of every utterance (SURVEY.md 8(b) file contract).
+
+Phases are timed separately (compute / gather / copy to host / file write) because the last two are rank 0's alone
+and bound the strong scaling of the sweep, whatever the kernels do.
+
+There is no CPU path: the analysis is libworld_mi355.so's.
+"""
+from __future__ import annotations
+
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import capi, sharding, world as W
+
+MAX_BATCH_FRAMES = 1_500_000          # about 12.3 GB of fp64 sp + ap at F = 1024; far inside 288 GB
+
+
+def batches(order, frames, limit):
+    """Consecutive groups of `order` whose frame counts stay within `limit` (a single larger utterance is its own group)."""
+    cur, tot = [], 0
+    for i in order:
+        if cur and tot + frames[i] > limit:
+            yield cur
+            cur, tot = [], 0
+        cur.append(i)
+        tot += frames[i]
+    if cur:
+        yield cur
+
+
+class ShardedSweep:
+    """One corpus, one sampling rate, `world` ranks.  Every rank builds the same plan; `load()` puts this rank's
+    waveforms into HBM; `run()` is one pass: analyse, gather to rank 0, write."""
+
+    def __init__(self, ctx, fs, frame_period, sample_counts, rank=0, world=1, spec_dim=0, ap_dim=24,
+                 max_batch_frames=MAX_BATCH_FRAMES, backend="nccl", rounds=1, writers="rank0"):
+        """rounds > 1 splits every shard into about that many batches, so that rank 0 copies and writes the
+        features of one round while the next is being analysed.  writers="all": no gather -- every rank copies its
+        own features to the host and writes its own files (what the rank-0 funnel of configs[3] costs is the
+        difference between the two)."""
+        self.ctx, self.fs, self.fp = ctx, int(fs), float(frame_period)
+        self.rank, self.world, self.backend = rank, world, backend
+        self.spec_dim, self.ap_dim = int(spec_dim), int(ap_dim)
+        self.samples = [int(n) for n in sample_counts]
+        self.frames = [sharding.frame_count(n, self.fs, self.fp) for n in self.samples]
+        self.shards = sharding.lpt_shards(self.frames, world)
+        self.writers = writers
+        if rounds > 1:
+            busiest = max(sum(self.frames[i] for i in s) for s in self.shards)
+            max_batch_frames = min(max_batch_frames, max(1, -(-busiest // rounds)))
+        # batch plan of EVERY rank (rank 0 needs the layout of what it receives): longest first inside a shard
+        self.plan = [list(batches(sorted(s, key=lambda i: (-self.frames[i], i)), self.frames, max_batch_frames))
+                     for s in self.shards]
+        self.rounds = max((len(p) for p in self.plan), default=0)
+        self.params = W.default_params(self.fs, self.fp)
+        self.loaded = []                 # [(WorldBatch, x on device)] for this rank's batches
+        self._pinned = {}                # rank 0's host staging of the gathered slabs
+        self.total_frames = sum(self.frames)
+        self.my_frames = sum(self.frames[i] for i in self.shards[rank])
+
+    # ---- input ------------------------------------------------------------------------------------------------
+    def load(self, waveform_of, io_threads=8):
+        """waveform_of(i) -> float64 samples of utterance i.  Called for this rank's utterances only."""
+        import torch
+        self.close()
+        with ThreadPoolExecutor(io_threads) as pool:
+            for group in self.plan[self.rank]:
+                xs = list(pool.map(waveform_of, group))
+                for i, x in zip(group, xs):
+                    if len(x) != self.samples[i]:
+                        raise ValueError("utterance %d has %d samples, the plan says %d" % (i, len(x), self.samples[i]))
+                b = W.WorldBatch(self.ctx, self.params, x_lengths=[len(x) for x in xs])
+                x = torch.from_numpy(np.concatenate(xs)).pin_memory().cuda(non_blocking=True)
+                self.loaded.append((b, x))
+        torch.cuda.synchronize()
+
+    def close(self):
+        for b, _ in self.loaded:
+            b.close()
+        self.loaded = []
+
+    # ---- one pass ---------------------------------------------------------------------------------------------
+    def _features(self, b, x):
+        t, f0, sp, ap = b.analyze(x)
+        if self.spec_dim:
+            return list(b.recipe_features(f0, sp, ap, self.spec_dim, self.ap_dim))          # analysis.cpp:292-366
+        return [f0.float(), sp.float(), ap.float()]                                          # analysis.cpp:360-390
+
+    def run(self, sink=None, io_threads=16):
+        """One pass over the corpus.  sink(i, f0, sp, ap) is called on rank 0 (on every rank for its own utterances
+        when writers == "all") for every utterance i with float32
+        numpy views (from a thread pool; the arrays stay valid until run() returns).  Returns the phase times in
+        seconds on this rank: compute, gather, to_host, write (the last two are zero off rank 0)."""
+        import torch
+        import torch.distributed as dist
+        ph = {"compute": 0.0, "gather": 0.0, "to_host": 0.0, "write": 0.0}
+        sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+        with ThreadPoolExecutor(io_threads) as pool:
+            pending = []
+            keep = []
+            for k in range(self.rounds):
+                t0 = time.perf_counter()
+                feats = None
+                if k < len(self.loaded):
+                    feats = self._features(*self.loaded[k])
+                sync()
+                t1 = time.perf_counter()
+                ph["compute"] += t1 - t0
+                # what each rank contributes in this round, known everywhere from the plan
+                groups = [p[k] if k < len(p) else [] for p in self.plan]
+                counts = [[self.frames[i] for i in g] for g in groups]
+                if self.writers == "all":
+                    groups = [g if r == self.rank else [] for r, g in enumerate(groups)]
+                    got = feats
+                elif self.world > 1:
+                    if feats is None:
+                        feats = self._empty()
+                    if self.backend == "gloo":
+                        feats = [v.cpu() for v in feats]
+                    res = sharding.gather_features(feats, counts[self.rank], dst=0, all_counts=counts)
+                    if self.backend != "gloo":
+                        sync()
+                    got = res[0] if self.rank == 0 else None
+                else:
+                    got = feats
+                t2 = time.perf_counter()
+                ph["gather"] += t2 - t1
+                if (self.rank == 0 or self.writers == "all") and got is not None:
+                    host = []
+                    for j, v in enumerate(got):
+                        if v.is_cuda:
+                            # pinned staging, allocated once per (round, array) and reused by later passes
+                            h = self._pinned.get((k, j))
+                            if h is None or h.shape != v.shape:
+                                h = self._pinned[(k, j)] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                            h.copy_(v, non_blocking=True)
+                        else:
+                            h = v
+                        host.append(h)
+                    sync()
+                    t3 = time.perf_counter()
+                    ph["to_host"] += t3 - t2
+                    if sink is not None:
+                        arrs = [h.numpy() for h in host]
+                        keep.append(host)
+                        off = 0
+                        for g in groups:                      # rank order, then batch order: the gather's layout
+                            for i in g:
+                                e = off + self.frames[i]
+                                pending.append(pool.submit(sink, i, arrs[0][off:e], arrs[1][off:e], arrs[2][off:e]))
+                                off = e
+            t4 = time.perf_counter()
+            for p in pending:
+                p.result()
+            ph["write"] = time.perf_counter() - t4 if pending else 0.0
+        if self.world > 1 and dist.is_initialized():
+            dist.barrier()
+        return ph
+
+    def _empty(self):
+        import torch
+        bins = (int(self.params.fft_size) or capi.cheaptrick_fft_size(self.fs)) // 2 + 1
+        cols = (self.spec_dim, self.ap_dim) if self.spec_dim else (bins, bins)
+        return [torch.empty(0, dtype=torch.float32, device="cuda"),
+                torch.empty(0, cols[0], dtype=torch.float32, device="cuda"),
+                torch.empty(0, cols[1], dtype=torch.float32, device="cuda")]
+
+
+def file_sink(paths):
+    """sink for ShardedSweep.run(): paths[i] = (f0_out, sp_out, ap_out); raw float32, as the CLI writes them."""
+    def put(i, f0, sp, ap):
+        for path, arr in zip(paths[i], (f0, sp, ap)):
+            arr.tofile(path)                      # row slices of a contiguous slab: no copy
+    return put
+
+
+def dir_sink(out_dir, names=("f0", "sp", "ap")):
+    os.makedirs(out_dir, exist_ok=True)
+
+    def put(i, f0, sp, ap):
+        for n, arr in zip(names, (f0, sp, ap)):
+            arr.tofile(os.path.join(out_dir, "utt%05d.%s" % (i, n)))
+    return put

@@ -42,6 +42,13 @@ def _envelope(f: np.ndarray) -> np.ndarray:
     return r1 + r2 + 0.02
 
 
+def utterance_samples(index: int, fs: int = 16000, dur_range=(2.0, 8.0)) -> int:
+    """Sample count of make_utterance(index, fs, dur_range) without generating it (the sweep's plan needs
+    only the lengths, like a wav header)."""
+    p0 = uniform(1000 + int(index), 0, 64)[0]
+    return int(round((dur_range[0] + (dur_range[1] - dur_range[0]) * p0) * fs))
+
+
 def make_utterance(index: int, fs: int = 16000, dur_range=(2.0, 8.0),
                    duration: float | None = None) -> np.ndarray:
     """Utterance ``index`` (seed 1000+index) as float64 samples s/32768."""
@@ -85,9 +92,9 @@ def make_utterance(index: int, fs: int = 16000, dur_range=(2.0, 8.0),
 
 
 def make_batch(count: int, fs: int = 16000, dur_range=(2.0, 8.0), first: int = 0,
-               workers: int = 1) -> list[np.ndarray]:
-    """``count`` utterances with indices first..first+count-1."""
-    idx = range(first, first + count)
+               workers: int = 1, indices=None) -> list[np.ndarray]:
+    """``count`` utterances with indices first..first+count-1 (or the given ``indices``)."""
+    idx = list(indices) if indices is not None else range(first, first + count)
     if workers > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:

@@ -1,0 +1,177 @@
+"""BASELINE.json configs[3]: the corpus sweep sharded over ranks (hts-train-world_amd/sweep.py, bench.py --workload sweep).
+
+CPU (gloo, 2 ranks): the launcher of `bench.py --gpus N`, the plan, and the way rank 0 lays out and hands on what it
+gathers -- with tagged stand-in features, because the analysis itself needs the GPU.
+GPU: the real thing on one device -- two gloo ranks against a single rank, file for file, bit for bit.
+"""
+import importlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = importlib.import_module("hts-train-world_amd")
+sd, sh, sweep = pkg.synth_data, pkg.sharding, pkg.sweep
+
+
+def _bench(*args, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *map(str, args)], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it starts two rank processes itself (before any GPU call:
+    this runs on a box without one) and each derives its own share of the fixed corpus."""
+    lines = _bench("--gpus", 2, "--backend", "gloo", "--workload", "sweep", "--utts", 30, "--plan-only")
+    assert sorted(ln["rank"] for ln in lines) == [0, 1] and all(ln["world"] == 2 for ln in lines)
+    assert [ln["local_rank"] for ln in sorted(lines, key=lambda v: v["rank"])] == [0, 1]
+    got = sorted(i for ln in lines for i in ln["utterances"])
+    assert got == list(range(30))
+    assert sum(ln["frames"] for ln in lines) == lines[0]["corpus_frames"]
+    assert abs(lines[0]["frames"] - lines[1]["frames"]) < 1700          # LPT: within one (longest) utterance
+    # weak-scaling workloads: rank r owns utterances [r * utts, (r + 1) * utts)
+    lines = _bench("--gpus", 3, "--backend", "gloo", "--utts", 4, "--plan-only")
+    assert sorted(tuple(ln["utterances"]) for ln in lines) == [(0, 1, 2, 3), (4, 5, 6, 7), (8, 9, 10, 11)]
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--plan-only"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert r.returncode != 0 and "RCCL needs one device per rank" in r.stderr
+
+
+def test_plan_is_the_same_on_every_rank_and_covers_the_corpus():
+    counts = [sd.utterance_samples(i, 16000, (0.5, 3.0)) for i in range(40)]
+    plans = [sweep.ShardedSweep(None, 16000, 5.0, counts, r, 4, max_batch_frames=1500).plan for r in range(4)]
+    assert all(p == plans[0] for p in plans)
+    flat = sorted(i for shard in plans[0] for group in shard for i in group)
+    assert flat == list(range(40))
+    frames = [sh.frame_count(n, 16000, 5.0) for n in counts]
+    for shard in plans[0]:
+        for group in shard:
+            assert sum(frames[i] for i in group) <= 1500 or len(group) == 1
+
+
+class _TaggedSweep(sweep.ShardedSweep):
+    """Stand-in features: f0 = utterance id, sp[:, 0] = frame index, ap[:, 0] = rank (the exchange is under test)."""
+
+    def load(self, waveform_of, io_threads=1):
+        self.loaded = [(None, group) for group in self.plan[self.rank]]
+
+    def close(self):
+        self.loaded = []
+
+    def _features(self, b, group):
+        f0 = torch.cat([torch.full((self.frames[i],), float(i)) for i in group]).float()
+        sp = torch.cat([torch.arange(self.frames[i], dtype=torch.float32) for i in group]).unsqueeze(1).repeat(1, 3)
+        ap = torch.full((len(f0), 2), float(self.rank))
+        return [f0, sp, ap]
+
+    def _empty(self):
+        return [torch.empty(0), torch.empty(0, 3), torch.empty(0, 2)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, counts, limit, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sw = _TaggedSweep(None, 16000, 5.0, counts, rank, world, max_batch_frames=limit, backend="gloo")
+    sw.load(None)
+    seen = {}
+
+    def sink(i, f0, sp, ap):
+        seen[i] = (f0.copy(), sp.copy(), ap.copy())
+    ph = sw.run(sink if rank == 0 else None)
+    if rank == 0:
+        assert sorted(seen) == list(range(len(counts)))
+        owner = {i: r for r, s in enumerate(sw.shards) for i in s}
+        for i, (f0, sp, ap) in seen.items():
+            assert f0.shape == (sw.frames[i],) and np.all(f0 == i)
+            assert np.array_equal(sp[:, 0], np.arange(sw.frames[i])) and sp.shape[1] == 3
+            assert np.all(ap == owner[i])
+        assert set(ph) == {"compute", "gather", "to_host", "write"}
+        q.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limit", [10 ** 9, 900])        # one round; several rounds with ragged batch counts
+def test_two_rank_sweep_layout(limit):
+    counts = [sd.utterance_samples(i, 16000, (0.3, 2.5)) for i in range(13)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, counts, limit, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("coded", [False, True])
+def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
+    """The sharded sweep (2 ranks, LPT shards, gather-v to rank 0, rank 0 writes) against the single-rank sweep:
+    every file of every utterance bit for bit.  Both ranks share the one GPU of the box, hence gloo."""
+    extra = ["--coded"] if coded else []
+    common = ["--workload", "sweep", "--utts", 14, "--dur", 0.4, 1.6, "--steps", 1, "--warmup", 0, "--no-cpu-baseline",
+              "--workers", 1]
+    one = _bench(*common, *extra, "--out-dir", tmp_path / "one")
+    two = _bench(*common, *extra, "--gpus", 2, "--backend", "gloo", "--out-dir", tmp_path / "two")
+    assert len(one) == 1 and len(two) == 1                      # rank 0 prints the one line
+    assert one[0]["n_gpus"] == 1 and two[0]["n_gpus"] == 2 and two[0]["scaling"] == "strong"
+    assert two[0]["config"]["frames"] == one[0]["config"]["frames"]
+    assert two[0]["config"]["frames_on_busiest_rank"] < one[0]["config"]["frames"] * 0.6
+    names = sorted(os.listdir(tmp_path / "one"))
+    assert names == sorted(os.listdir(tmp_path / "two")) and len(names) == 14 * 3
+    for n in names:
+        a, b = open(tmp_path / "one" / n, "rb").read(), open(tmp_path / "two" / n, "rb").read()
+        assert a == b and len(a) > 0, n
+    # and the content is the analysis of that utterance: spot check one against the per-utterance API
+    i = 3
+    x = sd.make_utterance(i, 16000, (0.4, 1.6))
+    t, f0 = pkg.capi.dio(x, 16000)
+    f0 = pkg.capi.stonemask(x, 16000, t, f0)
+    if not coded:
+        got = np.fromfile(tmp_path / "two" / ("utt%05d.f0" % i), dtype=np.float32)
+        np.testing.assert_array_equal(got, f0.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_recipe_gather_mode_writes_the_same_files(tmp_path):
+    """recipe.analysis_files(gather=True) on one rank = the plain driver (same files)."""
+    from test_cli_relink import write_wav as write_wav_py
+    recipe = pkg.recipe
+    jobs_a, jobs_b = [], []
+    for k, (fs, dur) in enumerate([(16000, 0.7), (16000, 1.1), (48000, 0.5)]):
+        wav = tmp_path / f"u{k}.wav"
+        write_wav_py(wav, sd.make_utterance(60 + k, fs, duration=dur), fs)
+        jobs_a.append((wav, tmp_path / f"a{k}.f0", tmp_path / f"a{k}.sp", tmp_path / f"a{k}.ap"))
+        jobs_b.append((wav, tmp_path / f"b{k}.f0", tmp_path / f"b{k}.sp", tmp_path / f"b{k}.ap"))
+    na = recipe.analysis_files(jobs_a, 5.0, 0)
+    nb = recipe.analysis_files(jobs_b, 5.0, 0, gather=True)
+    assert na == nb > 0
+    for ja, jb in zip(jobs_a, jobs_b):
+        for pa, pb in zip(ja[1:], jb[1:]):
+            assert open(pa, "rb").read() == open(pb, "rb").read()
