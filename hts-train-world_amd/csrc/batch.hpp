@@ -84,6 +84,7 @@ struct Batch {
   double* d_ap0 = nullptr;           // [total_f] D4C LoveTrain result
   double* d_f0_tmp = nullptr;        // [total_f] raw DIO f0 before StoneMask
   int* d_perm = nullptr;             // [total_f] costly frames first (partition.hpp)
+  int* d_perm2 = nullptr;            // [total_f] D4C: frames that need the wide-margin kernel first
   int* d_part_cnt = nullptr;         // [total_f / 1024 + 2]
   int* d_part_n = nullptr;           // [4] number of listed frames
   void* d_sm_twid = nullptr;         // StoneMask's DFT twiddle table (stonemask.hip)
@@ -97,6 +98,7 @@ struct Batch {
   double* d_dio_win = nullptr;       // Nuttall low-pass windows, all bands
   int* d_dio_fft = nullptr;          // [n_utt] the reference's fft_size (circular indexing)
   double* d_dio_ws = nullptr;        // [3][total_f] contour work arrays
+  int* d_dio_edges = nullptr;        // [n_utt][2][edge_cap] edge lists of the contour fix when they outgrow LDS
   int* d_dio_ylen = nullptr;         // [n_utt] y_length = 1 + N / speed
   double* d_dio_y = nullptr;         // decimated signals (speed > 1)
   double* d_dio_tmp = nullptr;       // decimation pass-1 output

@@ -28,7 +28,6 @@
 namespace wm {
 const char* last_error();
 void set_error(const char* msg);
-int launch_test_rfft(Context* ctx, int n, int count, const double* x, double* re, double* im, double* xb);
 int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0);
 void free_batch_buffers(Batch& b);
 }  // namespace wm
@@ -283,10 +282,6 @@ int WorldMi355TimingQuery(WorldMi355Context* h, const char* kernel, double* tota
     if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { *total_ms += ms; *launches += 1; }
   }
   return WM_OK;
-}
-int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
-                       double* im, double* x_back) {
-  return wm::launch_test_rfft(&ctx->c, n, count, x, re, im, x_back);
 }
 
 }  // extern "C"

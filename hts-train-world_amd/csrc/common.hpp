@@ -57,6 +57,23 @@ __device__ __forceinline__ int opaque_lane(int lane) {
   return lane;
 }
 
+// Compiler fence for a kernel-uniform scalar (an argument such as fs) inside persistent frame loops: whatever is
+// derived from the returned value is recomputed per frame instead of being hoisted out of the loop, where it would
+// hold registers -- often vector registers, for FP64 quotients -- for the whole kernel.
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// A wave-uniform double moved into scalar registers (two v_readfirstlane): per-frame quantities such as f0, the
+// frame position or a normalisation factor are computed by the vector ALU (there is no scalar FP64) and would
+// otherwise occupy a vector register pair each for the whole frame.
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // ---- wavefront collectives (64 lanes) ----------------------------------------
 // Built on DPP row shifts / row broadcasts (gfx9 family) instead of ds_bpermute shuffles: six
 // dependent VALU steps with no LDS round trip.  The six steps are a complete inclusive scan over

@@ -41,6 +41,12 @@ static void fill_randn_u32(uint32_t* out, int64_t count, uint32_t (&st)[4]) {
 // The table only ever grows: entries [0, rng_cap) stay, the tail continues the xorshift stream from
 // the saved state (a longer utterance after a shorter one costs its extra entries, not a new table).
 int Context::ensure_rng(int64_t count) {
+  // consumers index the table with 32-bit per-utterance offsets (d_rng_off, randn_at): an utterance whose draws
+  // could pass 2^31 (about 135 k frames at 48 kHz) is refused instead of wrapping silently
+  if (count > (int64_t)INT32_MAX) {
+    set_error("utterance too long: its randn offsets would not fit 32 bits");
+    return WM_ERR_UNSUPPORTED;
+  }
   if (count <= rng_cap) return WM_OK;
   int64_t cap = count + count / 4 + 4096;
   if (cap < 2 * rng_cap) cap = 2 * rng_cap;
@@ -151,8 +157,8 @@ void codec_free(void* p);
 
 void free_batch_buffers(Batch& b) {
   void* ptrs[] = {b.d_x_off, b.d_f_off, b.d_y_off, b.d_x_len, b.d_f0_len, b.d_y_len, b.d_frame_utt,
-                  b.d_rng_off, b.d_rng_off2, b.d_ap0, b.d_f0_tmp, b.d_perm, b.d_part_cnt, b.d_part_n, b.d_sm_twid, b.d_d4c_window, b.d_utt_total,
-                  b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_ylen, b.d_dio_y, b.d_dio_tmp,
+                  b.d_rng_off, b.d_rng_off2, b.d_ap0, b.d_f0_tmp, b.d_perm, b.d_perm2, b.d_part_cnt, b.d_part_n, b.d_sm_twid, b.d_d4c_window, b.d_utt_total,
+                  b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_edges, b.d_dio_ylen, b.d_dio_y, b.d_dio_tmp,
                   b.d_dio_yoff, b.d_dio_toff, b.d_dio_mean, b.d_dio_mean_part, b.d_dio_z,
                   b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_slot_off, b.d_dio_cand,
                   b.d_dio_score, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_phase, b.d_pulse_cnt,

@@ -5,9 +5,21 @@
 //                            LoveTrain first, then the frames that pass it)
 //   d4c_lovetrain_kernel     D4CLoveTrain(+Sub), d4c.cpp:225-282
 //   d4c_kernel               D4CGeneralBody d4c.cpp:290-316 + GetAperiodicity :325-333
-// The std::sort of d4c.cpp:215 only feeds "sum of all but the (boundary+1)
-// largest bins"; here the largest bins are peeled off by repeated wave-wide max
-// and the rest summed directly (no sort).
+//
+// How this differs from the reference's arithmetic (results agree to ~1e-12, tests/test_gpu_parity.py):
+//   * Frames are built in registers (frame.hpp), never staged in LDS.
+//   * GetCentroid (d4c.cpp:90-119) needs Re(X1 conj X2) with X1 = FFT(x), X2 = FFT((i+1) x), both of FD real
+//     points.  Both come out of ONE complex transform of z = s x + j (i+1) x (s a power of two near the ramp's
+//     mean, so that neither part drowns the other): with Z = s X1 + j X2 and real sequences,
+//         Im(Z[k] Z[FD-k]) = 2 s Re(X1[k] conj X2[k]).
+//     The FD-point complex transform is one decimation-in-frequency step by hand (even bins = FFT of the folded
+//     halves, odd bins = FFT of their twiddled difference) on top of the FD/2-point wavefront engine (fft.hpp);
+//     the usual 4-period window is shorter than FD/2 samples, so the fold is empty and only long frames
+//     (f0 below ~63 Hz at 16 kHz) take the general path.  Per side: 2 complex FFTs, no real-FFT split passes,
+//     no second spectrum held in registers.
+//   * The std::sort of d4c.cpp:215 only feeds "sum of all but the (boundary+1) largest bins": every lane sorts its
+//     own bins once, the largest are peeled off by repeated wave-wide max, the rest is summed directly.
+//   * DCCorrection / LinearSmoothing work in place on a spectrum stored with mirror margins (spectrum.hpp).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,12 +27,11 @@
 #include <type_traits>
 
 #include "batch.hpp"
-#include "bcommon.hpp"
-#include "bfft.hpp"
 #include "common.hpp"
 #include "fft.hpp"
+#include "frame.hpp"
 #include "partition.hpp"
-#include "window.hpp"
+#include "spectrum.hpp"
 
 namespace wm {
 
@@ -118,9 +129,8 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     const int u = frame_utt[frame];
     const double cf0 = f0v > 40.0 ? f0v : 40.0;
     cpx v[M];
-    windowed_waveform_lds<kBlackman, false>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0, rtab,
-                                            rng_off[frame], lane, smem, FL);
-    load_packed<N>(smem, lane, v);
+    const FrameGeom fg = frame_geom(fs, cf0, tpos[frame], 3.0);
+    frame_packed<kBlackman, false, M>(x + x_off[u], x_len[u], fg, rtab, rng_off[frame], lane, v);
     rfft_forward<N>(v, img, img, tw, lane);
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -173,450 +183,164 @@ struct D4CTables {
   int nap;                  // number_of_aperiodicities (d4c.cpp:351-353)
 };
 
-// FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
-// Variant B: one 256-thread workgroup per frame (bfft.hpp / bcommon.hpp): each thread owns the bins
-// tid + 256 q of every spectrum-domain array and one radix-4 butterfly of every FFT pass.
-template <int FD, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void d4c_block_kernel(
-    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
-    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
-    const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
-    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, double* __restrict__ ap, int dbg) {
-  constexpr int NW = 4, NT = 64 * NW;
-  constexpr int N = FD / 2, H = FD / 2;
-  constexpr int QB = (H + 1 + NT - 1) / NT;        // bins per thread
-  constexpr int QS = FD / NT;                      // time samples per thread
-  constexpr int kA = H + 2;
-  constexpr int kBMax = FD / 16;
-  constexpr int kImg = 2 * (N + 1);
-  constexpr int kMain = kImg > (kA + H + 2 * kBMax + 2) ? kImg : (kA + H + 2 * kBMax + 2);
-  constexpr int kTopMax = 80;                      // >= boundary + 1 (22 at 16 kHz, 65 at 48 kHz)
-  __shared__ __attribute__((aligned(16))) double smem[kMain + (NW + 1) * kTopMax + 2 * NW + 8];
-  double* arr = smem;                         // [H+1] spectrum-domain array
-  double* seg = smem + kA;                    // scan / DC scratch
-  cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image / time-domain frame (aliases both)
-  double* top = smem + kMain;                 // [NW][kTopMax] per-wave largest bins, then [kTopMax] global
-  double* gtop = top + NW * kTopMax;
-  double* red = gtop + kTopMax;               // [NW] reduction scratch
+// bins the widest LinearSmoothing of a frame mirrors at either end (width = f0; common.cpp:80)
+__host__ __device__ inline int d4c_mirror_bins(double cf0, int fft_size_d4c, int fs) {
+  return (int)(cf0 * fft_size_d4c / fs) + 1;
+}
+// margin of the spectrum in LDS: the usual kernel covers f0 < fs / 16, the RARE one everything the
+// reference defines (its DCCorrection reads past the spectrum from f0 ~ fs / 2 on, common.cpp:62-68)
+template <int FD, bool RARE> struct D4CMargin { static constexpr int kBM = RARE ? FD / 2 : FD / 16; };
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  BFft<N, NT> bf;
-  bf.init(tid);
-  const int out_bins = out_fft / 2 + 1;
-
-  const int n_run = *n_listed;
-  WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
-    double* row = ap + frame * (int64_t)out_bins;
-    for (int i = tid; i < out_bins; i += NT) row[i] = 1.0 - kSafe;
+// One GetCentroid (d4c.cpp:90-119) at `cpos`, added into ce / co:
+//   ce[m] += centroid at bin 2 j, co[m] += centroid at bin 2 j + 1, j = lane + 64 m, m < M / 2;
+//   ce[M / 2] (lane 0): bin FD / 2.
+// LONG: the frame has more than N = FD / 2 samples (fold not empty); it is then built twice, once per
+// sub-transform, instead of being kept in registers across the first.
+template <int N, bool LONG>
+__device__ __forceinline__ void d4c_centroid(const double* __restrict__ xu, int xl, const FrameGeom& fg,
+                                             const uint32_t* __restrict__ rtab, int ro, const FftTw<N>& tw, cpx* img,
+                                             int lane0, double (&ce)[N / 128 + 1], double (&co)[N / 128]) {
+  constexpr int M = N / 64, QX = LONG ? 2 * M : M;
+  // per call: the ramp values and sample indices derived from the lane are the same for both centroids of a
+  // frame, and the compiler would otherwise keep all of them in registers across the loop over the two
+  const int lane = opaque_lane(lane0);
+  // s: power of two next below the half window length (the mean of the ramp i + 1): exact scaling
+  const double s = (double)(1 << (31 - __clz(fg.hw | 1)));
+  double x[QX];
+  double pwr;
+  frame_strided<kBlackman, QX, !LONG>(xu, xl, fg, rtab, ro, lane, x, pwr);
+  // normalisation to unit energy (d4c.cpp:96-100) and the 1 / (2 s) of the identity above, on the result
+  const double scale = uniform_d(1.0 / (2.0 * s * pwr));
+  cpx v[M];
+  // ---- even bins: E = FFT_N(z[n] + z[n + N]), z[n] = x[n] (s + j (n + 1)) ----
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double r = (double)(lane + 64 * m + 1);
+    if constexpr (!LONG) v[m] = make_double2(s * x[m], r * x[m]);
+    else v[m] = make_double2(s * (x[m] + x[m + M]), r * x[m] + (r + N) * x[m + M]);
   }
-  WM_FOR_EACH_LISTED(frame, perm, n_run) {
-    double* row = ap + frame * (int64_t)out_bins;
-    const double f0v = f0[frame];
-    bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
-    const double cf0 = f0v > kFloorF0D4C ? f0v : kFloorF0D4C;         // d4c.cpp:381
-    // LDS capacity guard for the smoothing scratch (width = f0 is the widest): f0 < fs/16
-    if (run && (int)(cf0 * FD / fs) + 1 > kBMax) run = false;
-    if (!run) {
-      for (int i = tid; i < out_bins; i += NT) row[i] = 1.0 - kSafe;  // d4c.cpp:318-323
-      continue;
+  fft_forward<N>(v, img, tw, lane);
+  wave_sync();
+#pragma unroll
+  for (int m = M / 2; m < M; ++m) img[lane + 64 * m] = v[m];       // the partners E[N - j] of j < N / 2
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M / 2; ++m) {
+    const int j = lane + 64 * m;
+    cpx pt = img[(N - j) & (N - 1)];
+    if (m == 0) {                                                   // E[0] pairs with itself (component-wise:
+      pt.x = lane == 0 ? v[0].x : pt.x;                             // a select between two cpx objects keeps
+      pt.y = lane == 0 ? v[0].y : pt.y;                             // v[] addressable, i.e. in scratch memory)
     }
-    const int u = frame_utt[frame];
-    const double* xu = x + x_off[u];
-    const int xl = x_len[u];
-    const double pos = tpos[frame];
-    const int roff = rng_off[frame];
-    const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
-    __syncthreads();
-
-    // All three analysis windows of this frame (two Blackman centroid frames, one Hann power
-    // frame; d4c.cpp:94-95, :152-153) span 4 periods, so they share cos(pi a (i - hw)):
-    // generate it once per frame and keep this thread's QS samples in registers.
-    const int hw = matlab_round(4.0 * fs / cf0 / 2.0);            // d4c.cpp:55-56
-    const int L = 2 * hw + 1;
-    double cw[QS];
-    {
-      CosGen g;
-      g.init(2.0 * cf0 / (4.0 * fs), tid - hw, NT);               // d4c.cpp:36-37
-#pragma unroll
-      for (int q = 0; q < QS; ++q) { cw[q] = g.c; g.next(); }
-    }
-    // windowed, dithered, mean-removed frame of GetWindowedWaveform (d4c.cpp:52-84) into fv[]
-    auto build = [&](auto type_tag, double cpos, int ro, double (&fv)[QS]) {
-      constexpr int TYPE = decltype(type_tag)::value;
-      const int origin = matlab_round(cpos * fs + 0.001);
-      double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        const int i = tid + NT * q;
-        fv[q] = 0.0;
-        if (i < L) {
-          const double w = window_value<TYPE>(cw[q]);
-          fv[q] = xu[imin(xl - 1, imax(0, origin + i - hw))] * w + randn_at(rtab, ro + i) * kSafe;
-          s1 += fv[q];
-          s2 += w;
-        }
-      }
-      BlockOps<NW>::sum2(s1, s2, red, tid);
-      const double coef = s1 / s2;
-#pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        const int i = tid + NT * q;
-        if (i < L) fv[q] -= window_value<TYPE>(cw[q]) * coef;
-      }
-    };
-
-    // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
-    double sc[QB];
-#pragma unroll
-    for (int q = 0; q < QB; ++q) sc[q] = 0.0;
-#pragma unroll 1
-    for (int side = 0; side < ((dbg & 1) ? 0 : 2); ++side) {
-      const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-      double fv[QS];
-      build(std::integral_constant<int, kBlackman>{}, cpos, roff + side * Lw, fv);
-      double pwr = 0.0;                                   // d4c.cpp:96-100
-#pragma unroll
-      for (int q = 0; q < QS; ++q) pwr += fv[q] * fv[q];
-      const double nrm = sqrt(BlockOps<NW>::sum(pwr, red, tid));
-#pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        fv[q] /= nrm;
-        smem[tid + NT * q] = fv[q];
-      }
-      bf.rfft_forward(img, tid);
-      cpx s1[QB];
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        s1[q] = k <= H ? img[k] : make_double2(0.0, 0.0);
-      }
-      __syncthreads();
-      // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
-#pragma unroll
-      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fv[q] * (tid + NT * q + 1.0);
-      bf.rfft_forward(img, tid);
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        if (k <= H) {
-          const cpx s2 = img[k];
-          sc[q] += s2.x * s1[q].x + s1[q].y * s2.y;          // d4c.cpp:113-115
-        }
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int k = tid + NT * q;
-      if (k <= H) arr[k] = sc[q];
-    }
-    __syncthreads();
-    dc_correction_blk<NT>(arr, cf0, fs, FD, seg, tid);     // d4c.cpp:139
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int k = tid + NT * q;
-      if (k <= H) sc[q] = arr[k];
-    }
-    __syncthreads();
-
-    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
-    if (!(dbg & 2)) {
-      double fv[QS];
-      build(std::integral_constant<int, kHann>{}, pos, roff + 2 * Lw, fv);
-#pragma unroll
-      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fv[q];
-      bf.rfft_forward(img, tid);
-      double p[QB];
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        p[q] = 0.0;
-        if (k <= H) {
-          const cpx s = img[k];
-          p[q] = s.x * s.x + s.y * s.y;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        if (k <= H) arr[k] = p[q];
-      }
-      __syncthreads();
-    }
-    if (!(dbg & 4)) {
-    dc_correction_blk<NT>(arr, cf0, fs, FD, seg, tid);
-    linear_smoothing_blk<NW>(arr, cf0, fs, FD, seg, arr, red, tid);
-    }
-    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int k = tid + NT * q;
-      if (k <= H) arr[k] = sc[q] / arr[k];
-    }
-    __syncthreads();
-    if (!(dbg & 4)) linear_smoothing_blk<NW>(arr, cf0 / 2.0, fs, FD, seg, arr, red, tid);
-    double gd[QB];
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int k = tid + NT * q;
-      gd[q] = k <= H ? arr[k] : 0.0;
-    }
-    __syncthreads();
-    if (!(dbg & 4)) linear_smoothing_blk<NW>(arr, cf0, fs, FD, seg, arr, red, tid);
-#pragma unroll
-    for (int q = 0; q < QB; ++q) {
-      const int k = tid + NT * q;
-      if (k <= H) gd[q] -= arr[k];
-    }
-    __syncthreads();
-
-    // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
-    const int wl = tab.window_length;
-    const int bnd = imin(matlab_round(FD * 8.0 / wl), kTopMax - 1);
-    const int hwl = wl / 2;
-    double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int band = 0; band < ((dbg & 8) ? 0 : tab.nap); ++band) {
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        if (k <= H) arr[k] = gd[q];
-      }
-      __syncthreads();
-      const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
-      double fr[QS];
-#pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        const int i = tid + NT * q;
-        fr[q] = i < wl ? arr[center - hwl + i] * tab.nuttall[i] : 0.0;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < QS; ++q) smem[tid + NT * q] = fr[q];
-      bf.rfft_forward(img, tid);
-      double p[QB];
-      double tot = 0.0;
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        const int k = tid + NT * q;
-        p[q] = -1.0;
-        if (k <= H) {
-          const cpx s = img[k];
-          p[q] = s.x * s.x + s.y * s.y;
-          tot += p[q];
-        }
-      }
-      tot = BlockOps<NW>::sum(tot, red, tid);
-      // the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest (d4c.cpp:215-220).
-      // Level 1: every wave peels its own bnd + 1 largest; level 2: wave 0 peels the union.
-      {
-        double c[QB];
-#pragma unroll
-        for (int q = 0; q < QB; ++q) c[q] = p[q];
-#pragma unroll 1
-        for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
-          double mx = c[0];
-#pragma unroll
-          for (int q = 1; q < QB; ++q) mx = fmax(mx, c[q]);
-          const double wmx = wave_max(mx);
-          const unsigned long long vote = __ballot(mx == wmx);
-          const int winner = __ffsll((long long)vote) - 1;
-          if (lane == winner) {
-            bool done = false;
-#pragma unroll
-            for (int q = 0; q < QB; ++q)
-              if (!done && c[q] == wmx) { c[q] = -2.0; done = true; }
-            top[wv * kTopMax + it] = wmx;
-          }
-        }
-      }
-      __syncthreads();
-      if (wv == 0) {
-        constexpr int QC = (NW * kTopMax + 63) / 64;
-        double c[QC];
-#pragma unroll
-        for (int q = 0; q < QC; ++q) {
-          const int idx = lane + 64 * q;                  // candidate (wave = idx / (bnd+1), rank = idx % (bnd+1))
-          const int w2 = idx / (bnd + 1), r2 = idx - w2 * (bnd + 1);
-          c[q] = w2 < NW ? top[w2 * kTopMax + r2] : -2.0;
-        }
-#pragma unroll 1
-        for (int it = 0; it <= bnd; ++it) {
-          double mx = c[0];
-#pragma unroll
-          for (int q = 1; q < QC; ++q) mx = fmax(mx, c[q]);
-          const double wmx = wave_max(mx);
-          const unsigned long long vote = __ballot(mx == wmx);
-          const int winner = __ffsll((long long)vote) - 1;
-          if (lane == winner) {
-            bool done = false;
-#pragma unroll
-            for (int q = 0; q < QC; ++q)
-              if (!done && c[q] == wmx) { c[q] = -2.0; done = true; }
-            gtop[it] = wmx;
-          }
-        }
-      }
-      __syncthreads();
-      const double tau = gtop[bnd];                       // the (bnd+1)-th largest value
-      int n_gt = 0;
-      for (int it = 0; it <= bnd; ++it) n_gt += gtop[it] > tau ? 1 : 0;
-      const int need_eq = bnd + 1 - n_gt;                 // copies of tau among the removed bins
-      double low = 0.0, eq = 0.0;
-#pragma unroll
-      for (int q = 0; q < QB; ++q) {
-        if (p[q] >= 0.0 && p[q] < tau) low += p[q];
-        if (p[q] == tau) eq += 1.0;
-      }
-      low = BlockOps<NW>::sum(low, red, tid);
-      eq = BlockOps<NW>::sum(eq, red, tid);
-      low += (eq - need_eq) * tau;
-      double c = 10.0 * log10(low / tot);
-      c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
-      c = c < 0.0 ? c : 0.0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j)
-        if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
-      __syncthreads();
-    }
-
-    // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
-    const int nk = tab.nap + 2;
-    for (int i = tid; i < out_bins; i += NT) {
-      const double f = (double)i * fs / out_fft;
-      int k = 0;                                            // #{knots <= f}
-      for (int j = 0; j < nk; ++j) {
-        double xj = j <= tab.nap ? j * kFreqInterval : fs / 2.0;
-        k += xj <= f ? 1 : 0;
-      }
-      k = k < 1 ? 1 : (k > nk - 1 ? nk - 1 : k);
-      const double x0 = (k - 1) <= tab.nap ? (k - 1) * kFreqInterval : fs / 2.0;
-      const double x1 = k <= tab.nap ? k * kFreqInterval : fs / 2.0;
-      double y0 = -60.0, y1 = -kSafe;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (j < tab.nap) {
-          if (k - 1 == j + 1) y0 = coarse[j];
-          if (k == j + 1) y1 = coarse[j];
-        }
-      }
-      const double s = (f - x0) / (x1 - x0);
-      const double yi = y0 + s * (y1 - y0);
-      row[i] = exp(yi * (2.302585092994045684 / 20.0));       // 10^(yi/20), d4c.cpp:331-332
-    }
-    __syncthreads();
+    ce[m] += (v[m].x * pt.y + v[m].y * pt.x) * scale;
   }
+  ce[M / 2] += 2.0 * v[M / 2].x * v[M / 2].y * scale;              // lane 0: E[N / 2] pairs with itself
+  // ---- odd bins: O = FFT_N((z[n] - z[n + N]) W_FD^n) ----
+  if constexpr (LONG) frame_strided<kBlackman, QX, !LONG>(xu, xl, fg, rtab, ro, lane, x, pwr);
+  cpx w = tw.wsplit;                                                // W_FD^lane
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double r = (double)(lane + 64 * m + 1);
+    if constexpr (!LONG) {
+      // x (s + j r) w
+      v[m] = make_double2(x[m] * (s * w.x - r * w.y), x[m] * (s * w.y + r * w.x));
+    } else {
+      const cpx d = make_double2(s * (x[m] - x[m + M]), r * x[m] - (r + N) * x[m + M]);
+      v[m] = cmul(d, w);
+    }
+    w = cmul(w, tw.wstep());                                        // W_FD^64
+  }
+  fft_forward<N>(v, img, tw, lane);
+  wave_sync();
+#pragma unroll
+  for (int m = M / 2; m < M; ++m) img[lane + 64 * m] = v[m];
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M / 2; ++m) {
+    const cpx pt = img[N - 1 - (lane + 64 * m)];                    // O[N - 1 - j]
+    co[m] += (v[m].x * pt.y + v[m].y * pt.x) * scale;
+  }
+  wave_sync();
 }
 
 // FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
-// Variant A: one wavefront per frame (fft.hpp), everything in registers + 18.5 KB of LDS.
-template <int FD, int WAVES>
-__global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
+// One wavefront per frame (fft.hpp): registers + one LDS region that is FFT image, spectrum with margins and
+// selection scratch in turn.  RARE = false: the frames d4c_is_usual() accepts (short window, narrow mirror), at
+// the register and LDS budget of two waves per SIMD; RARE = true: the others (one wave per SIMD).
+template <int FD, int WAVES, bool RARE>
+__global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const double* __restrict__ ap0, const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab,
-    int fs, double threshold, D4CTables tab, int out_fft, int64_t total_frames, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, double* __restrict__ ap, int dbg) {
+    int fs_arg, double threshold, D4CTables tab, int out_fft_arg, int64_t total_frames, const int* __restrict__ perm,
+    const int* __restrict__ n_listed, double* __restrict__ ap) {
   constexpr int N = FD / 2, M = N / 64, H = FD / 2, MB = M + 1;
-  constexpr int kA = H + 2;
-  constexpr int kBMax = FD / 16;
+  constexpr int kBM = D4CMargin<FD, RARE>::kBM;
   constexpr int kImg = 2 * FftLds<N>::kElems;
-  constexpr int kCh = ((H + 2 * kBMax + 1 + 63) / 64) | 1;   // odd per-lane chunk of the smoothing scan
-  constexpr int kTot = kImg > (kA + 64 * kCh) ? kImg : (kA + 64 * kCh);
+  constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
+  constexpr int kHeads = (MB + 1) * 64;
+  constexpr int kTot = kImg > kRegion ? (kImg > kHeads ? kImg : kHeads) : (kRegion > kHeads ? kRegion : kHeads);
+  static_assert(kBM % 2 == 0, "the spectrum starts on a 16-byte boundary");
   __shared__ __attribute__((aligned(16))) double smem[kTot];
-  double* arr = smem;                         // [H+1] spectrum-domain array
-  double* seg = smem + kA;                    // scan / DC scratch
-  cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image (aliases both)
+  double* arr = smem + kBM;                   // [-kBM .. H + kBM] spectrum-domain array with mirror margins
+  cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image (aliases it)
 
   const int lane0 = threadIdx.x;
   FftTw<N> tw;
   tw.init(lane0);
-  const int out_bins = out_fft / 2 + 1;
+  const int out_bins = out_fft_arg / 2 + 1;
 
   const int n_run = *n_listed;
-  WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
-    double* row = ap + frame * (int64_t)out_bins;
-    for (int i = lane0; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
+  if (!RARE) {
+    WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
+      double* row = ap + frame * (int64_t)out_bins;
+      for (int i = lane0; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
+    }
   }
   WM_FOR_EACH_LISTED(frame, perm, n_run) {
     const int lane = opaque_lane(lane0);
+    const int fs = opaque_uniform(fs_arg), out_fft = opaque_uniform(out_fft_arg);   // nothing derived is hoisted
     double* row = ap + frame * (int64_t)out_bins;
     const double f0v = f0[frame];
-    bool run = f0v != 0.0 && ap0[frame] > threshold;                 // d4c.cpp:380
-    const double cf0 = f0v > kFloorF0D4C ? f0v : kFloorF0D4C;         // d4c.cpp:381
-    // LDS capacity guard for the smoothing scratch (width = f0 is the widest): f0 < fs/16
-    if (run && (int)(cf0 * FD / fs) + 1 > kBMax) run = false;
-    if (!run) {
-      for (int i = lane; i < out_bins; i += 64) row[i] = 1.0 - kSafe;  // d4c.cpp:318-323
-      continue;
-    }
+    const double cf0 = uniform_d(f0v > kFloorF0D4C ? f0v : kFloorF0D4C);   // d4c.cpp:381
     const int u = frame_utt[frame];
     const double* xu = x + x_off[u];
     const int xl = x_len[u];
-    const double pos = tpos[frame];
+    const double pos = uniform_d(tpos[frame]);
     const int roff = rng_off[frame];
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
 
     // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
+    double ce[M / 2 + 1], co[M / 2];
+#pragma unroll
+    for (int m = 0; m < M / 2; ++m) ce[m] = co[m] = 0.0;
+    ce[M / 2] = 0.0;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const double cpos = uniform_d(side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0);
+      const FrameGeom fg = frame_geom(fs, cf0, cpos, 4.0);
+      if (!RARE || fg.L <= N) d4c_centroid<N, false>(xu, xl, fg, rtab, roff + side * Lw, tw, img, lane, ce, co);
+      else d4c_centroid<N, true>(xu, xl, fg, rtab, roff + side * Lw, tw, img, lane, ce, co);
+    }
+    {
+      cpx* arr2 = reinterpret_cast<cpx*>(arr);
+#pragma unroll
+      for (int m = 0; m < M / 2; ++m) arr2[lane + 64 * m] = make_double2(ce[m], co[m]);   // bins 2 j, 2 j + 1
+      if (lane == 0) arr[H] = ce[M / 2];
+    }
+    wave_sync();
+    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);  // d4c.cpp:139
     double sc[MB];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) sc[m] = 0.0;
-#pragma unroll 1
-    for (int side = 0; side < ((dbg & 1) ? 0 : 2); ++side) {
-      const double cpos = side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-      const int ro = roff + side * Lw;
-      cpx v[M];
-      const FrameWindow fw = windowed_waveform_lds<kBlackman, false, 8>(xu, xl, fs, cf0, cpos, 4.0, rtab, ro, lane,
-                                                                     smem, FD);
-      double pwr = 0.0;                                   // d4c.cpp:96-100
-      for (int i = lane; i < fw.L; i += 64) pwr += smem[i] * smem[i];
-      // normalisation by sqrt(power) (d4c.cpp:99-100) applied as a multiplication by its reciprocal
-      const double rnrm = 1.0 / sqrt(wave_sum(pwr));
-      load_packed<N>(smem, lane, v);
-      cpx fv[M];                                          // normalised frame, kept for the ramped transform
-#pragma unroll
-      for (int m = 0; m < M; ++m) { v[m].x *= rnrm; v[m].y *= rnrm; fv[m] = v[m]; }
-      rfft_forward<N>(v, img, img, tw, lane);
-      cpx s1[MB];
-#pragma unroll
-      for (int m = 0; m < M; ++m) s1[m] = img[lane + 64 * m];
-      s1[M] = img[N];
-      // second transform of the same frame times (i + 1)  (d4c.cpp:110-112)
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const int i0 = 2 * (lane + 64 * m);
-        v[m] = make_double2(fv[m].x * (i0 + 1.0), fv[m].y * (i0 + 2.0));
-      }
-      rfft_forward<N>(v, img, img, tw, lane);
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        cpx s2 = img[lane + 64 * m];
-        sc[m] += s2.x * s1[m].x + s1[m].y * s2.y;          // d4c.cpp:113-115
-      }
-      {
-        cpx s2 = img[N];
-        sc[M] += s2.x * s1[M].x + s1[M].y * s2.y;
-      }
-      wave_sync();
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m];
-    if (lane == 0) arr[N] = sc[M];
-    wave_sync();
-    dc_correction_lds(arr, cf0, fs, FD, seg, lane);        // d4c.cpp:139
-#pragma unroll
     for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
-    sc[M] = arr[N];
+    sc[M] = arr[H];
     wave_sync();
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
-    double gd[MB];
-    if (!(dbg & 2)) {
+    {
       cpx v[M];
-      windowed_waveform_lds<kHann, false, 8>(xu, xl, fs, cf0, pos, 4.0, rtab, roff + 2 * Lw, lane, smem, FD);
-      load_packed<N>(smem, lane, v);
+      const FrameGeom fg = frame_geom(fs, cf0, pos, 4.0);
+      frame_packed<kHann, false, M>(xu, xl, fg, rtab, roff + 2 * Lw, lane, v);
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
 #pragma unroll
@@ -631,27 +355,26 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       wave_sync();
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
-      if (lane == 0) arr[N] = p[M];
+      if (lane == 0) arr[H] = p[M];
       wave_sync();
     }
-    if (!(dbg & 4)) {
-    dc_correction_lds(arr, cf0, fs, FD, seg, lane);
-    linear_smoothing_lds<kCh>(arr, cf0, fs, FD, seg, arr, lane);
-    }
+    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
-    if (lane == 0) arr[N] = sc[M] / arr[N];
+    if (lane == 0) arr[H] = sc[M] / arr[H];
     wave_sync();
-    if (!(dbg & 4)) linear_smoothing_lds<kCh>(arr, cf0 / 2.0, fs, FD, seg, arr, lane);
+    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
+    double gd[MB];
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
-    gd[M] = arr[N];
+    gd[M] = arr[H];
     wave_sync();
-    if (!(dbg & 4)) linear_smoothing_lds<kCh>(arr, cf0, fs, FD, seg, arr, lane);
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
 #pragma unroll
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
-    gd[M] -= arr[N];
+    gd[M] -= arr[H];
     wave_sync();
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
@@ -660,10 +383,10 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     const int hwl = wl / 2;
     double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-    for (int band = 0; band < ((dbg & 8) ? 0 : tab.nap); ++band) {
+    for (int band = 0; band < tab.nap; ++band) {
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
-      if (lane == 0) arr[N] = gd[M];
+      if (lane == 0) arr[H] = gd[M];
       wave_sync();
       const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
       cpx v[M];
@@ -709,9 +432,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       for (int m = 0; m < MB; ++m) heads[m * 64 + lane] = p[m];
       heads[MB * 64 + lane] = -1.0;                           // exhausted
       int taken = 0;
-      double cur = p[0];
+      double cur = heads[lane];                               // = p[0] (own column: no barrier needed)
 #pragma unroll 1
-      for (int it = 0; it <= ((dbg & 16) ? 0 : bnd); ++it) {
+      for (int it = 0; it <= bnd; ++it) {
         const double wmx = wave_max(cur);
         const unsigned long long vote = __ballot(cur == wmx);
         const int winner = __ffsll((long long)vote) - 1;
@@ -748,7 +471,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
       const double bin_hz = (double)fs / out_fft;
       const double last_w = fs / 2.0 - tab.nap * kFreqInterval;
       const double inv_last = 1.0 / last_w;
-      for (int i = lane; i < ((dbg & 64) ? 0 : out_bins); i += 64) {
+      for (int i = lane; i < out_bins; i += 64) {
         const double f = (double)i * bin_hz;
         int kk = (int)(f * (1.0 / kFreqInterval));
         kk = kk > tab.nap ? tab.nap : kk;
@@ -762,6 +485,38 @@ __global__ __launch_bounds__(64, WAVES) void d4c_wave_kernel(
     wave_sync();
   }
 }
+
+// The frames the two instantiations of d4c_kernel work on (both: d4c.cpp:380).  The usual one takes the frames
+// whose smoothing mirror fits FD / 16 bins (f0 < fs / 16) AND whose 4-period window fits FD / 2 samples (f0 above
+// ~4 fs / FD): every frame behind Dio / Harvest + StoneMask at their default 71-800 Hz range from 12.8 kHz up.
+// The RARE one takes the rest of what the reference defines.
+__host__ __device__ inline bool d4c_is_usual(double cf0, int fd, int fs) {
+  return d4c_mirror_bins(cf0, fd, fs) <= fd / 16 && 2 * matlab_round(2.0 * fs / cf0) + 1 <= fd / 2;
+}
+struct D4cRunUsualPred {
+  const double* f0;
+  const double* ap0;
+  double threshold;
+  int fd, fs;
+  __device__ bool operator()(int i) const {
+    const double v = f0[i];
+    if (!(v != 0.0 && ap0[i] > threshold)) return false;
+    return d4c_is_usual(v > kFloorF0D4C ? v : kFloorF0D4C, fd, fs);
+  }
+};
+struct D4cRunRarePred {
+  const double* f0;
+  const double* ap0;
+  double threshold;
+  int fd, fs;
+  __device__ bool operator()(int i) const {
+    const double v = f0[i];
+    if (!(v != 0.0 && ap0[i] > threshold)) return false;
+    const double cf0 = v > kFloorF0D4C ? v : kFloorF0D4C;
+    // beyond fd / 2 mirror bins the reference reads past its spectrum (common.cpp:62-68, :85-92): default row stays
+    return !d4c_is_usual(cf0, fd, fs) && d4c_mirror_bins(cf0, fd, fs) <= fd / 2;
+  }
+};
 
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
   Context& c = *b.ctx;
@@ -782,14 +537,15 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
       w[(size_t)i] = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) + 0.144232 * cos(4.0 * kPi * tmp) -
                      0.012604 * cos(6.0 * kPi * tmp);
     }
-    rc = wm_check(hipMalloc((void**)&b.d_d4c_window, sizeof(double) * (size_t)wl));
+    double* dw = nullptr;
+    rc = wm_check(hipMalloc((void**)&dw, sizeof(double) * (size_t)wl));
     if (rc) return rc;
-    rc = wm_check(hipMemcpyAsync(b.d_d4c_window, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
-    if (rc) return rc;
-    rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
-    if (rc) return rc;
-    rc = wm_check(hipMalloc((void**)&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
-    if (rc) return rc;
+    rc = wm_check(hipMemcpyAsync(dw, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
+    if (!rc) rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
+    if (!rc) rc = wm_check(hipMalloc((void**)&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
+    if (!rc) rc = wm_check(hipMalloc((void**)&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
+    if (rc) { (void)hipFree(dw); return rc; }
+    b.d_d4c_window = dw;
   }
   D4CTables tab;
   tab.nuttall = b.d_d4c_window;
@@ -821,41 +577,25 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
 #undef WM_LT_CASE
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
-  launch_partition(st, D4cRunPred{d_f0, b.d_ap0, b.p.d4c_threshold}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
-  // Variant choice: the one-wavefront kernel executes about half the instructions per FFT (radix 16/8/8 or
-  // 16/16/8 in registers) and wins at every size -- at fft 4096 (48 kHz) it runs one wave per SIMD on 512
-  // registers and still spills, but takes 11.8 ms where the workgroup-cooperative kernel takes 31.7 ms
-  // (64 utterances, tools/rate_48k.py).  WORLD_MI355_D4C_VARIANT=wave|block overrides.
-  static const int dbg = getenv("WORLD_MI355_D4C_DBG") ? atoi(getenv("WORLD_MI355_D4C_DBG")) : 0;
-  static const char* var = getenv("WORLD_MI355_D4C_VARIANT");
-  const bool use_block = var ? (var[0] == 'b') : false;
-  const int block_waves = (var && var[0] == 'b' && var[5] >= '1' && var[5] <= '3') ? var[5] - '0' : 3;   // block1|block2|block3
+  launch_partition(st, D4cRunUsualPred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt, b.d_perm,
+                   b.d_part_n);
+  // the rare frames (f0 >= fs / 16, or a window longer than FD / 2 samples) are listed separately for the
+  // wide-margin, long-frame instantiation; an empty list costs that launch a few microseconds
+  launch_partition(st, D4cRunRarePred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt, b.d_perm2,
+                   b.d_part_n + 1);
 #define WM_D4C_CASE(FF, WV)                                                                               \
-  case FF:                                                                                                \
-    if (use_block) {                                                                                      \
-      if (block_waves == 1)                                                                               \
-        hipLaunchKernelGGL((d4c_block_kernel<FF, 1>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,       \
-                           b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,      \
-                           c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,   \
-                           (const int*)b.d_part_n, d_ap, dbg);                                            \
-      else if (block_waves == 2)                                                                          \
-        hipLaunchKernelGGL((d4c_block_kernel<FF, 2>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,       \
-                           b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,      \
-                           c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,   \
-                           (const int*)b.d_part_n, d_ap, dbg);                                            \
-      else                                                                                                \
-      hipLaunchKernelGGL((d4c_block_kernel<FF, 3>), dim3(grid), dim3(256), 0, st, d_x, b.d_x_off,         \
-                         b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off,        \
-                         c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm,     \
-                         (const int*)b.d_part_n, d_ap, dbg);                                              \
-    } else {                                                                                              \
-      static const int per_ = persistent_grid(c, d4c_wave_kernel<FF, WV>, 64, (int64_t)1 << 40);          \
-      hipLaunchKernelGGL((d4c_wave_kernel<FF, WV>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,         \
-                         b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,          \
-                         b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,              \
-                         (const int*)b.d_perm, (const int*)b.d_part_n, d_ap, dbg);                        \
-    }                                                                                                     \
-    break;
+  case FF: {                                                                                              \
+    static const int per_ = persistent_grid(c, d4c_kernel<FF, WV, false>, 64, (int64_t)1 << 40);          \
+    hipLaunchKernelGGL((d4c_kernel<FF, WV, false>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,         \
+                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
+                       b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
+                       (const int*)b.d_perm, (const int*)b.d_part_n, d_ap);                               \
+    static const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
+    hipLaunchKernelGGL((d4c_kernel<FF, 1, true>), dim3(imin(grid, per2_)), dim3(64), 0, st, d_x,          \
+                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
+                       b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
+                       (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);                        \
+  } break;
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
     switch (FD) {

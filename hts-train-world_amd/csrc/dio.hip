@@ -221,17 +221,23 @@ __device__ __forceinline__ double dio_select_wave(double cur, double past, doubl
 // compacted into LDS lists up front, the chain state (current and previous f0) lives in registers,
 // the candidates of the next 16 frames are fetched in one round trip with the bands spread over
 // lanes, and results are stored without waiting.
-// ws holds 3 work arrays of the utterance's frame count; dynamic LDS: 2 * (max_nf / 2 + 2) ints.
+// ws holds 3 work arrays of the utterance's frame count.  The edge lists (2 * (max_nf / 2 + 2) ints) live in
+// dynamic LDS while they fit (EDGES_IN_LDS; up to 6 k frames per utterance = 48 KB) and in a per-utterance slice
+// of global memory beyond that: they are read once per voiced section, so where they live does not matter for
+// speed, only for the launch to be possible at all (a 40 s utterance at a 1 ms hop has 40 k frames).
 constexpr int kFixBlk = 16;
+template <bool EDGES_IN_LDS>
 __global__ __launch_bounds__(256) void dio_fix_kernel(const int64_t* __restrict__ f_off,
                                                       const double* __restrict__ cand,
                                                       const double* __restrict__ score, int nb,
                                                       double frame_period, double f0_floor, double allowed,
                                                       int64_t total_frames, int edge_cap, double* __restrict__ ws,
+                                                      int* __restrict__ edges_global,
                                                       double* __restrict__ tpos, double* __restrict__ f0) {
-  extern __shared__ int edges[];                      // [2][edge_cap]: falling (negative), rising (positive)
+  extern __shared__ int edges_lds[];                  // [2][edge_cap]: falling (negative), rising (positive)
   __shared__ int n_edges[2];
   const int u = blockIdx.x;
+  int* edges = EDGES_IN_LDS ? edges_lds : edges_global + (int64_t)u * 2 * edge_cap;
   const int lane = threadIdx.x & 63;
   const int64_t base = f_off[u];
   const int nf = (int)(f_off[u + 1] - base);
@@ -365,6 +371,20 @@ struct DioHost {
   std::vector<double> lowcut, win;
 };
 
+// frees every device buffer dio_setup() allocates and clears the pointers
+static void dio_release(Batch& b) {
+  void** ptrs[] = {(void**)&b.d_dio_lowcut, (void**)&b.d_dio_win, (void**)&b.d_dio_fft, (void**)&b.d_dio_ylen,
+                   (void**)&b.d_dio_yoff, (void**)&b.d_dio_toff, (void**)&b.d_dio_z_off, (void**)&b.d_dio_ev_off,
+                   (void**)&b.d_dio_mean, (void**)&b.d_dio_mean_part, (void**)&b.d_dio_y, (void**)&b.d_dio_tmp,
+                   (void**)&b.d_dio_z, (void**)&b.d_dio_events, (void**)&b.d_dio_ev_cnt, (void**)&b.d_dio_tile_cnt,
+                   (void**)&b.d_dio_slot_off, (void**)&b.d_dio_slots, (void**)&b.d_dio_cand, (void**)&b.d_dio_score,
+                   (void**)&b.d_dio_ws};
+  for (void** p : ptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+}
+
 static int dio_setup(Batch& b) {
   if (b.dio_ready) return WM_OK;
   const WorldMi355Params& p = b.p;
@@ -462,8 +482,13 @@ static int dio_setup(Batch& b) {
   al((void**)&b.d_dio_cand, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_score, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_ws, sizeof(double) * 3 * (size_t)b.total_f);
+  if (rc) {
+    // nothing half-built stays behind: a retry starts from scratch instead of leaking H and the buffers above
+    dio_release(b);
+    delete H;
+    return rc;
+  }
   b.dio_host = H;
-  if (rc) return rc;
   b.dio_ready = true;
   return WM_OK;
 }
@@ -545,9 +570,20 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   {
   TimedScope ts_(b.ctx, "dio_fix_kernel");
   const int edge_cap = b.max_f0_len / 2 + 2;
-  hipLaunchKernelGGL(dio_fix_kernel, dim3(b.n_utt), dim3(256), sizeof(int) * 2 * (size_t)edge_cap, st, b.d_f_off,
-                     b.d_dio_cand, b.d_dio_score, m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f,
-                     edge_cap, b.d_dio_ws, d_t, d_f0);
+  const size_t lds = sizeof(int) * 2 * (size_t)edge_cap;
+  if (lds <= 48 * 1024) {
+    hipLaunchKernelGGL(dio_fix_kernel<true>, dim3(b.n_utt), dim3(256), lds, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,
+                       m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f, edge_cap, b.d_dio_ws,
+                       (int*)nullptr, d_t, d_f0);
+  } else {
+    if (!b.d_dio_edges) {
+      rc = wm_check(hipMalloc((void**)&b.d_dio_edges, sizeof(int) * 2 * (size_t)edge_cap * (size_t)b.n_utt));
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(dio_fix_kernel<false>, dim3(b.n_utt), dim3(256), 0, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,
+                       m.nb, b.p.frame_period, b.p.f0_floor, b.p.allowed_range, b.total_f, edge_cap, b.d_dio_ws,
+                       b.d_dio_edges, d_t, d_f0);
+  }
   }
   return wm_check(hipGetLastError());
 }

@@ -146,30 +146,45 @@ template <> struct FftCfg<2048> { static constexpr int R1 = 16, R2 = 16, R3 = 8;
 // LDS doubles2 needed by one transform of N points (padded image)
 template <int N> struct FftLds { static constexpr int kElems = N + N / FftCfg<N>::R1; };
 
-// per-lane twiddle bases, computed once per kernel
+// exp(-2 pi i k / 64), k = 0..16 (a quarter turn): the lane-uniform twiddle factors below are entries of it
+__device__ __forceinline__ cpx cis64(int k) {
+  constexpr double c[17] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867,
+                            0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476,
+                            0.6343932841636455, 0.5555702330196022, 0.47139673682599764, 0.3826834323650898,
+                            0.2902846772544624, 0.19509032201612828, 0.0980171403295606, 0.0};
+  return make_double2(c[k], -c[16 - k]);
+}
+
+// Per-lane twiddle bases, computed once per kernel.  Only what depends on the lane in a way that cannot be
+// derived cheaply stays in registers for the whole kernel (two complex values); the rest is rebuilt per use:
+//   W_N^(lane + 64 b) = (W_2N^lane)^2 * W_N^(64 b), the second factor a compile-time constant;
+//   W_2N^64 (the step of the real-FFT split twiddles) is a compile-time constant.
+// Persistent frame loops keep these alive across everything else a frame needs, so every register here is one
+// less for the frame (d4c_kernel was spilling exactly these).
 template <int N> struct FftTw {
   static constexpr int M = N / 64;
   static constexpr int S3 = M / FftCfg<N>::R3;
+  static_assert(N >= 512 && 2048 % N == 0, "constant twiddles are tabulated in 64ths of a turn");
   cpx w2;            // W_{R1*R2}^(lane % R1)
-  cpx w3[S3];        // W_N^(lane + 64 b)
-  cpx wsplit;        // W_{2N}^lane          (real-FFT split)
-  cpx wstep;         // W_{2N}^64            (chain step for the split twiddles)
+  cpx wsplit;        // W_{2N}^lane          (real-FFT split; its square is W_N^lane)
   __device__ __forceinline__ void init(int lane) {
     constexpr int R1 = FftCfg<N>::R1, R2 = FftCfg<N>::R2;
     w2 = cis_neg2pi((double)(lane % R1) / (double)(R1 * R2));
-#pragma unroll
-    for (int b = 0; b < S3; ++b) w3[b] = cis_neg2pi((double)(lane + 64 * b) / (double)N);
     wsplit = cis_neg2pi((double)lane / (double)(2 * N));
-    wstep = cis_neg2pi(64.0 / (double)(2 * N));
   }
+  // W_N^(lane + 64 b): pass-3 twiddle base of butterfly b
+  __device__ __forceinline__ cpx w3(int b) const {
+    const cpx sq = make_double2(wsplit.x * wsplit.x - wsplit.y * wsplit.y, 2.0 * wsplit.x * wsplit.y);
+    return b == 0 ? sq : cmul(sq, cis64(b * (4096 / N)));          // 64 b / N turns = b * 4096 / N 64ths
+  }
+  // W_{2N}^64: chain step of the split twiddles (64 / 2N turns = 2048 / N 64ths)
+  __device__ __forceinline__ cpx wstep() const { return cis64(2048 / N); }
   // Compiler fence for persistent (grid-stride) kernels: called at the top of every frame, it makes
   // the twiddle bases opaque so that nothing derived from them (powers, products) is hoisted out of
   // the frame loop -- LICM otherwise precomputes dozens of twiddle powers and LDS addresses once per
   // kernel and then spills them, which costs far more than recomputing a few FMAs per transform.
   __device__ __forceinline__ void fence() {
-    asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(wsplit.x), "+v"(wsplit.y), "+v"(wstep.x), "+v"(wstep.y));
-#pragma unroll
-    for (int b = 0; b < S3; ++b) asm volatile("" : "+v"(w3[b].x), "+v"(w3[b].y));
+    asm volatile("" : "+v"(w2.x), "+v"(w2.y), "+v"(wsplit.x), "+v"(wsplit.y));
   }
 };
 
@@ -236,7 +251,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     cpx a[R3];
 #pragma unroll
     for (int r = 0; r < R3; ++r) a[r] = v[b + r * S3];
-    apply_twiddle_powers<R3>(a, tw.w3[b]);
+    apply_twiddle_powers<R3>(a, tw.w3(b));
     Dft<R3>::run(a);
 #pragma unroll
     for (int r = 0; r < R3; ++r) v[b + r * S3] = a[r];
@@ -281,7 +296,7 @@ __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* sp
     cpx d = csub(a, b);
     cpx o = make_double2(0.5 * d.y, -0.5 * d.x);             // (a-b)/(2i)
     xk[m] = cadd(e, cmul(w, o));
-    w = cmul(w, tw.wstep);
+    w = cmul(w, tw.wstep());
   }
   cpx z0 = lds[0];
   wave_sync();
@@ -303,7 +318,7 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
   asm volatile("" : "+v"(lane));
   const_cast<FftTw<N>&>(tw).fence();
   cpx w = cconj(tw.wsplit);                                  // e^{+j pi k / N}
-  const cpx wst = cconj(tw.wstep);
+  const cpx wst = cconj(tw.wstep());
   wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) {

@@ -996,10 +996,13 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
 }
 
 // ---- host side ------------------------------------------------------------------------------
+void harvest_free(void* p);
+
 static int hv_setup(Batch& b) {
   if (b.harvest_ws) return WM_OK;
+  // the workspace is published on the batch only once every allocation and upload has succeeded: a half-built
+  // one would make the next call skip the set-up and launch with null device pointers
   HarvestWs* W = new HarvestWs();
-  b.harvest_ws = W;
   HvMeta& m = W->m;
   const WorldMi355Params& p = b.p;
   const double adj_floor = p.f0_floor * 0.9, adj_ceil = p.f0_ceil * 1.1;
@@ -1009,7 +1012,7 @@ static int hv_setup(Batch& b) {
   m.lag = m.r == 1 ? 0 : (int)(ceil(140.0 / m.r) * m.r);
   m.cpf = matlab_round(m.nch / 10.0);
   m.maxc = m.cpf * kHvOverlap;
-  if (m.maxc > 64 * kSelPer) { b.harvest_ws = nullptr; delete W; return WM_ERR_UNSUPPORTED; }   // hv_select_wave: candidates over lanes
+  if (m.maxc > 64 * kSelPer) { delete W; return WM_ERR_UNSUPPORTED; }   // hv_select_wave: candidates over lanes
   std::vector<double> bf((size_t)m.nch), taps;
   std::vector<int> half((size_t)m.nch), tapoff((size_t)m.nch);
   m.ntap_max = 0;
@@ -1109,7 +1112,12 @@ static int hv_setup(Batch& b) {
     hipLaunchKernelGGL(hv_twiddle_kernel, dim3(kHvTwid / 256), dim3(256), 0, b.ctx->stream, W->d_twid);
     rc = wm_check(hipGetLastError());
   }
-  return rc;
+  if (rc) {
+    harvest_free(W);
+    return rc;
+  }
+  b.harvest_ws = W;
+  return WM_OK;
 }
 
 void harvest_free(void* p) {

@@ -88,8 +88,10 @@ inline void launch_partition(hipStream_t st, Pred pred, int n, int* block_cnt, i
   hipLaunchKernelGGL(partition_scatter_kernel<Pred>, dim3(nb), dim3(256), 0, st, pred, n, block_cnt, perm, n_true);
 }
 
+// readfirstlane: the entry is the same for every lane (the position depends on the workgroup only); saying so
+// keeps the frame index, and every per-frame quantity loaded through it, in scalar registers
 __device__ __forceinline__ int64_t listed_at(const int* __restrict__ perm, int64_t pos, int64_t count) {
-  return pos < count ? (int64_t)perm[pos] : -1;
+  return pos < count ? (int64_t)__builtin_amdgcn_readfirstlane(perm[pos]) : -1;
 }
 // Persistent-grid loop over perm[0 .. count): `frame` is the listed index; XCD-aware like WM_FOR_EACH_FRAME.
 // The entry of the next round is requested at the top of the body, so its latency is not in front of the

@@ -84,7 +84,6 @@ def load_library():
     L.WorldMi355ComposeCmp.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.WorldMi355HtkHeader.restype = None
     L.WorldMi355HtkHeader.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    L.WorldMi355TestRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.WorldMi355TimingEnable.argtypes = [vp, C.c_int]
     L.WorldMi355TimingQuery.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     _lib = L
@@ -323,20 +322,6 @@ class WorldBatch:
         if self.handle:
             load_library().WorldMi355DestroyBatch(self.handle)
             self.handle = None
-
-
-def test_rfft(ctx: Context, x):
-    """Run the in-kernel wavefront real FFT on the rows of x (cuda float64 [count, n])."""
-    import torch
-    count, n = x.shape
-    re = torch.empty(count, n // 2 + 1, dtype=torch.float64, device="cuda")
-    im = torch.empty_like(re)
-    xb = torch.empty_like(x)
-    _check(load_library().WorldMi355TestRfft(ctx.handle, n, count, C.c_void_p(x.data_ptr()),
-                                             C.c_void_p(re.data_ptr()), C.c_void_p(im.data_ptr()),
-                                             C.c_void_p(xb.data_ptr())), "TestRfft")
-    ctx.synchronize()
-    return re, im, xb
 
 
 def htk_header(n_frames, sampling_rate, frame_shift_samples, bytes_per_frame, htk_type=9):

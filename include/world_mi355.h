@@ -157,11 +157,6 @@ void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_sample
 int WorldMi355TimingEnable(WorldMi355Context* ctx, int on);
 int WorldMi355TimingQuery(WorldMi355Context* ctx, const char* kernel, double* total_ms, int* launches);
 
-/* Test hook: forward/backward real FFT of `count` rows of length n (512..4096) through the
- * in-kernel wavefront FFT; layouts as fft.cpp:26-72 (re/im split, n/2+1 bins). */
-int WorldMi355TestRfft(WorldMi355Context* ctx, int n, int count, const double* x, double* re,
-                       double* im, double* x_back);
-
 #ifdef __cplusplus
 }
 #endif

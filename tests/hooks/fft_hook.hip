@@ -1,6 +1,8 @@
-// fft_test.hip -- test hook exposing the wavefront FFT (fft.hpp) through the C ABI
-// (WorldMi355TestRfft) so that tests can check it against numpy; not on the product path.
-#include "batch.hpp"
+// fft_hook.hip -- TEST INFRASTRUCTURE: exposes the wavefront FFT engine of the product (csrc/fft.hpp) through a
+// small shared library of its own (tests/hooks/libfft_hook.so), so that tests can check it against numpy.
+// Nothing here is linked into libworld_mi355.so.
+#include <hip/hip_runtime.h>
+
 #include "fft.hpp"
 
 namespace wm {
@@ -45,15 +47,19 @@ __global__ __launch_bounds__(64) void rfft_test_kernel(int count, const double* 
   }
 }
 
-int launch_test_rfft(Context* ctx, int n, int count, const double* x, double* re, double* im, double* xb) {
+}  // namespace wm
+
+// Forward / backward real FFT of `count` rows of length n (1024, 2048, 4096) on `stream`; layouts as
+// externs/WORLD_v2/src/fft.cpp:26-72 (re / im split, n / 2 + 1 bins).  Returns 0, or -1 for another n.
+extern "C" int FftHookRfft(void* stream, int n, int count, const double* x, double* re, double* im, double* xb) {
+  using namespace wm;
+  hipStream_t st = (hipStream_t)stream;
   const int grid = count < 1024 ? count : 1024;
   switch (n) {
-    case 1024: hipLaunchKernelGGL(rfft_test_kernel<1024>, dim3(grid), dim3(64), 0, ctx->stream, count, x, re, im, xb); break;
-    case 2048: hipLaunchKernelGGL(rfft_test_kernel<2048>, dim3(grid), dim3(64), 0, ctx->stream, count, x, re, im, xb); break;
-    case 4096: hipLaunchKernelGGL(rfft_test_kernel<4096>, dim3(grid), dim3(64), 0, ctx->stream, count, x, re, im, xb); break;
-    default: return WM_ERR_UNSUPPORTED_FFT;
+    case 1024: hipLaunchKernelGGL(rfft_test_kernel<1024>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
+    case 2048: hipLaunchKernelGGL(rfft_test_kernel<2048>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
+    case 4096: hipLaunchKernelGGL(rfft_test_kernel<4096>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
+    default: return -1;
   }
-  return wm_check(hipGetLastError());
+  return hipGetLastError() == hipSuccess ? (hipStreamSynchronize(st) == hipSuccess ? 0 : -2) : -2;
 }
-
-}  // namespace wm

@@ -37,12 +37,28 @@ def cat(rs, k):
     return np.concatenate([r[k] for r in rs])
 
 
+def fft_hook(torch, x):
+    """The product's wavefront FFT (csrc/fft.hpp) on the rows of x, through tests/hooks/libfft_hook.so."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libfft_hook.so"))
+    count, n = x.shape
+    re = torch.empty(count, n // 2 + 1, dtype=torch.float64, device="cuda")
+    im, xb = torch.empty_like(re), torch.empty_like(x)
+    vp = C.c_void_p
+    lib.FftHookRfft.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    torch.cuda.synchronize()
+    rc = lib.FftHookRfft(vp(torch.cuda.current_stream().cuda_stream), n, count, vp(x.data_ptr()), vp(re.data_ptr()),
+                         vp(im.data_ptr()), vp(xb.data_ptr()))
+    assert rc == 0
+    return re, im, xb
+
+
 @pytest.mark.parametrize("n", [1024, 2048, 4096])
 def test_wavefront_fft_vs_numpy(gpu, n):
     torch, W, ctx = gpu
     g = torch.Generator(device="cuda").manual_seed(n)
     x = torch.randn(96, n, dtype=torch.float64, device="cuda", generator=g)
-    re, im, xb = W.test_rfft(ctx, x)
+    re, im, xb = fft_hook(torch, x)
     ref = np.fft.rfft(x.cpu().numpy(), axis=1)
     scale = np.abs(ref).max()
     assert np.abs(re.cpu().numpy() + 1j * im.cpu().numpy() - ref).max() < 1e-14 * n * scale
@@ -237,6 +253,35 @@ def test_edge_cases(gpu, oracle):
     ap = b.d4c(dev(x), dev(to), dev(f0r)).cpu().numpy()
     np.testing.assert_allclose(ap, oracle.d4c(x, fs, to, f0r, 1024, 0.85), atol=AP_TOL, rtol=0)
     b.close()
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_d4c_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
+    """D4C analyses every frame with f0 != 0 (d4c.cpp:380-382), also where Dio would never put one: windows longer
+    than half the D4C FFT (f0 towards the 47 Hz floor and below it) and smoothing widths beyond fs/16 (raised
+    f0_ceil).  Those frames take the second instantiation of the kernel; the usual ones beside them the first."""
+    torch, W, ctx = gpu
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    x = sd.make_utterance(70, fs, duration=0.6)
+    t, f0d = oracle.dio(x, fs)
+    nf = len(t)
+    f0 = np.full(nf, 180.0)
+    f0[0::7] = 30.0                  # below the floor: analysed at 47 Hz, window of 4 periods > FD / 2 samples
+    f0[1::7] = 55.0                  # long window
+    f0[2::7] = fs / 16.0 + 50.0      # mirror wider than FD / 16 bins
+    f0[3::7] = 1200.0                # raised ceiling
+    f0[4::7] = fs / 5.0
+    f0[5::7] = 0.0
+    F = oracle.cheaptrick_fft_size(fs)
+    want = oracle.d4c(x, fs, t, f0, F, 0.0)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    got = b.d4c(dev(x), dev(t), dev(f0)).cpu().numpy()
+    b.close()
+    np.testing.assert_allclose(got, want, atol=AP_TOL, rtol=0)
+    assert np.all(got[5::7] == 1.0 - 1e-12) and np.all(got[2::7] != 1.0 - 1e-12)
+    # the same through the drop-in entry point, as a caller with a raised f0_ceil would reach it
+    got2 = pkg.capi.d4c(x, fs, t, f0, F, threshold=0.0)
+    np.testing.assert_array_equal(got2, got)
 
 
 def test_full_size_properties(gpu, oracle):

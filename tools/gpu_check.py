@@ -17,12 +17,6 @@ def main():
     fs = 16000
     ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
     o = Oracle()
-    # FFT
-    for n in (1024, 2048, 4096):
-        x = torch.randn(64, n, dtype=torch.float64, device="cuda")
-        re, im, xb = W.test_rfft(ctx, x)
-        ref = np.fft.rfft(x.cpu().numpy(), axis=1)
-        print(f"rfft{n}: max|d| fwd {np.abs(re.cpu().numpy() + 1j*im.cpu().numpy() - ref).max():.3e}  roundtrip/n {np.abs(xb.cpu().numpy()/n - x.cpu().numpy()).max():.3e}", flush=True)
     nutt = int(os.environ.get("NUTT", "3"))
     xs = [sd.make_utterance(i, fs, (2.0, 4.0)) for i in range(nutt)]
     p = W.default_params(fs, 5.0)
