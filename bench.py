@@ -58,7 +58,7 @@ def d4c_flops_per_voiced_frame(fs):
 # HBM-side bytes of the dominant kernel come from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # runs, tools/pmc_hbm.sh) stored in profiles/pmc_traffic.json together with a hash of the kernel's sources: when the
 # sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
-D4C_SOURCES = ("d4c.hip", "fft.hpp", "common.hpp", "window.hpp", "partition.hpp", "wavesync.hpp")
+D4C_SOURCES = ("d4c.hip", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp", "partition.hpp", "wavesync.hpp")
 
 
 def kernel_source_hash():
@@ -79,12 +79,15 @@ def measured_traffic(fs):
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json missing"
     sha = kernel_source_hash()
-    for r in recs:
-        if r.get("fs") == fs and r.get("source_sha") == sha:
+    mine = [r for r in recs if r.get("fs") == fs]
+    if not mine:
+        return None, "no PMC passes recorded for fs %d in profiles/pmc_traffic.json" % fs
+    for r in mine:
+        if r.get("source_sha") == sha:
             per = (r["fetch_kb"] + r["write_kb"]) * 1024.0 / r["frames"]
             return per, "PMC FETCH_SIZE + WRITE_SIZE of %s, separate passes (%s), %d frames" % (
                 r["kernel"], r.get("files", "profiles/"), r["frames"])
-    return None, "kernel sources changed since the PMC passes in profiles/pmc_traffic.json (hash %s)" % sha
+    return None, "kernel sources changed since the PMC passes in profiles/pmc_traffic.json (now %s)" % sha
 
 
 def parse():

@@ -129,6 +129,7 @@ struct Batch {
   double* d_vuv = nullptr;           // [total_y] interpolated vuv
   double* d_phase = nullptr;         // [total_y] scratch (increments / wrapped phase)
   int* d_pulse_cnt = nullptr;        // [n_utt]
+  int* d_pulse_tile_cnt = nullptr;   // [n_utt][tiles] pulses per search tile
   int64_t* d_pulse_off = nullptr;    // [n_utt+1]
   int* h_pulse_cnt = nullptr;        // pinned
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
@@ -154,6 +155,8 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);
 int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y);
 int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
                               double* d_y);
+int launch_utterance_status(Batch& b, const double* d_x, const double* d_f0, const double* d_sp, const double* d_ap,
+                            int* d_status);
 int codec_num_aperiodicities(int fs);
 int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded);
 int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);

@@ -262,6 +262,10 @@ int WorldMi355AnalyzeSynthesize(WorldMi355Batch* hb, const double* x, double* t,
                                 double* ap, double* y) {
   return launch_analyze_synthesize(hb->b, x, t, f0, sp, ap, y);
 }
+int WorldMi355UtteranceStatus(WorldMi355Batch* hb, const double* x, const double* f0, const double* sp,
+                              const double* ap, int* status) {
+  return launch_utterance_status(hb->b, x, f0, sp, ap, status);
+}
 int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
   Context& c = h->c;
   int rc = wm_check(hipStreamSynchronize(c.stream));

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
     int c = 0;
     if (i < nf) {
       double v = f0[base + i];
-      double cf0 = v <= f0_floor ? kDefaultF0 : v;
+      double cf0 = !(v > f0_floor) ? kDefaultF0 : v;     // v <= floor (cheaptrick.cpp:217); a NaN f0 also takes the default
       c = 2 * matlab_round(1.5 * fs / cf0) + 1 + fft_size / 2 + 1;
     }
     part[threadIdx.x] = c;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
     tw.fence();
     const int u = frame_utt[frame];
     const double f0v = f0[frame];
-    const double cf0 = f0v <= f0_floor ? kDefaultF0 : f0v;     // cheaptrick.cpp:217
+    const double cf0 = !(f0v > f0_floor) ? kDefaultF0 : f0v;   // f0 <= floor (cheaptrick.cpp:217); NaN too
     const int roff = rng_off[frame];
     cpx v[M];
 

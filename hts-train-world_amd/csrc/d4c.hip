@@ -185,7 +185,8 @@ struct D4CTables {
 
 // bins the widest LinearSmoothing of a frame mirrors at either end (width = f0; common.cpp:80)
 __host__ __device__ inline int d4c_mirror_bins(double cf0, int fft_size_d4c, int fs) {
-  return (int)(cf0 * fft_size_d4c / fs) + 1;
+  const double q = cf0 * fft_size_d4c / fs;
+  return q < 1.0e6 ? (int)q + 1 : 1 << 30;      // an infinite f0 from the caller must not wrap around the int range
 }
 // margin of the spectrum in LDS: the usual kernel covers f0 < fs / 16, the RARE one everything the
 // reference defines (its DCCorrection reads past the spectrum from f0 ~ fs / 2 on, common.cpp:62-68)

@@ -166,60 +166,96 @@ __device__ __forceinline__ double wrap_two_pi(double t) {
   return w;
 }
 
-// Part 3 (synthesis.cpp:253-285): pulses where the wrapped phase jumps by more than pi, compacted in
-// order.  One 256-thread workgroup per utterance walks it in tiles with a running count.
+// Part 3 (synthesis.cpp:253-285): pulses where the wrapped phase jumps by more than pi, compacted in order.
+// Every tile of kSearchTile samples is its own workgroup (an utterance of 8 s at 48 kHz has 188 of them; walking
+// them in order on one workgroup was 8 ms of latency chain): WRITE = false counts the tile's pulses,
+// WRITE = true adds up the counts of the tiles before it and writes the tile's pulses at that offset.
+constexpr int kSearchSub = 8, kSearchTile = 256 * kSearchSub;
+template <bool WRITE>
 __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
-    const int64_t* __restrict__ y_off, const double* __restrict__ phase, int fs, int* __restrict__ pulse_idx,
-    double* __restrict__ pulse_shift, int* __restrict__ pulse_cnt) {
+    const int64_t* __restrict__ y_off, const double* __restrict__ phase, int fs, int tiles_max,
+    int* __restrict__ tile_cnt, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
+    int* __restrict__ pulse_cnt) {
 #pragma clang fp contract(off)
-  constexpr int kSub = 8;                                   // sub-tiles of 256 samples per trip
-  __shared__ int wave_cnt[kSub][4];
-  const int u = blockIdx.x;
+  __shared__ int wave_cnt[kSearchSub][4];
+  __shared__ int red[4];
+  const int u = blockIdx.y, tile = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
+  const int i0 = tile * kSearchTile;
+  if (i0 >= ylen && !(WRITE && tile == 0)) return;
+  int* cnt_u = tile_cnt + (int64_t)u * tiles_max;
   int count = 0;
-  for (int i0 = 0; i0 < ylen; i0 += 256 * kSub) {
-    // all loads of the trip first: one memory round trip per 2048 samples
-    double tc[kSub], tp[kSub];
-#pragma unroll
-    for (int q = 0; q < kSub; ++q) {
-      const int i = i0 + 256 * q + threadIdx.x;
-      const bool in = i >= 1 && i < ylen;
-      tc[q] = phase[yb + (in ? i : 0)];
-      tp[q] = phase[yb + (in ? i - 1 : 0)];
+  if (WRITE) {
+    // pulses of the tiles before this one (and, on tile 0, of the whole utterance)
+    const int ntile = (ylen + kSearchTile - 1) / kSearchTile;
+    int before = 0, all = 0;
+    for (int j = threadIdx.x; j < ntile; j += 256) {
+      const int c = cnt_u[j];
+      all += c;
+      if (j < tile) before += c;
     }
-    bool hit[kSub];
-    double wrap[kSub], prev[kSub];
-    unsigned long long bal[kSub];
-#pragma unroll
-    for (int q = 0; q < kSub; ++q) {
-      const int i = i0 + 256 * q + threadIdx.x;
-      wrap[q] = wrap_two_pi(tc[q]);
-      prev[q] = wrap_two_pi(tp[q]);
-      // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
-      hit[q] = i >= 1 && i < ylen && fabs(wrap[q] - prev[q]) > kPi;
-      bal[q] = __ballot(hit[q]);
-      if (lane == 0) wave_cnt[q][wv] = __popcll(bal[q]);
-    }
+    before = wave_sum_i(before);
+    all = wave_sum_i(all);
+    if (lane == 0) red[wv] = before;
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kSub; ++q) {
-      const int i = i0 + 256 * q + threadIdx.x;
-      int base = count;
-      for (int w = 0; w < wv; ++w) base += wave_cnt[q][w];
-      if (hit[q]) {
-        const int dst = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
-        const double y1 = prev[q] - 2.0 * kPi, y2 = wrap[q];  // :271-274
-        const double xx = -y1 / (y2 - y1);
-        pulse_idx[yb + dst] = i - 1;
-        pulse_shift[yb + dst] = xx / fs;
-      }
-      count += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
-    }
+    count = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
+    if (tile == 0) {
+      if (lane == 0) red[wv] = all;
+      __syncthreads();
+      if (threadIdx.x == 0) pulse_cnt[u] = red[0] + red[1] + red[2] + red[3];
+      __syncthreads();
+    }
+    if (i0 >= ylen) return;
   }
-  if (threadIdx.x == 0) pulse_cnt[u] = count;
+  // all loads of the tile first: one memory round trip
+  double tc[kSearchSub], tp[kSearchSub];
+#pragma unroll
+  for (int q = 0; q < kSearchSub; ++q) {
+    const int i = i0 + 256 * q + threadIdx.x;
+    const bool in = i >= 1 && i < ylen;
+    tc[q] = phase[yb + (in ? i : 0)];
+    tp[q] = phase[yb + (in ? i - 1 : 0)];
+  }
+  bool hit[kSearchSub];
+  double wrap[kSearchSub], prev[kSearchSub];
+  unsigned long long bal[kSearchSub];
+#pragma unroll
+  for (int q = 0; q < kSearchSub; ++q) {
+    const int i = i0 + 256 * q + threadIdx.x;
+    wrap[q] = wrap_two_pi(tc[q]);
+    prev[q] = wrap_two_pi(tp[q]);
+    // pulse at index i-1 when |wrap[i] - wrap[i-1]| > pi (:254-259)
+    hit[q] = i >= 1 && i < ylen && fabs(wrap[q] - prev[q]) > kPi;
+    bal[q] = __ballot(hit[q]);
+    if (lane == 0) wave_cnt[q][wv] = __popcll(bal[q]);
+  }
+  __syncthreads();
+  if (!WRITE) {
+    if (threadIdx.x == 0) {
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < kSearchSub; ++q) c += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+      cnt_u[tile] = c;
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < kSearchSub; ++q) {
+    const int i = i0 + 256 * q + threadIdx.x;
+    int base = count;
+    for (int w = 0; w < wv; ++w) base += wave_cnt[q][w];
+    if (hit[q]) {
+      const int dst = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
+      const double y1 = prev[q] - 2.0 * kPi, y2 = wrap[q];  // :271-274
+      const double xx = -y1 / (y2 - y1);
+      pulse_idx[yb + dst] = i - 1;
+      pulse_shift[yb + dst] = xx / fs;
+    }
+    count += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+  }
 }
 
 __global__ void synth_dc_remover_kernel(int fft_size, double* __restrict__ dcr) {   // GetDCRemover :322-334
@@ -573,6 +609,8 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     al((void**)&b.d_vuv, sizeof(double) * (size_t)b.total_y);
     al((void**)&b.d_phase, sizeof(double) * (size_t)b.total_y);
     al((void**)&b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt);
+    al((void**)&b.d_pulse_tile_cnt,
+       sizeof(int) * (size_t)b.n_utt * (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1));
     al((void**)&b.d_pulse_off, sizeof(int64_t) * ((size_t)b.n_utt + 1));
     al((void**)&b.d_dc_remover, sizeof(double) * (size_t)F);
     if (rc) return rc;
@@ -596,8 +634,11 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   }
   {
     TimedScope ts_(b.ctx, "synth_search_kernel");
-    hipLaunchKernelGGL(synth_pulse_search_kernel, dim3(b.n_utt), dim3(256), 0, st, b.d_y_off, b.d_phase, fs,
-                       b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
+    const int tiles_max = (b.max_y_len + kSearchTile - 1) / kSearchTile + 1;
+    hipLaunchKernelGGL(synth_pulse_search_kernel<false>, dim3(tiles_max, b.n_utt), dim3(256), 0, st, b.d_y_off,
+                       b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
+    hipLaunchKernelGGL(synth_pulse_search_kernel<true>, dim3(tiles_max, b.n_utt), dim3(256), 0, st, b.d_y_off,
+                       b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
   }
   rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
                                hipMemcpyDeviceToHost, st));

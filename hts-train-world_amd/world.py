@@ -74,6 +74,7 @@ def load_library():
     L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
     L.WorldMi355AnalyzeSynthesize.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.WorldMi355UtteranceStatus.argtypes = [vp, vp, vp, vp, vp, vp]
     L.WorldMi355GetNumberOfAperiodicities.argtypes = [C.c_int]
     L.WorldMi355CodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
     L.WorldMi355DecodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
@@ -233,6 +234,15 @@ class WorldBatch:
         _check(load_library().WorldMi355Synthesis(self.handle, self._p(f0), self._p(sp), self._p(ap), self._p(y)),
                "Synthesis")
         return y
+
+    def utterance_status(self, x=None, f0=None, sp=None, ap=None):
+        """int32 cuda tensor [n_utt] of WM_UTT_* flags (1 non-finite input, 2 too short for Dio, 4 non-finite output)."""
+        import torch
+        st = torch.zeros(self.n_utt, dtype=torch.int32, device="cuda")
+        ptr = lambda t: None if t is None else self._p(t)
+        _check(load_library().WorldMi355UtteranceStatus(self.handle, ptr(x), ptr(f0), ptr(sp), ptr(ap),
+                                                        C.c_void_p(st.data_ptr())), "UtteranceStatus")
+        return st
 
     # ---- feature codec (world/codec.h; SURVEY.md section 8(f)) ----
     def code_spectral_envelope(self, sp, number_of_dimensions):

@@ -107,6 +107,16 @@ int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0
 int WorldMi355AnalyzeSynthesize(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
                                 double* ap, double* y);
 
+/* Per-utterance status of a batch: status[u] (DEVICE pointer, n_utt ints) receives a bit mask.  Utterances of a
+ * batch never exchange data, so one with a flag set does not affect the results of the others (SURVEY.md section 5;
+ * the reference has no error reporting: every entry point returns void).  x, f0, sp, ap are the arrays of the
+ * analysis calls; any of them may be NULL and is then not scanned.  Asynchronous on the context's stream. */
+#define WM_UTT_INPUT_NONFINITE 1   /* NaN / Inf among the samples of x */
+#define WM_UTT_TOO_SHORT 2         /* f0_length <= Dio's voice_range_minimum: f0 is all zero (dio.cpp:263-266) */
+#define WM_UTT_OUTPUT_NONFINITE 4  /* NaN / Inf among the utterance's f0 / sp / ap */
+int WorldMi355UtteranceStatus(WorldMi355Batch* b, const double* x, const double* f0, const double* sp,
+                              const double* ap, int* status);
+
 /* ---- Feature codec (externs/WORLD_v2/src/codec.cpp), SURVEY.md section 8(f) ---------------------------
  * All arrays are device pointers over the batch's frames (row-major, frame order of the batch).
  *   coded sp : double[total_frames][number_of_dimensions]

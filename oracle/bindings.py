@@ -40,7 +40,8 @@ class Oracle:
     kind = "port"
 
     def __init__(self, path: str | None = None):
-        path = path or os.path.join(HERE, "liboracle.so")
+        # ORACLE_LIB selects another build of the same sources (make -C oracle asan: tests/test_sanitizers.py)
+        path = path or os.environ.get("ORACLE_LIB") or os.path.join(HERE, "liboracle.so")
         if not os.path.exists(path):
             build(ref=False)
         self.lib = L = C.CDLL(path)

@@ -284,6 +284,90 @@ def test_d4c_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
     np.testing.assert_array_equal(got2, got)
 
 
+def test_long_utterance_at_1ms_hop(gpu, oracle):
+    """21 s at a 1 ms hop = 21 001 frames: the contour fix's edge lists (2 x (T / 2 + 2) ints) no longer fit the
+    48 KB of LDS they use for ordinary lengths and move to global memory (dio.hip, dio_fix_kernel<false>)."""
+    torch, W, ctx = gpu
+    fs, fp = 16000, 1.0
+    x = np.concatenate([sd.make_utterance(90 + k, fs, duration=7.0) for k in range(3)])
+    b = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(x)])
+    assert b.total_frames == 21001
+    t, f0 = b.dio(torch.from_numpy(x).cuda())
+    to, fo = oracle.dio(x, fs, fp)
+    np.testing.assert_array_equal(t.cpu().numpy(), to)
+    np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+    assert (fo > 0).sum() > 5000
+    b.close()
+
+
+def test_status_flags_and_batch_isolation(gpu):
+    """A bad utterance is reported and does not touch its neighbours: NaN / Inf samples in
+    one utterance of a batch, a too-short one beside it; the others come out bit-identical to a clean batch."""
+    torch, W, ctx = gpu
+    fs = 16000
+    xs = [sd.make_utterance(80 + k, fs, duration=d) for k, d in enumerate((0.6, 0.9, 0.03, 0.7))]
+    bad = [x.copy() for x in xs]
+    bad[1][3000] = np.nan
+    bad[1][7000:7004] = np.inf
+    bad[1][9000] = -np.inf
+    lens = [len(x) for x in xs]
+    outs = []
+    for batch_xs in (xs, bad):
+        b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+        xc = torch.from_numpy(np.concatenate(batch_xs)).cuda()
+        t, f0, sp, ap, y = b.analyze_synthesize(xc)
+        st = b.utterance_status(xc, f0, sp, ap).cpu().numpy()
+        outs.append((b.split_frames(f0), b.split_frames(sp), b.split_frames(ap), b.split_out(y), st))
+        assert torch.isfinite(y[b.out_offsets[3]:]).all()
+        b.close()
+    clean, dirty = outs
+    assert list(clean[4]) == [0, 0, 2, 0]                         # WM_UTT_TOO_SHORT: 7 frames
+    assert dirty[4][1] & 1 and dirty[4][1] & 4 and list(dirty[4][[0, 2, 3]]) == [0, 2, 0]
+    for u in (0, 2, 3):
+        for k in range(4):
+            assert torch.equal(clean[k][u], dirty[k][u]), (u, k)
+    # (the damaged utterance itself is lost as a whole: Dio subtracts the mean over all its samples, dio.cpp:74-79)
+
+
+def test_full_size_batches(gpu, oracle):
+    """BASELINE.json's full sizes in the test suite proper: configs[1] (256 utterances of 2-8 s, analysis + synthesis)
+    and configs[4] (Synthesis only over 1024 feature sets): properties that do not need the oracle on everything --
+    run-to-run bit identity, ranges, the response scratch in several chunks giving the same bits -- plus spot
+    parity on the shortest and the longest utterance."""
+    torch, W, ctx = gpu
+    fs = 16000
+    xs = sd.make_batch(256, fs, (2.0, 8.0), first=0, workers=16)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    assert b.total_frames > 250_000
+    xc = torch.from_numpy(np.concatenate(xs)).cuda()
+    t, f0, sp, ap, y = b.analyze_synthesize(xc)
+    r1 = [v.clone() for v in (f0, sp, ap, y)]
+    t, f0, sp, ap, y = b.analyze_synthesize(xc)
+    for a, c in zip(r1, (f0, sp, ap, y)):
+        assert torch.equal(a, c)
+    assert int(b.utterance_status(xc, f0, sp, ap).max()) == 0
+    assert bool(((f0 == 0) | ((f0 >= 40.0) & (f0 <= 1000.0))).all())
+    assert bool((sp > 0).all()) and bool(((ap > 0) & (ap <= 1.0)).all()) and float(y.abs().max()) < 2.0
+    order = np.argsort([len(x) for x in xs])
+    for u in (int(order[0]), int(order[-1])):
+        r = oracle_chain(oracle, xs[u], fs)
+        g = slice(b.frame_offsets[u], b.frame_offsets[u + 1])
+        np.testing.assert_allclose(f0[g].cpu().numpy(), r["f0"], atol=F0_TOL, rtol=0)
+        sp_close(sp[g].cpu().numpy(), r["sp"])
+        np.testing.assert_allclose(ap[g].cpu().numpy(), r["ap"], atol=AP_TOL, rtol=0)
+        np.testing.assert_allclose(y[b.out_offsets[u]:b.out_offsets[u + 1]].cpu().numpy(), r["y"], atol=Y_TOL, rtol=0)
+    # configs[4]: 1024 feature sets = these 256 four times over, synthesised as one batch
+    T = np.diff(b.frame_offsets).tolist() * 4
+    Y = np.diff(b.out_offsets).tolist() * 4
+    bs = W.WorldBatch(ctx, W.default_params(fs, 5.0), f0_lengths=T, y_lengths=Y)
+    y4 = bs.synthesize(f0.repeat(4), sp.repeat(4, 1), ap.repeat(4, 1))
+    n = int(b.total_out)
+    for k in range(4):
+        assert torch.equal(y4[k * n:(k + 1) * n], y)           # the same pulses whatever the batch around them
+    bs.close()
+    b.close()
+
+
 def test_full_size_properties(gpu, oracle):
     """Config-2-sized durations (2-8 s): size-independent properties + spot parity."""
     torch, W, ctx = gpu

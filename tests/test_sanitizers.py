@@ -1,0 +1,33 @@
+"""The CPU restatement under AddressSanitizer + UndefinedBehaviorSanitizer (the reference has
+none; `make -C oracle asan`).  The golden-vector and primitive suites are re-run in a child interpreter with the
+sanitizer runtimes preloaded and ORACLE_LIB pointing at the instrumented build; any report fails the run.
+CPU only: the GPU pool offers no sanitizers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _runtime(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_oracle_suites_under_asan_ubsan():
+    asan, ubsan = _runtime("libasan.so"), _runtime("libubsan.so")
+    if not asan or not ubsan:
+        pytest.skip("gcc sanitizer runtimes not installed")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    env = dict(os.environ, ORACLE_LIB=os.path.join(ROOT, "oracle", "liboracle_asan.so"),
+               LD_PRELOAD=asan + ":" + ubsan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",     # CPython itself leaks by design
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_golden.py"), os.path.join(ROOT, "tests", "test_oracle_primitives.py"),
+                        "-m", "not gpu"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "passed" in r.stdout and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]

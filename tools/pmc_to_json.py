@@ -1,0 +1,55 @@
+"""Turn the two PMC passes of tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, counter_collection CSVs)
+into one record of profiles/pmc_traffic.json: HBM-side KB of the dominant kernel, the frames it processed, and a hash
+of the kernel's sources (bench.py prints `roofline.traffic` only while that hash still matches).
+
+    python tools/pmc_to_json.py FETCH_DIR WRITE_DIR FRAMES FS TAG
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_hash only; nothing touches the GPU)
+
+
+def is_usual_d4c(name):
+    """The usual instantiation of d4c_kernel (template argument RARE = false), demangled or mangled."""
+    return ("d4c_kernel<" in name and ", false>" in name) or ("d4c_kernelILi" in name and "ELb0E" in name)
+
+
+def total(dirname, counter):
+    kb, launches, name = 0.0, 0, None
+    for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") == counter and is_usual_d4c(row.get("Kernel_Name", "")):
+                    kb += float(row["Counter_Value"])
+                    launches += 1
+                    name = row["Kernel_Name"]
+    return kb, launches, name
+
+
+def main():
+    fdir, wdir, frames, fs, tag = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    fkb, fl, name = total(fdir, "FETCH_SIZE")
+    wkb, wl, _ = total(wdir, "WRITE_SIZE")
+    assert fl and fl == wl, (fl, wl)
+    rec = {"kernel": (name or "d4c_kernel").split("(")[0], "fs": fs, "frames": frames, "launches": fl,
+           "fetch_kb": fkb / fl, "write_kb": wkb / wl, "source_sha": bench.kernel_source_hash(), "tag": tag,
+           "files": "profiles/%s_pmc_fetch.csv, profiles/%s_pmc_write.csv" % (tag, tag),
+           "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); 8-byte-per-lane accesses, not the 16-byte streaming "
+                        "pattern the guide's x2 read correction was calibrated on"}
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    recs = []
+    if os.path.exists(path):
+        recs = [r for r in json.load(open(path)) if r.get("fs") != fs]
+    recs.append(rec)
+    json.dump(recs, open(path, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
