@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
 }
 
 template <int F>
-__global__ __launch_bounds__(64, 3) void cheaptrick_kernel(
+__global__ __launch_bounds__(64, F >= 4096 ? 1 : 3) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, double q1,
@@ -155,8 +155,10 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
   {
   TimedScope ts_(b.ctx, "cheaptrick_kernel");
   switch (F) {
+    WM_CT_CASE(512)       // fs <= 12.8 kHz (GetFFTSizeForCheapTrick, cheaptrick.cpp:191-194)
     WM_CT_CASE(1024)
     WM_CT_CASE(2048)
+    WM_CT_CASE(4096)      // fs > 51.2 kHz
     default:
       return WM_ERR_UNSUPPORTED_FFT;
   }

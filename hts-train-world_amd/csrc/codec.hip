@@ -299,7 +299,7 @@ int codec_num_aperiodicities(int fs) {                              // codec.cpp
 template <class OUT>
 static int code_sp(Batch& b, const double* d_in, int ndim, CodeOpts o, OUT* d_out, const char* name) {
   const int F = b.p.fft_size;
-  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
   if (ndim < 1 || ndim > F / 4 + 1) return WM_ERR_BAD_ARG;      // the reference reads spectrum[i], i <= fft_size/4
   int rc = codec_setup(b);
   if (rc) return rc;
@@ -315,8 +315,10 @@ static int code_sp(Batch& b, const double* d_in, int ndim, CodeOpts o, OUT* d_ou
                        d_in, T.d_code_k, T.d_code_s, T.d_code_w, ndim, o, tf, d_out);                        \
   } break;
   switch (F) {
+    WM_CODE_CASE(512)
     WM_CODE_CASE(1024)
     WM_CODE_CASE(2048)
+    WM_CODE_CASE(4096)
   }
 #undef WM_CODE_CASE
   return wm_check(hipGetLastError());
@@ -330,7 +332,7 @@ int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double
 template <class IN>
 static int decode_sp(Batch& b, const IN* d_coded, int ndim, DecodeOpts o, double* d_sp) {
   const int F = b.p.fft_size;
-  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
   if (ndim < 1 || ndim > F / 2) return WM_ERR_BAD_ARG;
   int rc = codec_setup(b);
   if (rc) return rc;
@@ -346,8 +348,10 @@ static int decode_sp(Batch& b, const IN* d_coded, int ndim, DecodeOpts o, double
                        d_coded, ndim, T.d_dec_k, T.d_dec_s, T.d_dec_w, o, tf, d_sp);                         \
   } break;
   switch (F) {
+    WM_DEC_CASE(512)
     WM_DEC_CASE(1024)
     WM_DEC_CASE(2048)
+    WM_DEC_CASE(4096)
   }
 #undef WM_DEC_CASE
   return wm_check(hipGetLastError());
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) void codec_f0_from_lf0_kernel(const float* __r
 int launch_recipe_decode(Batch& b, const float* d_lf0, const float* d_mgc, const float* d_bap, int spec_dim,
                          int ap_dim, double* d_f0, double* d_sp, double* d_ap) {
   const int F = b.p.fft_size;
-  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
   const int order = (ap_dim % 2 == 1) ? ap_dim - 1 : ap_dim;   // synth.cpp:233-235
   if (ap_dim < 1 || order < 1 || order > 63) return WM_ERR_BAD_ARG;
   int rc = decode_sp<float>(b, d_mgc, spec_dim, DecodeOpts{-12.0, 1e4}, d_sp);
@@ -530,9 +534,19 @@ int launch_recipe_decode(Batch& b, const float* d_lf0, const float* d_mgc, const
 #define WM_BAP_CASE(WW, FF)                                                                                   \
   hipLaunchKernelGGL((codec_bap_decode_kernel<WW, FF>), grid, dim3(64), 0, st, d_bap, ap_dim, order, 0.55, tf, d_ap)
     if (order < 32) {
-      if (F == 1024) WM_BAP_CASE(32, 1024); else WM_BAP_CASE(32, 2048);
+      switch (F) {
+        case 512: WM_BAP_CASE(32, 512); break;
+        case 1024: WM_BAP_CASE(32, 1024); break;
+        case 2048: WM_BAP_CASE(32, 2048); break;
+        default: WM_BAP_CASE(32, 4096); break;
+      }
     } else {
-      if (F == 1024) WM_BAP_CASE(64, 1024); else WM_BAP_CASE(64, 2048);
+      switch (F) {
+        case 512: WM_BAP_CASE(64, 512); break;
+        case 1024: WM_BAP_CASE(64, 1024); break;
+        case 2048: WM_BAP_CASE(64, 2048); break;
+        default: WM_BAP_CASE(64, 4096); break;
+      }
     }
 #undef WM_BAP_CASE
   }

@@ -553,7 +553,8 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   tab.window_length = wl;
   double lim = fs / 2.0 - kFreqInterval;
   tab.nap = (int)((kUpperLimit < lim ? kUpperLimit : lim) / kFreqInterval);
-  if (tab.nap < 1 || tab.nap > 6) return WM_ERR_UNSUPPORTED;
+  // no band at all below 12 kHz (fs / 2 - 3000 < 3000): the reference then interpolates between its two end knots only
+  if (tab.nap < 0 || tab.nap > 6) return WM_ERR_UNSUPPORTED;
 
   const int64_t tf = b.total_f;
   const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);

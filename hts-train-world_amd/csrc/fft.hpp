@@ -7,7 +7,8 @@
 // this file's own:
 //
 //   * one 64-lane wavefront owns one transform of N complex points
-//     (N = 256/512/1024/2048), lane l holding elements l + 64*m in registers;
+//     (N = 512/1024/2048; 256 rides on the 512-point plan, see the end of the file),
+//     lane l holding elements l + 64*m in registers;
 //   * three Stockham passes (radix 4/8/16) with exactly two LDS exchanges;
 //     pass-1 input and pass-3 output never touch LDS;
 //   * LDS image padded by one element per R1 so the stride-R1 stores of pass 1
@@ -138,7 +139,6 @@ template <int R> __device__ __forceinline__ void apply_twiddle_powers(cpx (&a)[R
 }
 
 template <int N> struct FftCfg;
-template <> struct FftCfg<256>  { static constexpr int R1 = 4,  R2 = 8,  R3 = 8; };
 template <> struct FftCfg<512>  { static constexpr int R1 = 8,  R2 = 8,  R3 = 8; };
 template <> struct FftCfg<1024> { static constexpr int R1 = 16, R2 = 8,  R3 = 8; };
 template <> struct FftCfg<2048> { static constexpr int R1 = 16, R2 = 16, R3 = 8; };
@@ -332,6 +332,45 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
     w = cmul(w, wst);
   }
   fft_backward<N>(v, lds, tw, lane);
+}
+
+// ---- N = 256 (fft_size 512: CheapTrick / Synthesis / codec at fs <= 12.8 kHz, cheaptrick.cpp:191-194) ----------
+// Four elements per lane leave no room for a three-pass radix plan, and the case is rare (8 kHz speech), so the
+// 256-point transform rides on the 512-point one: interleaving the input with zeros, z'[2 n] = z[n], z'[2 n + 1] = 0,
+// gives Z'[k] = Z[k mod 256].  Twice the arithmetic of a dedicated plan; same conventions, same call sites (the
+// real-transform wrappers above are generic in N once fft_forward<256> and FftTw<256> exist).
+template <> struct FftLds<256> { static constexpr int kElems = FftLds<512>::kElems; };
+
+template <> struct FftTw<256> {
+  FftTw<512> t;
+  cpx wsplit;        // W_512^lane
+  __device__ __forceinline__ void init(int lane) {
+    t.init(lane);
+    wsplit = cis_neg2pi((double)lane / 512.0);
+  }
+  __device__ __forceinline__ cpx wstep() const { return cis64(8); }      // W_512^64
+  __device__ __forceinline__ void fence() {
+    t.fence();
+    asm volatile("" : "+v"(wsplit.x), "+v"(wsplit.y));
+  }
+};
+
+template <>
+__device__ __forceinline__ void fft_forward<256>(cpx (&v)[4], cpx* lds, const FftTw<256>& tw, int lane) {
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < 4; ++m) lds[lane + 64 * m] = v[m];
+  wave_sync();
+  cpx c[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int i = lane + 64 * m;                       // element of the zero-interleaved sequence
+    const cpx a = lds[i >> 1];
+    c[m] = (i & 1) ? make_double2(0.0, 0.0) : a;
+  }
+  fft_forward<512>(c, lds, tw.t, lane);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) v[m] = c[m];             // Z'[k] = Z[k] for k < 256
 }
 
 }  // namespace wm

@@ -596,7 +596,7 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int F = b.p.fft_size, fs = b.p.fs;
-  if (F != 1024 && F != 2048) return WM_ERR_UNSUPPORTED_FFT;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
   int rc = c.ensure_rng(b.rng_bound_synthesis());
   if (rc) return rc;
   if (!b.d_pulse_idx) {
@@ -710,8 +710,10 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
       switch (F) {
+        WM_SY_CASE(512)
         WM_SY_CASE(1024)
         WM_SY_CASE(2048)
+        WM_SY_CASE(4096)
       }
     }
 #undef WM_SY_CASE

@@ -186,6 +186,70 @@ def test_other_sampling_rates(gpu, oracle, fs, fft):
     b.close()
 
 
+def test_fft_size_512_at_8khz(gpu, pkg, oracle):
+    """fs <= 12.8 kHz: GetFFTSizeForCheapTrick gives 512 (cheaptrick.cpp:191-194), D4C has no band at all
+    (fs / 2 - 3000 < 3000, d4c.cpp:351-353).  Whole chain, codec and the drop-in entry points."""
+    torch, W, ctx = gpu
+    fs = 8000
+    xs = [sd.make_utterance(110, fs, duration=0.8), sd.make_utterance(111, fs, duration=1.3)]
+    rs = [oracle_chain(oracle, x, fs) for x in xs]
+    assert rs[0]["F"] == 512
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    assert b.fft_size == 512
+    t, f0, sp, ap, y = b.analyze_synthesize(torch.from_numpy(np.concatenate(xs)).cuda())
+    assert ((f0.cpu().numpy() > 0) == (cat(rs, "f0") > 0)).all() and (cat(rs, "f0") > 0).sum() > 50
+    np.testing.assert_allclose(f0.cpu().numpy(), cat(rs, "f0"), atol=F0_TOL, rtol=0)
+    sp_close(sp.cpu().numpy(), cat(rs, "sp"))
+    np.testing.assert_allclose(ap.cpu().numpy(), cat(rs, "ap"), atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y.cpu().numpy(), cat(rs, "y"), atol=Y_TOL, rtol=0)
+    # codec at 512: 20 coefficients (the reference reads spectrum[i] for i <= fft_size / 4)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    csp = b.code_spectral_envelope(dev(cat(rs, "sp")), 20).cpu().numpy()
+    ref = oracle.code_spectral_envelope(cat(rs, "sp"), fs, 512, 20)
+    np.testing.assert_allclose(csp, ref, atol=1e-11, rtol=0)
+    np.testing.assert_allclose(b.decode_spectral_envelope(dev(ref)).cpu().numpy(),
+                               oracle.decode_spectral_envelope(ref, fs, 512), rtol=1e-10)
+    b.close()
+    # drop-in entry points, one utterance
+    C = pkg.capi
+    r, x = rs[0], xs[0]
+    sp1 = C.cheaptrick(x, fs, r["t"], r["f0"])
+    sp_close(sp1, r["sp"])
+    np.testing.assert_allclose(C.d4c(x, fs, r["t"], r["f0"], 512, threshold=0.0), r["ap"], atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(C.synthesis(r["f0"], r["sp"], r["ap"], 512, 5.0, fs), r["y"], atol=Y_TOL, rtol=0)
+
+
+def test_fft_size_4096_at_96khz(gpu, oracle):
+    """fs > 51.2 kHz: CheapTrick / Synthesis / codec at fft_size 4096 (configure.ac:540-549 lists it).  D4C's own
+    transform would be 8192 points there, beyond the one-wavefront engine: that call is refused, not answered wrongly."""
+    torch, W, ctx = gpu
+    fs = 96000
+    x = sd.make_utterance(112, fs, duration=0.5)
+    t, f0d = oracle.dio(x, fs)
+    f0 = oracle.stonemask(x, fs, t, f0d)
+    F = oracle.cheaptrick_fft_size(fs)
+    assert F == 4096
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    assert b.fft_size == 4096
+    sp = b.cheaptrick(dev(x), dev(t), dev(f0))
+    spo = oracle.cheaptrick(x, fs, t, f0, -0.15, F)
+    sp_close(sp.cpu().numpy(), spo)
+    with pytest.raises(RuntimeError):
+        b.d4c(dev(x), dev(t), dev(f0))
+    # Synthesis from a plausible aperiodicity (a smooth ramp; D4C is not available at this rate)
+    ap = np.tile(np.linspace(0.02, 0.9, F // 2 + 1), (len(f0), 1))
+    y = b.synthesize(dev(f0), sp, dev(ap))
+    yo = oracle.synthesis(f0, sp.cpu().numpy(), ap, F, 5.0, fs)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, atol=Y_TOL, rtol=0)
+    csp = b.code_spectral_envelope(sp, 60).cpu().numpy()
+    ref = oracle.code_spectral_envelope(sp.cpu().numpy(), fs, F, 60)
+    np.testing.assert_allclose(csp, ref, atol=1e-11, rtol=0)
+    np.testing.assert_allclose(b.decode_spectral_envelope(dev(ref)).cpu().numpy(),
+                               oracle.decode_spectral_envelope(ref, fs, F), rtol=1e-10)
+    b.close()
+
+
 @pytest.mark.parametrize("fs,fp", [(16000, 1.0), (16000, 10.0), (16000, 2.5), (22050, 3.0), (48000, 4.0)])
 def test_other_frame_periods(gpu, oracle, fs, fp):
     """Frame periods other than 5 ms, including ones that are not a whole number of samples (rounding ties)."""
@@ -650,8 +714,8 @@ def test_errors_are_reported_not_swallowed(gpu):
     fs = 16000
     n = 8000
     x = torch.zeros(n, dtype=torch.float64, device="cuda")
-    # CheapTrick / Synthesis sizes outside {1024, 2048}
-    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, fft_size=512), x_lengths=[n])
+    # CheapTrick / Synthesis sizes outside {512, 1024, 2048, 4096}
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, fft_size=256), x_lengths=[n])
     t, f0 = b.dio(x)
     with pytest.raises(RuntimeError):
         b.cheaptrick(x, t, f0)
