@@ -264,6 +264,7 @@ def main():
     kernel_ms = {k: ctx.timing_query(k) for k in ANALYSIS_KERNELS + SYNTHESIS_KERNELS}
     ctx.timing_enable(False)
     elapsed_max, total_frames = reduce_over_ranks(torch, dist, world, args.backend, elapsed, frames)
+    hi = host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world)
 
     if rank == 0:
         value = total_frames * args.steps / elapsed_max
@@ -295,6 +296,7 @@ def main():
         }
         if shared_gpu or (world > 1 and args.backend == "gloo"):
             line["config"]["note"] = "rehearsal: %d ranks over gloo on %d GPU(s)" % (world, torch.cuda.device_count())
+        line["host_inclusive"] = hi
         if cpu_all:
             line["cpu_baseline_all_cores"] = cpu_all
         if parity:
@@ -303,6 +305,46 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world):
+    """The same step fed from and drained to pinned HOST memory in the on-disk types (int16 samples up; float32
+    f0 / sp / ap and int16 resynthesised samples down), double-buffered on copy streams beside the kernels
+    (hts-train-world_amd/pipeline.py).  Reported beside `value`, never as it (the metric
+    "including H2D of waveforms and D2H of features")."""
+    pl = pkg.pipeline
+    pipe = pl.HostPipeline(ctx, pkg.world.default_params(fs, fp), [len(x) for x in xs], synthesis=True)
+    x16 = pl.to_int16(np.concatenate(xs))
+    for xb in pipe.x_pinned:                        # the waveforms wait in pinned memory, as decoded wav payloads would
+        xb.numpy()[:] = x16
+    steps = max(2, args.steps)
+    for _ in range(2):
+        pipe.result(pipe.submit())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prev = None
+    pipe.feed()
+    for k in range(steps):
+        if k + 1 < steps:
+            pipe.feed()                             # the next step's upload goes ahead of this step's download
+        slot = pipe.submit()
+        if prev is not None:
+            pipe.result(prev)
+        prev = slot
+    pipe.result(prev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = int(pipe.batch.total_frames)
+    up, down = pipe.bytes_per_step()
+    pipe.close()
+    dt_max, total = reduce_over_ranks(torch, dist, world, args.backend, dt, frames)
+    return {"value": round(total * steps / dt_max, 1), "unit": "frames/s", "ms_per_step": round(dt_max / steps * 1e3, 3),
+            "overlapped": True, "steps": steps,
+            "layout": "pinned host int16 waveforms up (%d B/frame), float32 f0/sp/ap + int16 resynthesis down (%d B/frame); "
+                      "two slots, uploads / kernels / downloads on three streams" % (up // max(1, frames), down // max(1, frames)),
+            "pcie_gbs": round((up + down) * steps / dt / 1e9, 2)}
 
 
 ANALYSIS_KERNELS = ("dio_lowcut_kernel", "dio_band_kernel", "dio_candidate_kernel", "dio_fix_kernel", "stonemask_kernel",

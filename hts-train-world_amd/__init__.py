@@ -14,7 +14,7 @@ from .world import WorldBatch, WorldParams, load_library  # noqa: F401
 
 def __getattr__(name):
     # `recipe` is also a command (python -m hts-train-world_amd.recipe): imported on first use, not with the package
-    if name in ("recipe", "sweep"):
+    if name in ("recipe", "sweep", "pipeline"):
         import importlib
         return importlib.import_module(__name__ + "." + name)
     raise AttributeError(name)

@@ -33,6 +33,8 @@ struct Context {
   int64_t scratch_cap = 0;           // in doubles
   int ensure_rng(int64_t count);     // grow + (re)generate, returns error code
   int ensure_scratch(int64_t doubles);
+  int64_t* h_pulse_info = nullptr;   // pinned, mapped: {total pulses, largest per-utterance count} of the last Synthesis
+  int64_t* d_pulse_info = nullptr;   // the same memory as the device sees it
   // second stream + events of launch_analyze_synthesize (created on first use)
   hipStream_t side = nullptr;
   hipEvent_t ev_f0 = nullptr, ev_prep = nullptr;
@@ -75,7 +77,8 @@ struct Batch {
   std::vector<int64_t> x_off, f_off, y_off;
   int64_t total_x = 0, total_f = 0, total_y = 0;
   int max_x_len = 0, max_f0_len = 0, max_y_len = 0;
-  // device descriptors
+  // device descriptors: sections of one allocation (d_arena), laid out by WorldMi355CreateBatch
+  void* d_arena = nullptr;
   int64_t *d_x_off = nullptr, *d_f_off = nullptr, *d_y_off = nullptr;
   int *d_x_len = nullptr, *d_f0_len = nullptr, *d_y_len = nullptr;
   int* d_frame_utt = nullptr;        // [total_f]
@@ -123,7 +126,8 @@ struct Batch {
   double* d_dio_score = nullptr;     // [band][total_f]
   void* harvest_ws = nullptr;        // HarvestWs (harvest.hip)
   void* codec_tables = nullptr;      // CodecTables (codec.hip)
-  // Synthesis workspace
+  // Synthesis workspace: sections of one allocation (d_syn_arena), laid out by synthesis_prepare
+  void* d_syn_arena = nullptr;
   int* d_pulse_idx = nullptr;        // [total_y]
   double* d_pulse_shift = nullptr;   // [total_y]
   double* d_vuv = nullptr;           // [total_y] interpolated vuv
@@ -131,7 +135,6 @@ struct Batch {
   int* d_pulse_cnt = nullptr;        // [n_utt]
   int* d_pulse_tile_cnt = nullptr;   // [n_utt][tiles] pulses per search tile
   int64_t* d_pulse_off = nullptr;    // [n_utt+1]
-  int* h_pulse_cnt = nullptr;        // pinned
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts

@@ -98,6 +98,7 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   c.timing_clear();
   if (c.d_rng) hipFree(c.d_rng);
   if (c.d_scratch) hipFree(c.d_scratch);
+  if (c.h_pulse_info) hipHostFree(c.h_pulse_info);
   if (c.own_stream) hipStreamDestroy(c.stream);
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
   if (c.ev_f0) hipEventDestroy(c.ev_f0);
@@ -153,25 +154,46 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
     b.max_y_len = imax(b.max_y_len, b.y_len[u]);
   }
   b.total_x = b.x_off[n_utt]; b.total_f = b.f_off[n_utt]; b.total_y = b.y_off[n_utt];
-  int rc = WM_OK;
-  rc = rc ? rc : upload(&b.d_x_off, b.x_off);
-  rc = rc ? rc : upload(&b.d_f_off, b.f_off);
-  rc = rc ? rc : upload(&b.d_y_off, b.y_off);
-  rc = rc ? rc : upload(&b.d_x_len, b.x_len);
-  rc = rc ? rc : upload(&b.d_f0_len, b.f0_len);
-  rc = rc ? rc : upload(&b.d_y_len, b.y_len);
-  std::vector<int> fu((size_t)b.total_f);
-  for (int u = 0; u < n_utt; ++u)
-    for (int64_t i = b.f_off[u]; i < b.f_off[u + 1]; ++i) fu[(size_t)i] = u;
-  rc = rc ? rc : upload(&b.d_frame_utt, fu);
-  rc = rc ? rc : dev_alloc(&b.d_rng_off, (size_t)b.total_f);
-  rc = rc ? rc : dev_alloc(&b.d_rng_off2, (size_t)b.total_f);
-  rc = rc ? rc : dev_alloc(&b.d_ap0, (size_t)b.total_f);
-  rc = rc ? rc : dev_alloc(&b.d_f0_tmp, (size_t)b.total_f);
-  rc = rc ? rc : dev_alloc(&b.d_perm, (size_t)b.total_f);
-  rc = rc ? rc : dev_alloc(&b.d_part_cnt, (size_t)b.total_f / 1024 + 2);
-  rc = rc ? rc : dev_alloc(&b.d_part_n, 4);
-  if (rc) { WorldMi355DestroyBatch(hb); return rc; }
+  // One device allocation and one upload for every descriptor and per-frame work array of the batch (a batch of
+  // one utterance is created per call by the per-utterance entry points: fourteen hipMallocs and seven blocking
+  // copies were most of its cost).  Layout: 256-byte aligned sections; the first `init_bytes` are initialised
+  // from a host image, the rest is scratch.
+  const size_t n1 = (size_t)n_utt + 1, nf = (size_t)b.total_f;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
+  const size_t o_xoff = take(8 * n1), o_foff = take(8 * n1), o_yoff = take(8 * n1);
+  const size_t o_xlen = take(4 * (size_t)n_utt), o_flen = take(4 * (size_t)n_utt), o_ylen = take(4 * (size_t)n_utt);
+  const size_t o_futt = take(4 * nf);
+  const size_t init_bytes = at;
+  const size_t o_rng = take(4 * nf), o_rng2 = take(4 * nf), o_ap0 = take(8 * nf), o_f0t = take(8 * nf);
+  const size_t o_perm = take(4 * nf), o_pcnt = take(4 * (nf / 1024 + 2)), o_pn = take(4 * 4);
+  std::vector<unsigned char> img(init_bytes, 0);
+  memcpy(&img[o_xoff], b.x_off.data(), 8 * n1);
+  memcpy(&img[o_foff], b.f_off.data(), 8 * n1);
+  memcpy(&img[o_yoff], b.y_off.data(), 8 * n1);
+  memcpy(&img[o_xlen], b.x_len.data(), 4 * (size_t)n_utt);
+  memcpy(&img[o_flen], b.f0_len.data(), 4 * (size_t)n_utt);
+  memcpy(&img[o_ylen], b.y_len.data(), 4 * (size_t)n_utt);
+  {
+    int* fu = reinterpret_cast<int*>(&img[o_futt]);
+    for (int u = 0; u < n_utt; ++u)
+      for (int64_t i = b.f_off[u]; i < b.f_off[u + 1]; ++i) fu[i] = u;
+  }
+  unsigned char* base = nullptr;
+  int rc = wm_check(hipMalloc((void**)&base, at));
+  if (!rc) rc = wm_check(hipMemcpy(base, img.data(), init_bytes, hipMemcpyHostToDevice));
+  if (rc) {
+    if (base) (void)hipFree(base);
+    delete hb;
+    return rc;
+  }
+  b.d_arena = base;
+  b.d_x_off = (int64_t*)(base + o_xoff); b.d_f_off = (int64_t*)(base + o_foff); b.d_y_off = (int64_t*)(base + o_yoff);
+  b.d_x_len = (int*)(base + o_xlen); b.d_f0_len = (int*)(base + o_flen); b.d_y_len = (int*)(base + o_ylen);
+  b.d_frame_utt = (int*)(base + o_futt);
+  b.d_rng_off = (int*)(base + o_rng); b.d_rng_off2 = (int*)(base + o_rng2);
+  b.d_ap0 = (double*)(base + o_ap0); b.d_f0_tmp = (double*)(base + o_f0t);
+  b.d_perm = (int*)(base + o_perm); b.d_part_cnt = (int*)(base + o_pcnt); b.d_part_n = (int*)(base + o_pn);
   *out = hb;
   return WM_OK;
 }
@@ -311,44 +333,132 @@ WorldMi355Context* default_context() {
   return g_ctx;
 }
 
-struct DevBuf {
-  double* p = nullptr;
-  explicit DevBuf(size_t n) {
-    if (hipMalloc((void**)&p, sizeof(double) * (n ? n : 1)) != hipSuccess) die("hipMalloc", WM_ERR_HIP);
-  }
-  ~DevBuf() { if (p) hipFree(p); }
-  void put(const double* h, size_t n) {
-    if (n && hipMemcpy(p, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) die("H2D", WM_ERR_HIP);
-  }
-  void get(double* h, size_t n) {
-    if (n && hipMemcpy(h, p, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) die("D2H", WM_ERR_HIP);
-  }
-};
+// ---- persistent workspace of the per-utterance entry points ------------------------------------------------
+// The reference's API is stateless: every call brings host pointers and takes its results home.  Doing that
+// literally -- a fresh batch, fresh device buffers and pageable copies per call -- cost 8 ms per utterance of 5 s,
+// most of it allocation and staging rather than kernels.  What persists here between calls (per process, under the
+// same mutex as the calls; nothing of it is visible to the caller):
+//   * device buffers by role (x, t, f0, f0 out, sp, ap, coded, y), grow-only;
+//   * one pinned staging buffer, grow-only: `double**` rows are gathered into / scattered from it, so the DMA
+//     engine always sees pinned contiguous memory;
+//   * the last few batches by (parameters, lengths): Dio, StoneMask, CheapTrick and D4C of one utterance, or the
+//     same call on the next utterance of equal length, reuse descriptors and stage workspaces;
+//   * a host copy of the last uploaded waveform: the four analysis calls of one utterance pass the same x, which
+//     is then uploaded once (a memcmp of the samples decides, not the pointer).
+enum Slot { kX, kT, kF0, kOut, kSp, kAp, kCoded, kY, kSlots };
 
-struct OneBatch {
-  WorldMi355Batch* b = nullptr;
-  OneBatch(const WorldMi355Params& p, const int* xl, const int* fl, const int* yl) {
-    int rc = WorldMi355CreateBatch(default_context(), &p, 1, xl, fl, yl, &b);
+struct Workspace {
+  void* dev[kSlots] = {};
+  size_t dev_cap[kSlots] = {};
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  std::vector<double> x_copy;           // what dev[kX] holds
+  bool x_valid = false;
+  struct Entry { WorldMi355Params p; int xl, fl, yl; WorldMi355Batch* b; unsigned long stamp; };
+  std::vector<Entry> cache;
+  unsigned long clock = 0;
+
+  double* device(Slot s, size_t n) {
+    const size_t bytes = sizeof(double) * (n ? n : 1);
+    if (bytes > dev_cap[s]) {
+      if (s == kX) x_valid = false;
+      if (dev[s]) (void)hipFree(dev[s]);
+      dev[s] = nullptr;
+      const size_t cap = bytes + bytes / 4;
+      if (hipMalloc(&dev[s], cap) != hipSuccess) die("hipMalloc", WM_ERR_HIP);
+      dev_cap[s] = cap;
+    }
+    return (double*)dev[s];
+  }
+  double* stage(size_t n) {
+    const size_t bytes = sizeof(double) * (n ? n : 1);
+    if (bytes > pinned_cap) {
+      if (pinned) (void)hipHostFree(pinned);
+      pinned = nullptr;
+      const size_t cap = bytes + bytes / 4;
+      if (hipHostMalloc(&pinned, cap, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc", WM_ERR_HIP);
+      pinned_cap = cap;
+    }
+    return (double*)pinned;
+  }
+  WorldMi355Batch* batch(const WorldMi355Params& p, int xl, int fl, int yl) {
+    ++clock;
+    for (Entry& e : cache)
+      if (e.xl == xl && e.fl == fl && e.yl == yl && memcmp(&e.p, &p, sizeof(p)) == 0) {
+        e.stamp = clock;
+        return e.b;
+      }
+    if (cache.size() >= 8) {                  // drop the least recently used
+      size_t lru = 0;
+      for (size_t i = 1; i < cache.size(); ++i)
+        if (cache[i].stamp < cache[lru].stamp) lru = i;
+      WorldMi355DestroyBatch(cache[lru].b);
+      cache.erase(cache.begin() + (long)lru);
+    }
+    WorldMi355Batch* b = nullptr;
+    int rc = WorldMi355CreateBatch(default_context(), &p, 1, xl >= 0 ? &xl : nullptr, fl >= 0 ? &fl : nullptr,
+                                   yl >= 0 ? &yl : nullptr, &b);
     if (rc) die("CreateBatch", rc);
+    Entry e;
+    e.p = p; e.xl = xl; e.fl = fl; e.yl = yl; e.b = b; e.stamp = clock;
+    cache.push_back(e);
+    return b;
   }
-  ~OneBatch() { WorldMi355DestroyBatch(b); }
 };
+Workspace g_ws;
 
-void sync_or_die(const char* where, int rc) {
-  if (rc) die(where, rc);
-  rc = WorldMi355Synchronize(default_context());
-  if (rc) die(where, rc);
-}
+hipStream_t ws_stream() { return default_context()->c.stream; }
 
-void put_rows(DevBuf& d, const double* const* rows, int n_rows, int width) {
-  std::vector<double> h((size_t)n_rows * width);
-  for (int i = 0; i < n_rows; ++i) memcpy(&h[(size_t)i * width], rows[i], sizeof(double) * width);
-  d.put(h.data(), h.size());
+void h2d(double* dst, const double* staged, size_t n) {
+  if (n && hipMemcpyAsync(dst, staged, sizeof(double) * n, hipMemcpyHostToDevice, ws_stream()) != hipSuccess)
+    die("H2D", WM_ERR_HIP);
 }
-void get_rows(DevBuf& d, double** rows, int n_rows, int width) {
-  std::vector<double> h((size_t)n_rows * width);
-  d.get(h.data(), h.size());
-  for (int i = 0; i < n_rows; ++i) memcpy(rows[i], &h[(size_t)i * width], sizeof(double) * width);
+// contiguous host array -> device slot (through the pinned staging buffer; waits for the copy: the staging buffer
+// is reused by the next argument)
+double* put(Slot s, const double* h, size_t n) {
+  double* d = g_ws.device(s, n);
+  double* st = g_ws.stage(n);
+  if (n) memcpy(st, h, sizeof(double) * n);
+  h2d(d, st, n);
+  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("H2D", WM_ERR_HIP);
+  return d;
+}
+double* put_x(const double* x, size_t n) {
+  if (g_ws.x_valid && g_ws.x_copy.size() == n && (n == 0 || memcmp(g_ws.x_copy.data(), x, sizeof(double) * n) == 0))
+    return (double*)g_ws.dev[kX];
+  g_ws.x_valid = false;
+  double* d = put(kX, x, n);
+  g_ws.x_copy.assign(x, x + n);
+  g_ws.x_valid = true;
+  return d;
+}
+double* put_rows(Slot s, const double* const* rows, int n_rows, int width) {
+  const size_t n = (size_t)n_rows * width;
+  double* d = g_ws.device(s, n);
+  double* st = g_ws.stage(n);
+  for (int i = 0; i < n_rows; ++i) memcpy(st + (size_t)i * width, rows[i], sizeof(double) * width);
+  h2d(d, st, n);
+  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("H2D", WM_ERR_HIP);
+  return d;
+}
+// device -> pinned staging (after the kernels on the stream); returns the staged data
+const double* fetch(const double* d, size_t n) {
+  double* st = g_ws.stage(n);
+  if (n && hipMemcpyAsync(st, d, sizeof(double) * n, hipMemcpyDeviceToHost, ws_stream()) != hipSuccess)
+    die("D2H", WM_ERR_HIP);
+  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("D2H", WM_ERR_HIP);
+  return st;
+}
+void get(const double* d, double* h, size_t n) {
+  const double* st = fetch(d, n);
+  if (n) memcpy(h, st, sizeof(double) * n);
+}
+void get_rows(const double* d, double** rows, int n_rows, int width) {
+  const double* st = fetch(d, (size_t)n_rows * width);
+  for (int i = 0; i < n_rows; ++i) memcpy(rows[i], st + (size_t)i * width, sizeof(double) * width);
+}
+void run_or_die(const char* where, int rc) {
+  if (rc) die(where, rc);
 }
 
 }  // namespace
@@ -375,13 +485,14 @@ void Dio(const double* x, int x_length, int fs, const DioOption* option, double*
   p.channels_in_octave = option->channels_in_octave; p.speed = option->speed;
   p.allowed_range = option->allowed_range;
   p.fft_size = 1024;   // unused by DIO
-  OneBatch ob(p, &x_length, nullptr, nullptr);
-  const int nf = (int)WorldMi355BatchTotalFrames(ob.b);
-  DevBuf dx((size_t)x_length), dt((size_t)nf), df((size_t)nf);
-  dx.put(x, (size_t)x_length);
-  sync_or_die("Dio", WorldMi355Dio(ob.b, dx.p, dt.p, df.p));
-  dt.get(temporal_positions, (size_t)nf);
-  df.get(f0, (size_t)nf);
+  WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
+  const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
+  double* dx = put_x(x, (size_t)x_length);
+  double* dt = g_ws.device(kT, nf);
+  double* df = g_ws.device(kF0, nf);
+  run_or_die("Dio", WorldMi355Dio(b, dx, dt, df));
+  get(dt, temporal_positions, nf);
+  get(df, f0, nf);
 }
 
 int GetSamplesForHarvest(int fs, int x_length, double frame_period) {  // harvest.cpp:1219-1221
@@ -399,13 +510,14 @@ void Harvest(const double* x, int x_length, int fs, const HarvestOption* option,
   WorldMi355DefaultParams(fs, option->frame_period, &p);
   p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
   p.fft_size = 1024;   // unused by Harvest
-  OneBatch ob(p, &x_length, nullptr, nullptr);
-  const int nf = (int)WorldMi355BatchTotalFrames(ob.b);
-  DevBuf dx((size_t)x_length), dt((size_t)nf), df((size_t)nf);
-  dx.put(x, (size_t)x_length);
-  sync_or_die("Harvest", WorldMi355Harvest(ob.b, dx.p, dt.p, df.p));
-  dt.get(temporal_positions, (size_t)nf);
-  df.get(f0, (size_t)nf);
+  WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
+  const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
+  double* dx = put_x(x, (size_t)x_length);
+  double* dt = g_ws.device(kT, nf);
+  double* df = g_ws.device(kF0, nf);
+  run_or_die("Harvest", WorldMi355Harvest(b, dx, dt, df));
+  get(dt, temporal_positions, nf);
+  get(df, f0, nf);
 }
 
 void StoneMask(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
@@ -414,13 +526,13 @@ void StoneMask(const double* x, int x_length, int fs, const double* temporal_pos
   WorldMi355Params p;
   WorldMi355DefaultParams(fs, 5.0, &p);
   p.fft_size = 1024;   // unused by StoneMask
-  OneBatch ob(p, &x_length, &f0_length, nullptr);
-  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), dr((size_t)f0_length);
-  dx.put(x, (size_t)x_length);
-  dt.put(temporal_positions, (size_t)f0_length);
-  df.put(f0, (size_t)f0_length);
-  sync_or_die("StoneMask", WorldMi355StoneMask(ob.b, dx.p, dt.p, df.p, dr.p));
-  dr.get(refined_f0, (size_t)f0_length);
+  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+  double* dx = put_x(x, (size_t)x_length);
+  double* dt = put(kT, temporal_positions, (size_t)f0_length);
+  double* df = put(kF0, f0, (size_t)f0_length);
+  double* dr = g_ws.device(kOut, (size_t)f0_length);
+  run_or_die("StoneMask", WorldMi355StoneMask(b, dx, dt, df, dr));
+  get(dr, refined_f0, (size_t)f0_length);
 }
 
 int GetFFTSizeForCheapTrick(int fs, const CheapTrickOption* option) {   // cheaptrick.cpp:191-194
@@ -442,12 +554,12 @@ void CheapTrick(const double* x, int x_length, int fs, const double* temporal_po
   p.q1 = option->q1;
   p.fft_size = option->fft_size;
   const int w = option->fft_size / 2 + 1;
-  OneBatch ob(p, &x_length, &f0_length, nullptr);
-  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), ds((size_t)f0_length * w);
-  dx.put(x, (size_t)x_length);
-  dt.put(temporal_positions, (size_t)f0_length);
-  df.put(f0, (size_t)f0_length);
-  sync_or_die("CheapTrick", WorldMi355CheapTrick(ob.b, dx.p, dt.p, df.p, ds.p));
+  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+  double* dx = put_x(x, (size_t)x_length);
+  double* dt = put(kT, temporal_positions, (size_t)f0_length);
+  double* df = put(kF0, f0, (size_t)f0_length);
+  double* ds = g_ws.device(kSp, (size_t)f0_length * w);
+  run_or_die("CheapTrick", WorldMi355CheapTrick(b, dx, dt, df, ds));
   get_rows(ds, spectrogram, f0_length, w);
 }
 
@@ -460,12 +572,12 @@ void D4C(const double* x, int x_length, int fs, const double* temporal_positions
   p.fft_size = fft_size;
   p.d4c_threshold = option->threshold;
   const int w = fft_size / 2 + 1;
-  OneBatch ob(p, &x_length, &f0_length, nullptr);
-  DevBuf dx((size_t)x_length), dt((size_t)f0_length), df((size_t)f0_length), da((size_t)f0_length * w);
-  dx.put(x, (size_t)x_length);
-  dt.put(temporal_positions, (size_t)f0_length);
-  df.put(f0, (size_t)f0_length);
-  sync_or_die("D4C", WorldMi355D4C(ob.b, dx.p, dt.p, df.p, da.p));
+  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+  double* dx = put_x(x, (size_t)x_length);
+  double* dt = put(kT, temporal_positions, (size_t)f0_length);
+  double* df = put(kF0, f0, (size_t)f0_length);
+  double* da = g_ws.device(kAp, (size_t)f0_length * w);
+  run_or_die("D4C", WorldMi355D4C(b, dx, dt, df, da));
   get_rows(da, aperiodicity, f0_length, w);
 }
 
@@ -474,26 +586,22 @@ int GetNumberOfAperiodicities(int fs) { return codec_num_aperiodicities(fs); }  
 
 namespace {
 // a frames-only batch: the codec needs fs, fft_size and the frame count
-struct CodecBatch {
+WorldMi355Batch* codec_batch(int fs, int fft_size, int f0_length) {
   WorldMi355Params p;
-  OneBatch* ob = nullptr;
-  CodecBatch(int fs, int fft_size, int f0_length) {
-    WorldMi355DefaultParams(fs, 5.0, &p);
-    p.fft_size = fft_size;
-    ob = new OneBatch(p, nullptr, &f0_length, nullptr);
-  }
-  ~CodecBatch() { delete ob; }
-};
+  WorldMi355DefaultParams(fs, 5.0, &p);
+  p.fft_size = fft_size;
+  return g_ws.batch(p, -1, f0_length, -1);
+}
 }  // namespace
 
 void CodeSpectralEnvelope(const double* const* spectrogram, int f0_length, int fs, int fft_size,
                           int number_of_dimensions, double** coded_spectral_envelope) {
   std::lock_guard<std::mutex> lock(g_mu);
   const int w = fft_size / 2 + 1;
-  CodecBatch cb(fs, fft_size, f0_length);
-  DevBuf ds((size_t)f0_length * w), dc((size_t)f0_length * number_of_dimensions);
-  put_rows(ds, spectrogram, f0_length, w);
-  sync_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(cb.ob->b, ds.p, number_of_dimensions, dc.p));
+  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+  double* ds = put_rows(kSp, spectrogram, f0_length, w);
+  double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_dimensions);
+  run_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(b, ds, number_of_dimensions, dc));
   get_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
 }
 
@@ -501,11 +609,10 @@ void DecodeSpectralEnvelope(const double* const* coded_spectral_envelope, int f0
                             int number_of_dimensions, double** spectrogram) {
   std::lock_guard<std::mutex> lock(g_mu);
   const int w = fft_size / 2 + 1;
-  CodecBatch cb(fs, fft_size, f0_length);
-  DevBuf dc((size_t)f0_length * number_of_dimensions), ds((size_t)f0_length * w);
-  put_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
-  sync_or_die("DecodeSpectralEnvelope",
-              WorldMi355DecodeSpectralEnvelope(cb.ob->b, dc.p, number_of_dimensions, ds.p));
+  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+  double* dc = put_rows(kCoded, coded_spectral_envelope, f0_length, number_of_dimensions);
+  double* ds = g_ws.device(kSp, (size_t)f0_length * w);
+  run_or_die("DecodeSpectralEnvelope", WorldMi355DecodeSpectralEnvelope(b, dc, number_of_dimensions, ds));
   get_rows(ds, spectrogram, f0_length, w);
 }
 
@@ -515,10 +622,10 @@ void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, 
   if (number_of_aperiodicities != codec_num_aperiodicities(fs))
     die("CodeAperiodicity: number_of_aperiodicities must be GetNumberOfAperiodicities(fs)", WM_ERR_BAD_ARG);
   const int w = fft_size / 2 + 1;
-  CodecBatch cb(fs, fft_size, f0_length);
-  DevBuf da((size_t)f0_length * w), dc((size_t)f0_length * number_of_aperiodicities);
-  put_rows(da, aperiodicity, f0_length, w);
-  sync_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(cb.ob->b, da.p, dc.p));
+  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+  double* da = put_rows(kAp, aperiodicity, f0_length, w);
+  double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_aperiodicities);
+  run_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(b, da, dc));
   get_rows(dc, coded_aperiodicity, f0_length, number_of_aperiodicities);
 }
 
@@ -531,10 +638,10 @@ void DecodeAperiodicity(const double* const* coded_aperiodicity, int f0_length, 
   if (nap != codec_num_aperiodicities(fs))
     die("DecodeAperiodicity: 4th argument must be GetNumberOfAperiodicities(fs) (codec.cpp:237-238)", WM_ERR_BAD_ARG);
   const int w = fft_size / 2 + 1;
-  CodecBatch cb(fs, fft_size, f0_length);
-  DevBuf dc((size_t)f0_length * nap), da((size_t)f0_length * w);
-  put_rows(dc, coded_aperiodicity, f0_length, nap);
-  sync_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(cb.ob->b, dc.p, da.p));
+  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+  double* dc = put_rows(kCoded, coded_aperiodicity, f0_length, nap);
+  double* da = g_ws.device(kAp, (size_t)f0_length * w);
+  run_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(b, dc, da));
   get_rows(da, aperiodicity, f0_length, w);
 }
 
@@ -546,13 +653,13 @@ void Synthesis(const double* f0, int f0_length, const double* const* spectrogram
   WorldMi355DefaultParams(fs, frame_period, &p);
   p.fft_size = fft_size;
   const int w = fft_size / 2 + 1;
-  OneBatch ob(p, nullptr, &f0_length, &y_length);
-  DevBuf df((size_t)f0_length), ds((size_t)f0_length * w), da((size_t)f0_length * w), dy((size_t)y_length);
-  df.put(f0, (size_t)f0_length);
-  put_rows(ds, spectrogram, f0_length, w);
-  put_rows(da, aperiodicity, f0_length, w);
-  sync_or_die("Synthesis", WorldMi355Synthesis(ob.b, df.p, ds.p, da.p, dy.p));
-  dy.get(y, (size_t)y_length);
+  WorldMi355Batch* b = g_ws.batch(p, -1, f0_length, y_length);
+  double* df = put(kF0, f0, (size_t)f0_length);
+  double* ds = put_rows(kSp, spectrogram, f0_length, w);
+  double* da = put_rows(kAp, aperiodicity, f0_length, w);
+  double* dy = g_ws.device(kY, (size_t)y_length);
+  run_or_die("Synthesis", WorldMi355Synthesis(b, df, ds, da, dy));
+  get(dy, y, (size_t)y_length);
 }
 
 }  // extern "C"

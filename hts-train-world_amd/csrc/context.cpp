@@ -156,16 +156,13 @@ void harvest_free(void* p);
 void codec_free(void* p);
 
 void free_batch_buffers(Batch& b) {
-  void* ptrs[] = {b.d_x_off, b.d_f_off, b.d_y_off, b.d_x_len, b.d_f0_len, b.d_y_len, b.d_frame_utt,
-                  b.d_rng_off, b.d_rng_off2, b.d_ap0, b.d_f0_tmp, b.d_perm, b.d_perm2, b.d_part_cnt, b.d_part_n, b.d_sm_twid, b.d_d4c_window, b.d_utt_total,
+  void* ptrs[] = {b.d_arena, b.d_perm2, b.d_sm_twid, b.d_d4c_window, b.d_utt_total,
                   b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_edges, b.d_dio_ylen, b.d_dio_y, b.d_dio_tmp,
                   b.d_dio_yoff, b.d_dio_toff, b.d_dio_mean, b.d_dio_mean_part, b.d_dio_z,
                   b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_slot_off, b.d_dio_cand,
-                  b.d_dio_score, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv, b.d_phase, b.d_pulse_cnt, b.d_pulse_tile_cnt,
-                  b.d_pulse_off, b.d_dc_remover, b.d_pulse_rec, b.d_pulse_perm};
+                  b.d_dio_score, b.d_syn_arena, b.d_pulse_rec, b.d_pulse_perm};
   for (void* p : ptrs)
     if (p) hipFree(p);
-  if (b.h_pulse_cnt) hipHostFree(b.h_pulse_cnt);
   if (b.dio_host) dio_free_host(b.dio_host);
   b.dio_host = nullptr;
   if (b.harvest_ws) harvest_free(b.harvest_ws);

@@ -258,6 +258,44 @@ __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
   }
 }
 
+// exclusive scan of the per-utterance pulse counts; info[0] = total, info[1] = largest count (pinned host memory)
+__global__ __launch_bounds__(256) void synth_pulse_off_kernel(const int* __restrict__ cnt, int n_utt,
+                                                              int64_t* __restrict__ off, int64_t* __restrict__ info) {
+  __shared__ int64_t part[256];
+  __shared__ int mx[256];
+  const int per = (n_utt + 255) / 256;
+  const int lo = threadIdx.x * per, hi = imin(n_utt, lo + per);
+  int64_t sum = 0;
+  int m = 0;
+  for (int u = lo; u < hi; ++u) {
+    sum += cnt[u];
+    m = imax(m, cnt[u]);
+  }
+  part[threadIdx.x] = sum;
+  mx[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    int mm = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t v = part[i];
+      part[i] = run;
+      run += v;
+      mm = imax(mm, mx[i]);
+    }
+    off[n_utt] = run;
+    info[0] = run;
+    info[1] = mm;
+    __threadfence_system();
+  }
+  __syncthreads();
+  int64_t run = part[threadIdx.x];
+  for (int u = lo; u < hi; ++u) {
+    off[u] = run;
+    run += cnt[u];
+  }
+}
+
 __global__ void synth_dc_remover_kernel(int fft_size, double* __restrict__ dcr) {   // GetDCRemover :322-334
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double dc = 0.0;
@@ -600,22 +638,26 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   int rc = c.ensure_rng(b.rng_bound_synthesis());
   if (rc) return rc;
   if (!b.d_pulse_idx) {
-    auto al = [&](void** dst, size_t bytes) {
-      if (rc) return;
-      rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
-    };
-    al((void**)&b.d_pulse_idx, sizeof(int) * (size_t)b.total_y);
-    al((void**)&b.d_pulse_shift, sizeof(double) * (size_t)b.total_y);
-    al((void**)&b.d_vuv, sizeof(double) * (size_t)b.total_y);
-    al((void**)&b.d_phase, sizeof(double) * (size_t)b.total_y);
-    al((void**)&b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt);
-    al((void**)&b.d_pulse_tile_cnt,
-       sizeof(int) * (size_t)b.n_utt * (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1));
-    al((void**)&b.d_pulse_off, sizeof(int64_t) * ((size_t)b.n_utt + 1));
-    al((void**)&b.d_dc_remover, sizeof(double) * (size_t)F);
+    // one allocation for the work arrays of this batch (sections aligned to 256 bytes)
+    const size_t ny = (size_t)b.total_y, nu = (size_t)b.n_utt;
+    const size_t tiles = (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1);
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
+    const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
+    const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
+    unsigned char* base = nullptr;
+    rc = wm_check(hipMalloc((void**)&base, at));
     if (rc) return rc;
-    rc = wm_check(hipHostMalloc((void**)&b.h_pulse_cnt, sizeof(int) * (size_t)b.n_utt));
-    if (rc) return rc;
+    if (!c.h_pulse_info) {            // per context: two pinned, device-visible integers
+      rc = wm_check(hipHostMalloc((void**)&c.h_pulse_info, sizeof(int64_t) * 2, hipHostMallocMapped));
+      if (!rc) rc = wm_check(hipHostGetDevicePointer((void**)&c.d_pulse_info, c.h_pulse_info, 0));
+      if (rc) { (void)hipFree(base); return rc; }
+    }
+    b.d_syn_arena = base;
+    b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
+    b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
+    b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
+    b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
     hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, st, F, b.d_dc_remover);
   }
   const double fp = b.p.frame_period / 1000.0;
@@ -640,18 +682,17 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     hipLaunchKernelGGL(synth_pulse_search_kernel<true>, dim3(tiles_max, b.n_utt), dim3(256), 0, st, b.d_y_off,
                        b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
   }
-  rc = wm_check(hipMemcpyAsync(b.h_pulse_cnt, b.d_pulse_cnt, sizeof(int) * (size_t)b.n_utt,
-                               hipMemcpyDeviceToHost, st));
+  // Pulse offsets (exclusive scan over the utterances) stay on the device; the host needs two numbers only -- the
+  // total, which sizes the response scratch, and the largest count, which sizes a grid -- and reads them from
+  // pinned memory the kernel writes directly.  No hipMemcpy in either direction: a small copy queues on the same
+  // DMA engine as whatever bulk transfer another stream has in flight (a 1 GB feature download held this
+  // synchronisation, and with it the whole step, for 20 ms).
+  hipLaunchKernelGGL(synth_pulse_off_kernel, dim3(1), dim3(256), 0, st, (const int*)b.d_pulse_cnt, b.n_utt,
+                     b.d_pulse_off, c.d_pulse_info);
+  rc = wm_check(hipStreamSynchronize(st));                // the one host round trip of the path
   if (rc) return rc;
-  rc = wm_check(hipStreamSynchronize(st));                // the pulse count sizes the response scratch
-  if (rc) return rc;
-  std::vector<int64_t> poff((size_t)b.n_utt + 1, 0);
-  for (int u = 0; u < b.n_utt; ++u) poff[(size_t)u + 1] = poff[(size_t)u] + b.h_pulse_cnt[u];
-  const int64_t total_p = poff[(size_t)b.n_utt];
-  rc = wm_check(hipMemcpyAsync(b.d_pulse_off, poff.data(), sizeof(int64_t) * poff.size(), hipMemcpyHostToDevice, st));
-  if (rc) return rc;
-  rc = wm_check(hipStreamSynchronize(st));                // poff is a local
-  if (rc) return rc;
+  const int64_t total_p = c.h_pulse_info[0];
+  const int max_np = (int)c.h_pulse_info[1];
   b.syn_total_p = total_p;
   b.syn_chunk = 0;
   if (total_p == 0) return WM_OK;
@@ -676,8 +717,6 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     b.pulse_rec_cap = cap;
   }
   {
-    int max_np = 0;
-    for (int u = 0; u < b.n_utt; ++u) max_np = b.h_pulse_cnt[u] > max_np ? b.h_pulse_cnt[u] : max_np;
     hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (max_np + 255) / 256), b.n_utt), dim3(256), 0, st,
                        b.d_f_off, b.d_y_off, b.d_pulse_off, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,
                        (PulseRec*)b.d_pulse_rec);

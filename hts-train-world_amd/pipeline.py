@@ -1,0 +1,136 @@
+"""Host-to-host pipeline: waveforms in pinned host memory in, feature files' contents in pinned host memory out.
+
+SURVEY.md 8(d) counts the metric "including H2D of waveforms and D2H of features", and 8(e) asks for double-buffered
+pinned copies.  The types on the wire are the on-disk ones of the reference's CLIs:
+
+    in   int16 samples (the wav payload; x = s / 32768 is formed on the device, test/audioio.cpp:236-249)   2 B/sample
+    out  float32 f0 [T], sp [T][F/2+1], ap [T][F/2+1] (test/analysis.cpp:360-390)                            4 B/value
+         int16 resynthesised samples (test/audioio.cpp:160-167), when synthesis is on
+
+Three HIP streams: uploads, kernels (the context's), downloads; two slots of device and pinned buffers.  While the
+kernels of step k run, the waveforms of step k+1 travel up and the features of step k-1 travel down; PCIe and the
+kernels overlap, so a step costs max(kernels, download) instead of their sum (the download dominates: 4.1 KB per frame
+against 160 B up).
+
+Order matters on the copy engine: copies of both directions are served in the order they were issued, so the (small)
+upload of step k+1 has to be issued BEFORE the (large) download of step k, or the next step's kernels wait for that
+whole download to drain.  Hence the two calls: feed() issues an upload, submit() the kernels and the download of the
+oldest fed step; keep one upload ahead:
+
+    feed()                       # step 0
+    for k in range(K):
+        fill input_buffer(); feed()      # step k + 1 (while there is one)
+        slot = submit()                  # step k
+        ... result(previous slot) ...
+
+torch is plumbing here (streams, events, pinned memory, dtype conversion); the analysis is libworld_mi355.so's.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import world as W
+
+
+class HostPipeline:
+    """Fixed batch shape (a list of utterance lengths), processed repeatedly with different waveforms."""
+
+    SLOTS = 2
+
+    def __init__(self, ctx, params, x_lengths, synthesis=True):
+        import torch
+        self.torch = torch
+        self.batch = b = W.WorldBatch(ctx, params, x_lengths=x_lengths)
+        self.synthesis = synthesis
+        T, bins, n, ny = int(b.total_frames), b.bins, int(b.total_samples), int(b.total_out)
+        dev = lambda *shape, dtype: torch.empty(*shape, dtype=dtype, device="cuda")
+        pin = lambda *shape, dtype: torch.empty(*shape, dtype=dtype, pin_memory=True)
+        f32, f64, i16 = torch.float32, torch.float64, torch.int16
+        self.x_pinned = [pin(n, dtype=i16) for _ in range(self.SLOTS)]
+        self.x_dev = [dev(n, dtype=i16) for _ in range(self.SLOTS)]
+        self.out64 = (dev(T, dtype=f64), dev(T, dtype=f64), dev(T, bins, dtype=f64), dev(T, bins, dtype=f64))
+        self.y64 = dev(ny, dtype=f64)
+        self.out32 = [(dev(T, dtype=f32), dev(T, bins, dtype=f32), dev(T, bins, dtype=f32), dev(ny, dtype=i16))
+                      for _ in range(self.SLOTS)]
+        self.host = [(pin(T, dtype=f32), pin(T, bins, dtype=f32), pin(T, bins, dtype=f32), pin(ny, dtype=i16))
+                     for _ in range(self.SLOTS)]
+        self.compute = torch.cuda.current_stream()
+        self.up, self.down = torch.cuda.Stream(), torch.cuda.Stream()
+        ev = lambda: [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.ev_up, self.ev_x_free, self.ev_done, self.ev_down = ev(), ev(), ev(), ev()
+        for s in range(self.SLOTS):                          # everything starts free
+            self.ev_x_free[s].record(self.compute)
+            self.ev_down[s].record(self.down)
+        self.step = 0                                        # steps submitted
+        self.fed = 0                                         # steps fed
+
+    def input_buffer(self):
+        """The pinned int16 buffer of the next feed() (numpy view); fill it, then call feed()."""
+        s = self.fed % self.SLOTS
+        self.ev_up[s].synchronize()                          # the slot's previous upload has left the buffer
+        return self.x_pinned[s].numpy()
+
+    def feed(self):
+        """Issue the upload of the buffer input_buffer() returned.  At most SLOTS steps may be fed and not submitted."""
+        assert self.fed - self.step < self.SLOTS, "feed() is more than %d steps ahead of submit()" % self.SLOTS
+        torch = self.torch
+        s = self.fed % self.SLOTS
+        with torch.cuda.stream(self.up):
+            self.up.wait_event(self.ev_x_free[s])            # the kernels that read this slot last have consumed it
+            self.x_dev[s].copy_(self.x_pinned[s], non_blocking=True)
+            self.ev_up[s].record(self.up)
+        self.fed += 1
+
+    def submit(self):
+        """Issue the kernels and the download of the oldest fed step (feeds it first if nothing is fed).  Returns
+        the step's slot; everything is asynchronous except the one host round trip inside Synthesis."""
+        torch = self.torch
+        if self.fed == self.step:
+            self.feed()
+        s = self.step % self.SLOTS
+        b = self.batch
+        self.compute.wait_event(self.ev_up[s])
+        x = self.x_dev[s].to(torch.float64).mul_(1.0 / 32768.0)            # exact: a power of two
+        self.ev_x_free[s].record(self.compute)
+        f0, sp, ap, y = self.out64[1], self.out64[2], self.out64[3], None
+        if self.synthesis:
+            b.analyze_synthesize(x, out=self.out64, y=self.y64)
+            y = self.y64
+        else:
+            b.analyze(x, out=self.out64)
+        self.compute.wait_event(self.ev_down[s])                           # slot s's previous download has finished
+        o = self.out32[s]
+        o[0].copy_(f0)
+        o[1].copy_(sp)
+        o[2].copy_(ap)
+        if y is not None:                                                  # wavwrite: clip(trunc(y * 32767))
+            o[3].copy_(torch.clamp(torch.trunc(y * 32767.0), -32768.0, 32767.0))
+        self.ev_done[s].record(self.compute)
+        with torch.cuda.stream(self.down):
+            self.down.wait_event(self.ev_done[s])
+            for h, d in zip(self.host[s], o):
+                h.copy_(d, non_blocking=True)
+            self.ev_down[s].record(self.down)
+        self.step += 1
+        return s
+
+    def result(self, slot):
+        """Wait for the download of `slot`; returns numpy views (f0, sp, ap, y_int16) of its pinned buffers, valid
+        until that slot is submitted again."""
+        self.ev_down[slot].synchronize()
+        return tuple(h.numpy() for h in self.host[slot])
+
+    def bytes_per_step(self):
+        b = self.batch
+        up = 2 * int(b.total_samples)
+        down = 4 * int(b.total_frames) * (1 + 2 * b.bins) + (2 * int(b.total_out) if self.synthesis else 0)
+        return up, down
+
+    def close(self):
+        self.torch.cuda.synchronize()
+        self.batch.close()
+
+
+def to_int16(x):
+    """float samples s / 32768 (synth_data, wavread) back to the int16 payload."""
+    return np.round(np.asarray(x) * 32768.0).astype(np.int16)

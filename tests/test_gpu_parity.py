@@ -748,3 +748,44 @@ def test_synthesis_in_response_chunks(gpu, monkeypatch):
         assert torch.equal(b.synthesize(f0, sp, ap), y_ref)
         assert torch.equal(b.analyze_synthesize(torch.from_numpy(np.concatenate(xs)).cuda())[4], y_ref)
     b.close()
+
+
+def test_host_pipeline_gives_the_device_results(gpu, pkg):
+    """hts-train-world_amd/pipeline.py: int16 in, float32 features and int16 resynthesis out, three streams, two
+    slots -- the same numbers as the resident API converted afterwards, whatever the overlap, step after step."""
+    torch, W, ctx = gpu
+    pl, recipe = pkg.pipeline, pkg.recipe
+    fs = 16000
+    sets = [[sd.make_utterance(120 + 3 * k + j, fs, duration=d) for j, d in enumerate((0.5, 0.9, 0.7))] for k in range(4)]
+    lens = [len(x) for x in sets[0]]
+    pipe = pl.HostPipeline(ctx, W.default_params(fs, 5.0), lens, synthesis=True)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+    want = []
+    for xs in sets:
+        t, f0, sp, ap, y = b.analyze_synthesize(torch.from_numpy(np.concatenate(xs)).cuda())
+        y16 = np.clip(np.trunc(y.cpu().numpy() * 32767.0), -32768, 32767).astype(np.int16)
+        want.append((f0.float().cpu().numpy(), sp.float().cpu().numpy(), ap.float().cpu().numpy(), y16))
+    got, prev = [], None
+    pipe.input_buffer()[:] = pl.to_int16(np.concatenate(sets[0]))
+    pipe.feed()
+    for k in range(len(sets)):                        # one upload ahead, two steps in flight
+        if k + 1 < len(sets):
+            pipe.input_buffer()[:] = pl.to_int16(np.concatenate(sets[k + 1]))
+            pipe.feed()
+        slot = pipe.submit()
+        if prev is not None:
+            got.append(tuple(a.copy() for a in pipe.result(prev)))
+        prev = slot
+    got.append(tuple(a.copy() for a in pipe.result(prev)))
+    # and the simple form: submit() feeds by itself when nothing is fed
+    pipe.input_buffer()[:] = pl.to_int16(np.concatenate(sets[1]))
+    again = pipe.result(pipe.submit())
+    for a, c in zip(again, want[1]):
+        np.testing.assert_array_equal(a, c)
+    for g, w in zip(got, want):
+        for a, c in zip(g, w):
+            np.testing.assert_array_equal(a, c)
+    up, down = pipe.bytes_per_step()
+    assert up == 2 * sum(lens) and down > 4 * int(b.total_frames) * 2 * b.bins
+    pipe.close()
+    b.close()
