@@ -126,6 +126,7 @@ struct Batch {
   double* d_dio_score = nullptr;     // [band][total_f]
   void* harvest_ws = nullptr;        // HarvestWs (harvest.hip)
   void* codec_tables = nullptr;      // CodecTables (codec.hip)
+  void* vibrato_ws = nullptr;        // VibWs (vibrato.hip)
   // Synthesis workspace: sections of one allocation (d_syn_arena), laid out by synthesis_prepare
   void* d_syn_arena = nullptr;
   int* d_pulse_idx = nullptr;        // [total_y]
@@ -160,6 +161,8 @@ int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* 
                               double* d_y);
 int launch_utterance_status(Batch& b, const double* d_x, const double* d_f0, const double* d_sp, const double* d_ap,
                             int* d_status);
+int launch_vibrato(Batch& b, const float* d_lf0, const int* seg_utt_off, const int* seg_start, const int* seg_end,
+                   const double* seg_pitch, float* d_vib, float* d_lf0_out, int* n_too_long);
 int codec_num_aperiodicities(int fs);
 int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded);
 int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);

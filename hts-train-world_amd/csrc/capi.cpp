@@ -284,6 +284,10 @@ int WorldMi355AnalyzeSynthesize(WorldMi355Batch* hb, const double* x, double* t,
                                 double* ap, double* y) {
   return launch_analyze_synthesize(hb->b, x, t, f0, sp, ap, y);
 }
+int WorldMi355Vibrato(WorldMi355Batch* hb, const float* lf0, const int* seg_utt_off, const int* seg_start,
+                      const int* seg_end, const double* seg_pitch, float* vib, float* lf0_out, int* n_too_long) {
+  return launch_vibrato(hb->b, lf0, seg_utt_off, seg_start, seg_end, seg_pitch, vib, lf0_out, n_too_long);
+}
 int WorldMi355UtteranceStatus(WorldMi355Batch* hb, const double* x, const double* f0, const double* sp,
                               const double* ap, int* status) {
   return launch_utterance_status(hb->b, x, f0, sp, ap, status);

@@ -154,6 +154,7 @@ namespace wm {
 void dio_free_host(void* h);
 void harvest_free(void* p);
 void codec_free(void* p);
+void vibrato_free(void* p);
 
 void free_batch_buffers(Batch& b) {
   void* ptrs[] = {b.d_arena, b.d_perm2, b.d_sm_twid, b.d_d4c_window, b.d_utt_total,
@@ -169,5 +170,7 @@ void free_batch_buffers(Batch& b) {
   b.harvest_ws = nullptr;
   if (b.codec_tables) codec_free(b.codec_tables);
   b.codec_tables = nullptr;
+  if (b.vibrato_ws) vibrato_free(b.vibrato_ws);
+  b.vibrato_ws = nullptr;
 }
 }  // namespace wm

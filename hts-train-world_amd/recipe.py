@@ -303,6 +303,79 @@ def cmp_files(jobs, streams, sampling_rate, frame_shift, htk_type=9, ctx=None, m
     return done
 
 
+# ---- vibrato (data/scripts/Extract.py, data/Makefile.in:215) --------------------------------------------------------
+_SCALE = ("C", "Db", "D", "Eb", "E", "F", "Gb", "G", "Ab", "A", "Bb", "B")
+
+
+def note_pitch(note):
+    """Hz of a note name such as "A4" or "Db5" (equal temperament around A4 = 440; Extract.py:109-114); 0 for "xx"."""
+    if note == "xx":
+        return 0.0
+    return 440.0 * 2.0 ** (int(note[-1:]) - 4) * 2.0 ** ((_SCALE.index(note[:-1]) - 9) / 12.0)
+
+
+def read_label_segments(mono_path, full_path, frame_period, n_frames):
+    """[(start_frame, end_frame, note_pitch_hz)] of an utterance from its mono and full-context label files, as
+    Extract.py reads them (:63-84, :176-187): three fields per line, times in units of 100 ns divided by 10e3 (ms),
+    frames = floor(time / frame_period) clamped to [0, n_frames], the note from the `/E:<note>]` field of the
+    full-context label."""
+    import math
+    import re
+    with open(mono_path) as f:
+        mono = f.read().split("\n")
+    with open(full_path) as f:
+        full = f.read().split("\n")
+    if len(mono) != len(full):
+        raise ValueError("mono label not equal with full label")
+    out = []
+    for m, fl in zip(mono, full):
+        if m == "" or fl == "":
+            continue
+        md, fd = m.split(" "), fl.split(" ")
+        if len(md) != 3 or len(fd) != 3:
+            raise ValueError("label line without three fields")
+        t0, t1 = float(md[0]) / 10e3, float(md[1]) / 10e3
+        note = re.findall(r"/E:\w+\]", fd[2])[0].replace("/E:", "").replace("]", "")
+        out.append((max(math.floor(t0 / frame_period), 0), min(math.floor(t1 / frame_period), n_frames), note_pitch(note)))
+    return out
+
+
+def vibrato_files(jobs, frame_period, fs=48000, ctx=None, max_batch_frames=MAX_BATCH_FRAMES, io_threads=8):
+    """jobs: [(lf0_file, mono_label, full_label, vib_out)].  What `Extract.py <base> <frame_period>` does for every
+    job: the lf0 file (float32 log f0, one column) is REWRITTEN with two columns (log f0, log(f0 - note + 500)), the
+    vib file gets (log depth, log period) per frame.  fs only labels the batch (nothing here depends on it)."""
+    import torch
+    jobs = list(jobs)
+    frames = [os.path.getsize(j[0]) // 4 for j in jobs]
+    mine = _my_share(frames)
+    own_ctx = ctx is None
+    ctx = ctx or _own_context()
+    done = 0
+    with ThreadPoolExecutor(io_threads) as pool:
+        writes = []
+        for group in _batches(sorted(mine, key=lambda i: -frames[i]), frames, max_batch_frames):
+            T = [frames[i] for i in group]
+            b = W.WorldBatch(ctx, W.default_params(fs, frame_period), f0_lengths=T)
+            lf0s = list(pool.map(lambda i: _f32(jobs[i][0]), group))
+            segs = [read_label_segments(jobs[i][1], jobs[i][2], frame_period, frames[i]) for i in group]
+            lf0 = torch.from_numpy(np.ascontiguousarray(np.concatenate(lf0s))).cuda()
+            vib, lf2, too_long = b.vibrato(lf0, segs)
+            if too_long:
+                print("warning: %d voiced run(s) longer than 3072 frames left without vibrato" % too_long, file=sys.stderr)
+            vh, lh = vib.cpu().numpy(), lf2.cpu().numpy()
+            fo = b.frame_offsets
+            for k, i in enumerate(group):
+                writes.append(pool.submit(np.ascontiguousarray(lh[fo[k]:fo[k + 1]]).tofile, jobs[i][0]))
+                writes.append(pool.submit(np.ascontiguousarray(vh[fo[k]:fo[k + 1]]).tofile, jobs[i][3]))
+            done += int(b.total_frames)
+            b.close()
+        for w_ in writes:
+            w_.result()
+    if own_ctx:
+        ctx.close()
+    return done
+
+
 def _read_scp(path):
     with open(path) as f:
         rows = [ln.split() for ln in f if ln.strip() and not ln.startswith("#")]

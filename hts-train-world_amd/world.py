@@ -75,6 +75,7 @@ def load_library():
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
     L.WorldMi355AnalyzeSynthesize.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.WorldMi355UtteranceStatus.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.WorldMi355Vibrato.argtypes = [vp, vp, _ip, _ip, _ip, _dp, vp, vp, _ip]
     L.WorldMi355GetNumberOfAperiodicities.argtypes = [C.c_int]
     L.WorldMi355CodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
     L.WorldMi355DecodeSpectralEnvelope.argtypes = [vp, vp, C.c_int, vp]
@@ -234,6 +235,27 @@ class WorldBatch:
         _check(load_library().WorldMi355Synthesis(self.handle, self._p(f0), self._p(sp), self._p(ap), self._p(y)),
                "Synthesis")
         return y
+
+    def vibrato(self, lf0, segments):
+        """The recipe's vibrato feature (data/scripts/Extract.py).  lf0: float32 cuda [total_frames];
+        segments: per utterance a list of (start_frame, end_frame, note_pitch_hz).  Returns (vib, lf0_2col, n_too_long):
+        float32 cuda tensors [total_frames][2] after the script's soprLog."""
+        import torch
+        assert lf0.dtype == torch.float32 and lf0.is_cuda and lf0.is_contiguous() and len(segments) == self.n_utt
+        off = np.zeros(self.n_utt + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(s) for s in segments])
+        flat = [seg for s in segments for seg in s]
+        ss = np.ascontiguousarray([int(v[0]) for v in flat], dtype=np.int32)
+        se = np.ascontiguousarray([int(v[1]) for v in flat], dtype=np.int32)
+        sp_ = np.ascontiguousarray([float(v[2]) for v in flat], dtype=np.float64)
+        vib = torch.empty(self.total_frames, 2, dtype=torch.float32, device="cuda")
+        out = torch.empty(self.total_frames, 2, dtype=torch.float32, device="cuda")
+        n = C.c_int(0)
+        _check(load_library().WorldMi355Vibrato(self.handle, C.c_void_p(lf0.data_ptr()), off.ctypes.data_as(_ip),
+                                                ss.ctypes.data_as(_ip), se.ctypes.data_as(_ip), sp_.ctypes.data_as(_dp),
+                                                C.c_void_p(vib.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(n)),
+               "Vibrato")
+        return vib, out, n.value
 
     def utterance_status(self, x=None, f0=None, sp=None, ap=None):
         """int32 cuda tensor [n_utt] of WM_UTT_* flags (1 non-finite input, 2 too short for Dio, 4 non-finite output)."""

@@ -159,6 +159,19 @@ void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_sample
                          int htk_type, unsigned char out12[12]);
 
 
+/* ---- Vibrato feature (data/scripts/Extract.py:115-227, invoked at data/Makefile.in:215), SURVEY.md 8(f) rank 4 ----
+ * lf0: DEVICE, float32 [total_frames], log f0 with 0 for unvoiced frames (WorldMi355RecipeFeatures' lf0).
+ * Label segments: HOST arrays.  Utterance u owns segments seg_utt_off[u] .. seg_utt_off[u+1]-1 (n_utt + 1 offsets);
+ * segment s covers frames [seg_start[s], seg_end[s]) of its utterance (floor(label time / frame period), clamped as
+ * Extract.py:181-182) and has note pitch seg_pitch[s] in Hz (0 for "xx").
+ * Outputs (DEVICE, float32, after the script's soprLog): vib [total_frames][2] = log depth, log period;
+ * lf0_out [total_frames][2] = log f0, log(f0 - pitch + 500) -- what the script writes back over the lf0 file.
+ * *n_too_long (may be NULL): voiced runs longer than 3072 frames, left without vibrato.  Synchronises the stream.
+ * Parity of this entry point is UNPINNED: the reference holds no fixtures for it and its LOWESS is an unpinned
+ * third-party dependency (statsmodels); see oracle/world_oracle_vibrato.c. */
+int WorldMi355Vibrato(WorldMi355Batch* b, const float* lf0, const int* seg_utt_off, const int* seg_start,
+                      const int* seg_end, const double* seg_pitch, float* vib, float* lf0_out, int* n_too_long);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around each launch of the
  * named kernels ("dio_lowcut_kernel", "dio_band_kernel", "stonemask_kernel", "cheaptrick_kernel",
  * "d4c_lovetrain_kernel", "d4c_kernel", "synth_timebase_kernel", "synth_pulse_kernel",

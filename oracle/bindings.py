@@ -197,6 +197,43 @@ class Oracle:
         self.lib.orc_htk_header(int(nframes), int(samprate), int(frameshift), int(bytes_per_frame), int(kind), buf)
         return bytes(buf)
 
+    # -- vibrato (Extract.py; world_oracle_vibrato.c, parity unpinned) ---------
+    def lowess(self, y, frac=2.0 / 3.0, it=20):
+        y = _c(y)
+        out = np.zeros(len(y))
+        self.lib.orc_lowess.argtypes = [_dp, C.c_int, C.c_double, C.c_int, _dp]
+        self.lib.orc_lowess(_p(y), len(y), frac, it, _p(out))
+        return out
+
+    def get_vibrate(self, f):
+        f = _c(f)
+        t = np.zeros((2 * len(f) + 2, 2))
+        self.lib.orc_get_vibrate.restype = C.c_int
+        self.lib.orc_get_vibrate.argtypes = [_dp, C.c_int, _dp]
+        n = self.lib.orc_get_vibrate(_p(f), len(f), _p(t))
+        return t[:n]
+
+    def vibrato(self, lf0, segments):
+        """lf0: float32 [T] as the lf0 file holds it; segments: [(start_frame, end_frame, pitch_hz)].
+        Returns (vib, lf0_2col) float32 [T][2] after soprLog, and the number of runs."""
+        e = np.exp(np.asarray(lf0, dtype=np.float32).astype(np.float64))
+        f0 = np.where(e < 1.0, 0.0, e)                                  # soprExp, Extract.py:98-108
+        T = len(f0)
+        ip = C.POINTER(C.c_int)
+        ss = np.ascontiguousarray([s[0] for s in segments], dtype=np.int32)
+        se = np.ascontiguousarray([s[1] for s in segments], dtype=np.int32)
+        sp = np.ascontiguousarray([s[2] for s in segments], dtype=np.float64)
+        vib, df0 = np.zeros((T, 2)), np.zeros((T, 2))
+        self.lib.orc_vibrato.restype = C.c_int
+        self.lib.orc_vibrato.argtypes = [_dp, C.c_int, ip, ip, _dp, C.c_int, _dp, _dp]
+        runs = self.lib.orc_vibrato(_p(f0), T, ss.ctypes.data_as(ip), se.ctypes.data_as(ip), _p(sp), len(ss), _p(vib), _p(df0))
+        fp_ = C.POINTER(C.c_float)
+        self.lib.orc_sopr_log.argtypes = [_dp, C.c_int, fp_]
+        o1, o2 = np.zeros((T, 2), dtype=np.float32), np.zeros((T, 2), dtype=np.float32)
+        self.lib.orc_sopr_log(_p(vib), 2 * T, o1.ctypes.data_as(fp_))
+        self.lib.orc_sopr_log(_p(df0), 2 * T, o2.ctypes.data_as(fp_))
+        return o1, o2, runs
+
     # -- primitives ----------------------------------------------------------
     def randn_table(self, n):
         out = np.zeros(n)

@@ -101,6 +101,13 @@ void orc_recipe_decode(const float *lf0, const float *mgc, const float *bap, int
 void orc_htk_header(int nframes, int samprate, int frameshift, int bytes_per_frame, int type,
                     unsigned char *out12);                                 /* addhtkheader.pl:45-82 */
 
+/* ---- vibrato (data/scripts/Extract.py:115-227; world_oracle_vibrato.c) -- PARITY UNPINNED ---- */
+void orc_lowess(const double *y, int n, double frac, int it, double *fit);   /* statsmodels lowess on x = 0..n-1 */
+int  orc_get_vibrate(const double *f, int n, double *t);                      /* Extract.py:115-158 */
+int  orc_vibrato(const double *f0, int T, const int *seg_start, const int *seg_end, const double *seg_pitch,
+                 int nseg, double *vib, double *df0);                         /* Extract.py:161-227 */
+void orc_sopr_log(const double *in, int n, float *out);                       /* Extract.py:86-96 */
+
 #ifdef __cplusplus
 }
 #endif

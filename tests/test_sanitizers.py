@@ -27,6 +27,7 @@ def test_oracle_suites_under_asan_ubsan():
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_golden.py"), os.path.join(ROOT, "tests", "test_oracle_primitives.py"),
+                        os.path.join(ROOT, "tests", "test_vibrato.py"),
                         "-m", "not gpu"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
