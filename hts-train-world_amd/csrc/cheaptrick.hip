@@ -10,7 +10,8 @@
 #include "batch.hpp"
 #include "common.hpp"
 #include "fft.hpp"
-#include "window.hpp"
+#include "frame.hpp"
+#include "spectrum.hpp"
 
 namespace wm {
 
@@ -56,49 +57,62 @@ template <int F>
 __global__ __launch_bounds__(64, F >= 4096 ? 1 : 3) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
-    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, double q1,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, double q1,
     int64_t total_frames, double* __restrict__ sp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2;
+  // mirror margin of the smoothing (width 2 f0 / 3: int(width F / fs) + 1 bins) and of DCCorrection
+  // (2 + int(f0 F / fs) bins) for any f0 up to fs / 2
+  constexpr int kBM = ((F / 3 + 2) + 1) & ~1;
   constexpr int kImg = 2 * FftLds<N>::kElems;                 // doubles
-  constexpr int kCh = ((H + 2 * (F / 3 + 1) + 1 + 63) / 64) | 1;   // odd per-lane chunk of the smoothing scan
-  constexpr int kSeg = 64 * kCh;                                // worst-case smoothing scratch
-  constexpr int kWork = kImg > kSeg ? kImg : kSeg;
-  __shared__ __attribute__((aligned(16))) double smem[(H + 2) + kWork];
-  double* pw = smem;                                           // [H+1] power / log spectrum
-  double* work = smem + (H + 2);                               // frame | FFT image | spectrum | scan scratch
-  cpx* img = reinterpret_cast<cpx*>(work);
+  constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
+  constexpr int kTot = kImg > kRegion ? kImg : kRegion;
+  __shared__ __attribute__((aligned(16))) double smem[kTot];
+  double* pw = smem + kBM;                                     // [-kBM .. H + kBM] power / log spectrum with margins
+  cpx* img = reinterpret_cast<cpx*>(smem);                     // FFT image | spectrum (aliases it)
 
   const int lane0 = threadIdx.x;
   FftTw<N> tw;
   tw.init(lane0);
-  const double f0_floor = 3.0 * fs / (F - 3.0);                // cheaptrick.cpp:196-198
 
   WM_FOR_EACH_FRAME(frame, total_frames) {
     const int lane = opaque_lane(lane0);
+    const int fs = opaque_uniform(fs_arg);
     tw.fence();
+    const double f0_floor = 3.0 * fs / (F - 3.0);              // cheaptrick.cpp:196-198
     const int u = frame_utt[frame];
     const double f0v = f0[frame];
-    const double cf0 = !(f0v > f0_floor) ? kDefaultF0 : f0v;   // f0 <= floor (cheaptrick.cpp:217); NaN too
+    const double cf0 = uniform_d(!(f0v > f0_floor) ? kDefaultF0 : f0v);   // f0 <= floor (cheaptrick.cpp:217); NaN too
     const int roff = rng_off[frame];
     cpx v[M];
 
-    // ---- GetWindowedWaveform (cheaptrick.cpp:87-142) ----
-    const FrameWindow fw = windowed_waveform_lds<kHann, true>(x + x_off[u], x_len[u], fs, cf0, tpos[frame], 3.0,
-                                                              rtab, roff, lane, work, F);
-    load_packed<N>(work, lane, v);
+    // ---- GetWindowedWaveform (cheaptrick.cpp:87-142), straight into the FFT operand ----
+    const FrameGeom fg = frame_geom(fs, cf0, uniform_d(tpos[frame]), 3.0);
+    frame_packed<kHann, true, M>(x + x_off[u], x_len[u], fg, rtab, roff, lane, v);
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
     rfft_forward<N>(v, img, img, tw, lane);
-    for (int k = lane; k <= H; k += 64) {
-      const cpx s = img[k];
-      pw[k] = s.x * s.x + s.y * s.y;
+    {
+      double p[M + 1];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const cpx s = img[lane + 64 * m];
+        p[m] = s.x * s.x + s.y * s.y;
+      }
+      {
+        const cpx s = img[N];
+        p[M] = s.x * s.x + s.y * s.y;
+      }
+      wave_sync();
+#pragma unroll
+      for (int m = 0; m < M; ++m) pw[lane + 64 * m] = p[m];
+      if (lane == 0) pw[H] = p[M];
+      wave_sync();
     }
-    wave_sync();
-    dc_correction_lds(pw, cf0, fs, F, work, lane);
+    dc_correction_margin<H, kBM>(pw, cf0, fs, F, lane);
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
-    linear_smoothing_lds<kCh>(pw, cf0 * 2.0 / 3.0, fs, F, work, pw, lane);
-    for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fw.L + i)) * kEps);
+    linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane);
+    for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fg.L + i)) * kEps);
     wave_sync();
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
@@ -125,12 +139,14 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : 3) void cheaptrick_kernel(
       }
     }
     rfft_backward<N>(img, v, img, tw, lane);
-    wave_sync();
-#pragma unroll
-    for (int m = 0; m < M; ++m) img[lane + 64 * m] = v[m];       // x[2n], x[2n+1] -> work[0..F)
-    wave_sync();
+    // x[2n], x[2n+1] for n = lane + 64 m: the first H + 1 samples are the envelope's logarithm
     double* row = sp + frame * (int64_t)(H + 1);
-    for (int i = lane; i <= H; i += 64) row[i] = exp(work[i]);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i0 = 2 * (lane + 64 * m);
+      if (i0 <= H) row[i0] = exp(v[m].x);
+      if (i0 + 1 <= H) row[i0 + 1] = exp(v[m].y);
+    }
     wave_sync();
   }
 }
