@@ -25,7 +25,9 @@ struct Context {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int num_cu = 256;
-  int frame_grid = 256 * 8;          // workgroups for grid-stride per-frame kernels
+  int frame_grid = 256 * 8;          // upper bound on the workgroups of a grid-stride per-frame kernel
+  int oversub = 8;                   // workgroups per resident slot of those kernels (persistent_grid): measured on
+                                     // configs[1], 21.2 / 18.0 / 17.7 / 17.3 / 17.3 ms per step at 1 / 2 / 4 / 8 / 16
   uint32_t* d_rng = nullptr;         // universal randn table, uint32 sums
   int64_t rng_cap = 0;
   uint32_t rng_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};   // matlabfunctions.cpp:247-250
@@ -44,13 +46,17 @@ struct Context {
   void timing_clear();
 };
 
-// Grid of a persistent (grid-stride) kernel: exactly the workgroups that are resident at once, so
-// that every wave slot gets the same share of frames and there is no half-empty second round.
+// Grid of a grid-stride per-frame kernel: a small multiple (Context::oversub) of the workgroups that are resident
+// at once.  Exactly the resident number gives every wave slot the same share when the kernel has the machine to
+// itself, but then a slot that is busy with another stream's kernel when this one starts (the f0-only first part
+// of Synthesis runs beside CheapTrick and D4C) delays a whole share by that much: the launch ends late by the
+// overlap.  With a few workgroups per slot the hardware dispatcher hands the shares out as slots become free; the
+// price is a last round that is not full (at most one share of 1 / oversub of a slot's work).
 template <class K> inline int persistent_grid(const Context& c, K kernel, int block, int64_t items) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
     per_cu = 4;
-  const int64_t g = (int64_t)c.num_cu * per_cu;
+  const int64_t g = (int64_t)c.num_cu * per_cu * c.oversub;
   return (int)(items < g ? items : g);
 }
 

@@ -82,7 +82,7 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
   hipGetDevice(&c.device);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) c.num_cu = prop.multiProcessorCount;
-  c.frame_grid = c.num_cu * 16;
+  c.frame_grid = c.num_cu * 128;
   // NULL selects the legacy default stream (stream 0): it orders with every blocking stream, which
   // is what callers that allocate and copy with plain hipMemcpy / torch's default stream expect.
   c.stream = (hipStream_t)hip_stream;

@@ -52,12 +52,6 @@ struct VoicedPred {
   const double* f0;
   __device__ bool operator()(int i) const { return f0[i] != 0.0; }
 };
-struct D4cRunPred {
-  const double* f0;
-  const double* ap0;
-  double threshold;
-  __device__ bool operator()(int i) const { return f0[i] != 0.0 && ap0[i] > threshold; }
-};
 
 // MODE 0: LoveTrain consumption 2*round(1.5 fs/max(f0,40))+1 for frames with f0 != 0
 //         (d4c.cpp:231-233, :272-278); writes per-utterance totals to utt_total.
@@ -84,7 +78,7 @@ __global__ __launch_bounds__(256) void d4c_offsets_kernel(const double* __restri
       if (MODE == 0) {
         if (v != 0.0) c = 2 * matlab_round(1.5 * fs / (v > 40.0 ? v : 40.0)) + 1;
       } else {
-        if (v != 0.0 && ap0[base + i] > threshold)
+        if (!(v == 0.0 || ap0[base + i] <= threshold))
           c = 3 * (2 * matlab_round(2.0 * fs / (v > kFloorF0D4C ? v : kFloorF0D4C)) + 1);
       }
     }
@@ -123,14 +117,15 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
   const int n_run = *n_listed;
   for (int64_t i = n_run + blockIdx.x * 64 + lane0; i < total_frames; i += (int64_t)gridDim.x * 64)
     ap0[perm[i]] = 0.0;                                     // f0 == 0 (d4c.cpp:231-233)
-  WM_FOR_EACH_LISTED(frame, perm, n_run) {
+  FramePipe pipe;
+  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    const int64_t frame = sc.frame;
     const int lane = opaque_lane(lane0);
-    const double f0v = f0[frame];
-    const int u = frame_utt[frame];
-    const double cf0 = f0v > 40.0 ? f0v : 40.0;
+    const double cf0 = uniform_d(sc.f0 > 40.0 ? sc.f0 : 40.0);
     cpx v[M];
-    const FrameGeom fg = frame_geom(fs, cf0, tpos[frame], 3.0);
-    frame_packed<kBlackman, false, M>(x + x_off[u], x_len[u], fg, rtab, rng_off[frame], lane, v);
+    const FrameGeom fg = frame_geom(fs, cf0, uniform_d(sc.tpos), 3.0);
+    frame_packed<kBlackman, false, M>(sc.xu, sc.xlen, fg, rtab, sc.roff, lane, v);
     rfft_forward<N>(v, img, img, tw, lane);
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -152,6 +147,19 @@ __global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
     if (lane == 0) ap0[frame] = s1 / s2;
     wave_sync();
   }
+}
+
+// D4CLoveTrain when the threshold is <= 0 (the recipe's setting, test/analysis.cpp:190).  Its ratio is used only
+// in `f0 == 0 || aperiodicity0 <= threshold -> skip` (d4c.cpp:380).  The ratio of two sums of squared magnitudes
+// is never negative, and it is zero only if every bin from 100 Hz to 4 kHz is exactly zero, which the 1e-12 randn
+// dither of the window (d4c.cpp:66-67) rules out; a NaN ratio (non-finite samples under the window) compares
+// false and does not skip either.  So for threshold <= 0 every frame with f0 != 0 is analysed whatever LoveTrain
+// computes, and its transform is not run: aperiodicity0 is set to 1 on those frames.  The randn draws LoveTrain
+// would have consumed are still accounted for by d4c_offsets_kernel<0>.
+__global__ __launch_bounds__(256) void d4c_lovetrain_all_pass_kernel(const double* __restrict__ f0, int64_t total_frames,
+                                                                     double* __restrict__ ap0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total_frames) ap0[i] = f0[i] != 0.0 ? 1.0 : 0.0;
 }
 
 // Descending sort of a[0..NS) in registers, NS a power of two: Batcher's odd-even merge sort.  All
@@ -298,17 +306,19 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       for (int i = lane0; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
     }
   }
-  WM_FOR_EACH_LISTED(frame, perm, n_run) {
+  FramePipe pipe;
+  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    const int64_t frame = sc.frame;
     const int lane = opaque_lane(lane0);
     const int fs = opaque_uniform(fs_arg), out_fft = opaque_uniform(out_fft_arg);   // nothing derived is hoisted
     double* row = ap + frame * (int64_t)out_bins;
-    const double f0v = f0[frame];
+    const double f0v = sc.f0;
     const double cf0 = uniform_d(f0v > kFloorF0D4C ? f0v : kFloorF0D4C);   // d4c.cpp:381
-    const int u = frame_utt[frame];
-    const double* xu = x + x_off[u];
-    const int xl = x_len[u];
-    const double pos = uniform_d(tpos[frame]);
-    const int roff = rng_off[frame];
+    const double* xu = sc.xu;
+    const int xl = sc.xlen;
+    const double pos = uniform_d(sc.tpos);
+    const int roff = sc.roff;
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
 
     // ---- GetStaticCentroid (d4c.cpp:125-142): two centroids at pos -/+ 0.25/f0 ----
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       low = wave_sum(low);
       double c = 10.0 * log10(low / tot);
       c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
-      c = c < 0.0 ? c : 0.0;
+      c = 0.0 < c ? 0.0 : c;                                // MyMinDouble(0.0, c), common.h:80: a NaN stays a NaN
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
@@ -501,7 +511,7 @@ struct D4cRunUsualPred {
   int fd, fs;
   __device__ bool operator()(int i) const {
     const double v = f0[i];
-    if (!(v != 0.0 && ap0[i] > threshold)) return false;
+    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
     return d4c_is_usual(v > kFloorF0D4C ? v : kFloorF0D4C, fd, fs);
   }
 };
@@ -512,7 +522,7 @@ struct D4cRunRarePred {
   int fd, fs;
   __device__ bool operator()(int i) const {
     const double v = f0[i];
-    if (!(v != 0.0 && ap0[i] > threshold)) return false;
+    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
     const double cf0 = v > kFloorF0D4C ? v : kFloorF0D4C;
     // beyond fd / 2 mirror bins the reference reads past its spectrum (common.cpp:62-68, :85-92): default row stays
     return !d4c_is_usual(cf0, fd, fs) && d4c_mirror_bins(cf0, fd, fs) <= fd / 2;
@@ -570,10 +580,16 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   } break;
   {
     TimedScope ts_(b.ctx, "d4c_lovetrain_kernel");
-    switch (FL) {
-      WM_LT_CASE(1024)
-      WM_LT_CASE(2048)
-      WM_LT_CASE(4096)
+    if (b.p.d4c_threshold <= 0.0) {
+      // every voiced frame passes whatever the ratio is: see d4c_lovetrain_all_pass_kernel
+      hipLaunchKernelGGL(d4c_lovetrain_all_pass_kernel, dim3((unsigned)((tf + 255) / 256)), dim3(256), 0, st, d_f0, tf,
+                         b.d_ap0);
+    } else {
+      switch (FL) {
+        WM_LT_CASE(1024)
+        WM_LT_CASE(2048)
+        WM_LT_CASE(4096)
+      }
     }
   }
 #undef WM_LT_CASE

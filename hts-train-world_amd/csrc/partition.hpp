@@ -101,4 +101,90 @@ __device__ __forceinline__ int64_t listed_at(const int* __restrict__ perm, int64
        base_ < (int64_t)(count); base_ += gridDim.x, frame = nxt_)                                        \
     if ((nxt_ = listed_at((perm), xcd_dealt(base_ + gridDim.x, (count)), (count))), frame >= 0)
 
+// Per-frame scalars of the analysis kernels, fetched AHEAD through a three-stage pipeline.  A frame starts with a
+// chain of dependent loads -- list entry -> frame -> (f0, position, utterance, randn offset) -> utterance base and
+// length -> samples -- and at one or two resident waves per SIMD nothing hides those round trips (LoveTrain spent a
+// third of its time in them).  Requesting the whole chain one frame ahead does not help: the dependent scalar
+// loads need a wait between them, and the wave would sit through the chain at the top of every body.  So every
+// level of the chain belongs to a different future frame and each iteration advances all levels by one load each:
+//     frame k+3: its list entry is requested
+//     frame k+2: its entry has arrived (requested one iteration ago) -> f0, position, utterance, offset requested
+//     frame k+1: its utterance has arrived -> the utterance's base and length requested
+//     frame k  : everything is in registers
+// Every value is consumed one iteration after its request; the sample loads of a frame are the only round trip
+// left on its critical path.
+struct FrameScalars {
+  int64_t frame;        // -1 beyond the end of the list
+  double f0, tpos;
+  const double* xu;     // the utterance's samples
+  int xlen, roff;
+};
+struct FramePipe {
+  const int* perm;
+  int64_t count;
+  const double *x, *tpos, *f0;
+  const int64_t* x_off;
+  const int *x_len, *frame_utt, *rng_off;
+  int64_t base;                       // list position (before dealing) of stage 0
+  // stage 3: list entry; stage 2: + per-frame scalars; stage 1: + utterance base / length
+  int raw3;                           // list entry as loaded (valid only if ok3): not looked at until the next step,
+  bool ok3;                           // so that its load is not waited for in the iteration that issued it
+  int64_t fr2, fr1;
+  double f0_2, tp_2, f0_1, tp_1;
+  int utt_2, ro_2, ro_1, xl_1;
+  int64_t xo_1;
+  __device__ __forceinline__ void request_entry(int64_t b) {
+    const int64_t pos = xcd_dealt(b, count);
+    ok3 = pos < count;
+    raw3 = perm[ok3 ? pos : 0];         // unconditional load (clamped), no select on the value here
+  }
+  __device__ __forceinline__ int64_t entry3() const {
+    return ok3 ? (int64_t)__builtin_amdgcn_readfirstlane(raw3) : -1;
+  }
+  __device__ __forceinline__ void scalars(int64_t fr, double& a, double& t, int& u, int& r) const {
+    const int64_t i = fr < 0 ? 0 : fr;          // beyond the list: a harmless reload of frame 0
+    a = f0[i]; t = tpos[i]; u = frame_utt[i]; r = rng_off[i];
+  }
+  __device__ __forceinline__ void init(const int* perm_, int64_t count_, const double* x_, const int64_t* x_off_,
+                                       const int* x_len_, const int* frame_utt_, const double* tpos_,
+                                       const double* f0_, const int* rng_off_) {
+    perm = perm_; count = count_; x = x_; x_off = x_off_; x_len = x_len_; frame_utt = frame_utt_;
+    tpos = tpos_; f0 = f0_; rng_off = rng_off_;
+    base = 0;
+    // fill: frames of rounds 0, 1, 2 (blocking, once per kernel)
+    request_entry(0);
+    fr1 = entry3();
+    request_entry((int64_t)gridDim.x);
+    fr2 = entry3();
+    request_entry(2 * (int64_t)gridDim.x);
+    int u1;
+    scalars(fr1, f0_1, tp_1, u1, ro_1);
+    xo_1 = x_off[u1];
+    xl_1 = x_len[u1];
+    scalars(fr2, f0_2, tp_2, utt_2, ro_2);
+  }
+  // the scalars of the frame of round `base`, and one step of every stage
+  __device__ __forceinline__ FrameScalars next() {
+    FrameScalars c;
+    c.frame = fr1; c.f0 = f0_1; c.tpos = tp_1; c.xu = x + xo_1; c.xlen = xl_1; c.roff = ro_1;
+    const int64_t e3 = entry3();        // arrived: requested one step ago
+    // new stage 3 first: its destination is then not behind this step's other requests
+    request_entry(base + 3 * (int64_t)gridDim.x);
+    base += gridDim.x;
+    // stage 2 -> 1: the utterance of the frame after this one is known by now
+    fr1 = fr2; f0_1 = f0_2; tp_1 = tp_2; ro_1 = ro_2;
+    xo_1 = x_off[utt_2];
+    xl_1 = x_len[utt_2];
+    // stage 3 -> 2
+    fr2 = e3;
+    scalars(fr2, f0_2, tp_2, utt_2, ro_2);
+    return c;
+  }
+};
+// for-loop header: `sc` is the FrameScalars of the current frame; frames beyond the list are skipped
+#define WM_FOR_EACH_PIPED(sc, pipe, count)                                                                   \
+  for (int64_t base_ = 0; base_ < (int64_t)(count); base_ += gridDim.x)                                      \
+    for (FrameScalars sc = (pipe).next(), *once_ = &sc; once_; once_ = nullptr)                              \
+      if (sc.frame >= 0)
+
 }  // namespace wm

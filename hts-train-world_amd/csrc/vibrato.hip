@@ -16,8 +16,9 @@
 //                       AFTER the run's own frames -- the script appends to a list that already holds `length`
 //                       zero pairs, :148,150 -- and a later run overwrites an earlier run's spill-over), soprLog
 //
-// PARITY UNPINNED (oracle/world_oracle_vibrato.c has the reasons: no fixtures, statsmodels not installed and not
-// pinned by the reference).  What is tested is this file against that CPU restatement of the same reading.
+// PARITY UNPINNED: the reference holds no fixtures for this script, statsmodels is neither installed here nor
+// pinned by the reference (DESIGN.md has the details).  What the tests compare this file with is a CPU restatement
+// of the same reading of the script and of the published LOWESS algorithm.
 // Limits: a run of more than kVibMaxRun frames (15 s of unbroken voicing at a 5 ms hop) is left without vibrato
 // and counted in the status word.
 #include <math.h>

@@ -168,7 +168,7 @@ void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_sample
  * lf0_out [total_frames][2] = log f0, log(f0 - pitch + 500) -- what the script writes back over the lf0 file.
  * *n_too_long (may be NULL): voiced runs longer than 3072 frames, left without vibrato.  Synchronises the stream.
  * Parity of this entry point is UNPINNED: the reference holds no fixtures for it and its LOWESS is an unpinned
- * third-party dependency (statsmodels); see oracle/world_oracle_vibrato.c. */
+ * third-party dependency (statsmodels); DESIGN.md section 4. */
 int WorldMi355Vibrato(WorldMi355Batch* b, const float* lf0, const int* seg_utt_off, const int* seg_start,
                       const int* seg_end, const double* seg_pitch, float* vib, float* lf0_out, int* n_too_long);
 

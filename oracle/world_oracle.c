@@ -765,7 +765,7 @@ static void d4c_frame(const double *x, int x_length, int fs, double f0, int n,
   }
   for (int b = 0; b < nap; ++b) {                              /* :309-311 */
     double v = coarse[b] + (f0 - 100) / 50.0;
-    coarse[b] = v < 0.0 ? v : 0.0;
+    coarse[b] = 0.0 < v ? 0.0 : v;                             /* MyMinDouble(0.0, v), common.h:80: a NaN stays */
   }
   free(c1); free(c2); free(sc); free(wave); free(re); free(im); free(pw); free(gd); free(sg);
 }

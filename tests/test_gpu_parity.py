@@ -348,6 +348,32 @@ def test_d4c_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
     np.testing.assert_array_equal(got2, got)
 
 
+@pytest.mark.parametrize("thr", [0.0, -1.0])
+def test_d4c_threshold_zero_with_bad_samples(gpu, oracle, thr):
+    """With a threshold <= 0 D4CLoveTrain cannot skip a voiced frame (its ratio is >= 0, zero is ruled out by the
+    window's dither, and a NaN ratio does not satisfy `<= threshold`, d4c.cpp:380), so the library does not run its
+    transform (d4c_lovetrain_all_pass_kernel).  Same rows as the reference's arithmetic, also around NaN / Inf
+    samples, where that ratio is NaN and the rows are NaN as well."""
+    torch, W, ctx = gpu
+    fs = 16000
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    x = sd.make_utterance(95, fs, duration=0.8).copy()
+    x[4000] = np.nan
+    x[8000:8003] = np.inf
+    x[11000] = -np.inf
+    t, _ = oracle.dio(np.nan_to_num(x, posinf=0.0, neginf=0.0), fs)
+    f0 = np.full(len(t), 170.0)
+    f0[::9] = 0.0
+    f0[3::9] = 45.0                  # LoveTrain's 3-period window at max(f0, 40) is then wider than the body's frames
+    want = oracle.d4c(x, fs, t, f0, 1024, thr)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, d4c_threshold=thr), x_lengths=[len(x)])
+    got = b.d4c(dev(x), dev(t), dev(f0)).cpu().numpy()
+    b.close()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(want).any() and (want == 1.0 - 1e-12).all(axis=1).sum() >= len(t) // 9     # both kinds of rows occur
+    np.testing.assert_allclose(got, want, atol=AP_TOL, rtol=0, equal_nan=True)
+
+
 def test_long_utterance_at_1ms_hop(gpu, oracle):
     """21 s at a 1 ms hop = 21 001 frames: the contour fix's edge lists (2 x (T / 2 + 2) ints) no longer fit the
     48 KB of LDS they use for ordinary lengths and move to global memory (dio.hip, dio_fix_kernel<false>)."""
