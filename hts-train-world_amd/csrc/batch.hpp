@@ -107,6 +107,7 @@ struct Batch {
   double* d_dio_win = nullptr;       // Nuttall low-pass windows, all bands
   int* d_dio_fft = nullptr;          // [n_utt] the reference's fft_size (circular indexing)
   double* d_dio_ws = nullptr;        // [3][total_f] contour work arrays
+  void* d_dio_H = nullptr;           // filter spectra of the FFT-convolution path (fftconv.hpp)
   int* d_dio_edges = nullptr;        // [n_utt][2][edge_cap] edge lists of the contour fix when they outgrow LDS
   int* d_dio_ylen = nullptr;         // [n_utt] y_length = 1 + N / speed
   double* d_dio_y = nullptr;         // decimated signals (speed > 1)

@@ -20,6 +20,7 @@
 #include "batch.hpp"
 #include "common.hpp"
 #include "decimate.hpp"
+#include "fftconv.hpp"
 #include "zcfilter.hpp"
 
 namespace wm {
@@ -35,7 +36,12 @@ struct DioMeta {
   int pad;                      // 2 * hal[0]: how far the low-cut output is needed outside [0, y_len)
   int ratio;                    // decimation ratio (only 1 is implemented on device)
   double afs;                   // actual_fs
+  int step;                     // outputs per tile of the band filters (tiles overlap by 2 samples of look-ahead)
+  int band_conv;                // block size of the FFT convolution of the band filters (fftconv.hpp); 0: direct FIR
+  int lc_conv;                  // same for the low-cut filter
 };
+__host__ __device__ inline int dio_tiles(int ylen, int step) { return (ylen + step - 1) / step; }
+constexpr int kDioConvC = 28;   // samples per lane of a block's event passes: a block's step is at most 64 * 28
 
 // src is x itself (speed 1: y_length = N + 1, the extra sample is zero) or the decimated signal
 // (speed > 1: all y_length samples materialised, zeros beyond decimate's output).
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void dio_band_kernel(
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int u = blockIdx.z, band = blockIdx.y, tile = blockIdx.x;
   const int ylen = ylen_a[u];
-  const int nt = zc_tiles(ylen);
+  const int nt = dio_tiles(ylen, meta.step);
   if (tile >= nt) return;
   const int hal = meta.hal[band];
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
@@ -137,12 +143,105 @@ __global__ __launch_bounds__(256) void dio_band_kernel(
                              slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, lds);
 }
 
+// ---- the same two stages by block FFT convolution (fftconv.hpp): one wavefront per block ---------------------
+// z storage index m0 + i <-> signal index m0 + i - pad; z[m] = sum_k h[k] y[(m - pad) + cut - k], k < 2 cut + 1.
+template <int B>
+__global__ __launch_bounds__(64) void dio_lowcut_fft_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ ylen_a, const double* __restrict__ mean, const int* __restrict__ fft_sizes,
+    const cpx* __restrict__ H, DioMeta meta, const int64_t* __restrict__ z_off, double* __restrict__ z) {
+  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M;
+  __shared__ __attribute__((aligned(16))) double smem[ConvCfg<B>::kImg];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int u = blockIdx.y, lane = threadIdx.x;
+  const int n = x_len[u], ylen = ylen_a[u], fftn = fft_sizes[u];
+  const int ntap = 2 * meta.cut + 1, V = B - ntap + 1;
+  const int total = ylen + 2 * meta.pad;
+  const int m0 = blockIdx.x * V;
+  if (m0 >= total) return;
+  FftTw<N> tw;
+  tw.init(lane);
+  const double* xu = x + x_off[u];
+  const double mu = mean[u];
+  const int base = m0 - meta.pad + meta.cut - (ntap - 1);        // block element i is y[base + i]
+  cpx v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = base + 2 * (lane + 64 * m);
+    v[m] = make_double2(dio_y(xu, n, ylen, fftn, mu, i0), dio_y(xu, n, ylen, fftn, mu, i0 + 1));
+  }
+  cpx zr[M + 1];
+  conv_forward<B>(v, img, tw, lane, zr);
+  conv_apply<B>(zr, H, img, tw, lane, v);
+  double* zu = z + z_off[u];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int j = 2 * (lane + 64 * m);
+    const int a = m0 + j - (ntap - 1);                             // storage index of out[j]
+    if (j >= ntap - 1 && a < total) zu[a] = v[m].x;
+    if (j + 1 >= ntap - 1 && a + 1 < total) zu[a + 1] = v[m].y;
+  }
+}
+
+// One wavefront per (block, utterance): the block's spectrum once, then per band the product with the band's
+// (delayed) Nuttall spectrum, the inverse transform and the four zero-crossing passes.  All bands share
+// ntap0 = 4 hal[0], bias0 = 2 hal[0]: band b's window is delayed by 2 (hal[0] - hal[b]) samples.
+template <int B>
+__global__ __launch_bounds__(64, 2) void dio_band_fft_kernel(
+    const int* __restrict__ ylen_a, const int64_t* __restrict__ z_off, const double* __restrict__ z,
+    const cpx* __restrict__ H, DioMeta meta, int tiles_max, int* __restrict__ tile_cnt,
+    const int64_t* __restrict__ slot_off, double* __restrict__ slots) {
+  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  cpx* img = reinterpret_cast<cpx*>(lds);
+  double* s = lds;                                               // the filtered block, after the inverse transform
+  unsigned short* lists = reinterpret_cast<unsigned short*>(lds + ConvCfg<B>::kImg);
+  const int u = blockIdx.y, tile = blockIdx.x, lane_k = threadIdx.x, lane = lane_k;
+  const int ylen = ylen_a[u];
+  const int nt = dio_tiles(ylen, meta.step);
+  if (tile >= nt) return;
+  FftTw<N> tw;
+  tw.init(lane);
+  const int ntap0 = 4 * meta.hal[0], bias0 = 2 * meta.hal[0];
+  const int n0 = tile * meta.step;
+  const int base = n0 + bias0 - (ntap0 - 1);                     // block element i is sig[base + i]
+  const double* zu = z + z_off[u] + meta.pad;                    // sig[m], valid for m in [-pad, ylen + pad)
+  const int lo = -meta.pad, hi = ylen + meta.pad;
+  cpx v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = base + 2 * (lane + 64 * m), i1 = i0 + 1;
+    const double a = zu[imin(hi - 1, imax(lo, i0))], c = zu[imin(hi - 1, imax(lo, i1))];
+    v[m] = make_double2(i0 >= lo && i0 < hi ? a : 0.0, i1 >= lo && i1 < hi ? c : 0.0);
+  }
+  cpx zr[M + 1];
+  conv_forward<B>(v, img, tw, lane, zr);
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+#pragma unroll 1
+  for (int band = 0; band < meta.nb; ++band) {
+    const int lane = opaque_lane(lane_k);                        // nothing lane-derived is carried across the bands
+    tw.fence();
+    conv_apply<B>(zr, H + (int64_t)band * (N + 1), img, tw, lane, v);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int j = 2 * (lane + 64 * m) - (ntap0 - 1);
+      if (j >= 0) s[j] = v[m].x;
+      if (j + 1 >= 0) s[j + 1] = v[m].y;
+    }
+    wave_sync();
+    conv_block_events<kDioConvC>(s, n0, meta.step, ylen, tile, lists, ConvCfg<B>::kListCap,
+                      tile_cnt + (((int64_t)u * meta.nb + band) * (tiles_max + 1) + tile) * 4,
+                      slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, lane);
+  }
+}
+
 __global__ __launch_bounds__(64) void dio_band_scan_kernel(const int* __restrict__ ylen_a, DioMeta meta,
                                                            int tiles_max, int* __restrict__ tile_cnt,
                                                            int* __restrict__ ev_cnt) {
   const int u = blockIdx.y, band = blockIdx.x;
   const int ylen = ylen_a[u];
-  zc_scan_tiles(tile_cnt + ((int64_t)u * meta.nb + band) * (tiles_max + 1) * 4, zc_tiles(ylen), ylen / 2 + 2,
+  zc_scan_tiles(tile_cnt + ((int64_t)u * meta.nb + band) * (tiles_max + 1) * 4, dio_tiles(ylen, meta.step), ylen / 2 + 2,
                 ev_cnt + ((int64_t)u * meta.nb + band) * 4, threadIdx.x);
 }
 
@@ -152,7 +251,7 @@ __global__ __launch_bounds__(256) void dio_band_compact_kernel(
     double* __restrict__ events) {
   const int u = blockIdx.z, band = blockIdx.y, tile = blockIdx.x;
   const int ylen = ylen_a[u];
-  const int nt = zc_tiles(ylen);
+  const int nt = dio_tiles(ylen, meta.step);
   if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
@@ -378,7 +477,7 @@ static void dio_release(Batch& b) {
                    (void**)&b.d_dio_mean, (void**)&b.d_dio_mean_part, (void**)&b.d_dio_y, (void**)&b.d_dio_tmp,
                    (void**)&b.d_dio_z, (void**)&b.d_dio_events, (void**)&b.d_dio_ev_cnt, (void**)&b.d_dio_tile_cnt,
                    (void**)&b.d_dio_slot_off, (void**)&b.d_dio_slots, (void**)&b.d_dio_cand, (void**)&b.d_dio_score,
-                   (void**)&b.d_dio_ws};
+                   (void**)&b.d_dio_ws, (void**)&b.d_dio_H};
   for (void** p : ptrs) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -403,6 +502,10 @@ static int dio_setup(Batch& b) {
   }
   m.pad = 2 * m.hal[0];
   m.cut = matlab_round(m.afs / 50.0);                                                  // :86
+  // block FFT convolution where the filters fit a block comfortably (fftconv.hpp), the direct FIR otherwise
+  m.band_conv = 4 * m.hal[0] <= 1024 ? 2048 : 0;
+  m.lc_conv = 2 * m.cut + 1 <= 1024 ? 2048 : (2 * m.cut + 1 <= 3072 ? 4096 : 0);
+  m.step = m.band_conv ? imin(m.band_conv - 4 * m.hal[0] + 1 - 2, 64 * kDioConvC) : kZcStep;
   // Nuttall low-pass windows (dio.cpp:301, common.cpp:113-121)
   H->win.resize((size_t)woff);
   for (int i = 0; i < m.nb; ++i) {
@@ -471,17 +574,52 @@ static int dio_setup(Batch& b) {
   al((void**)&b.d_dio_events, sizeof(double) * (size_t)b.dio_ev_off[(size_t)b.n_utt]);
   al((void**)&b.d_dio_ev_cnt, sizeof(int) * (size_t)b.n_utt * m.nb * 4);
   al((void**)&b.d_dio_tile_cnt,
-     sizeof(int) * (size_t)b.n_utt * m.nb * 4 * ((size_t)zc_tiles(b.max_x_len / m.ratio + 1) + 1));
+     sizeof(int) * (size_t)b.n_utt * m.nb * 4 * ((size_t)dio_tiles(b.max_x_len / m.ratio + 1, m.step) + 1));
   {
     std::vector<int64_t> soff((size_t)b.n_utt + 1, 0);
     for (int u = 0; u < b.n_utt; ++u)
-      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nb * 4 * zc_tiles(ylens[(size_t)u]) * kZcSlot;
+      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nb * 4 * dio_tiles(ylens[(size_t)u], m.step) * kZcSlot;
     up((void**)&b.d_dio_slot_off, soff.data(), sizeof(int64_t) * soff.size());
     al((void**)&b.d_dio_slots, sizeof(double) * (size_t)soff[(size_t)b.n_utt]);
   }
   al((void**)&b.d_dio_cand, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_score, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_ws, sizeof(double) * 3 * (size_t)b.total_f);
+  // filter spectra of the FFT-convolution path: [0] low-cut (block lc_conv), [1 .. nb] bands (block band_conv)
+  if (!rc && (m.band_conv || m.lc_conv)) {
+    const size_t n_lc = m.lc_conv ? (size_t)m.lc_conv / 2 + 1 : 0, n_bd = m.band_conv ? (size_t)m.band_conv / 2 + 1 : 0;
+    al((void**)&b.d_dio_H, sizeof(cpx) * (n_lc + (size_t)m.nb * n_bd));
+    std::vector<int> off((size_t)m.nb + 1), nt((size_t)m.nb + 1), dl((size_t)m.nb + 1);
+    off[0] = 0; nt[0] = 2 * m.cut + 1; dl[0] = 0;
+    for (int i = 0; i < m.nb; ++i) {
+      off[(size_t)i + 1] = m.win_off[i];
+      nt[(size_t)i + 1] = 4 * m.hal[i];
+      dl[(size_t)i + 1] = 2 * (m.hal[0] - m.hal[i]);
+    }
+    int* d_desc = nullptr;
+    std::vector<int> desc;
+    desc.insert(desc.end(), off.begin(), off.end());
+    desc.insert(desc.end(), nt.begin(), nt.end());
+    desc.insert(desc.end(), dl.begin(), dl.end());
+    up((void**)&d_desc, desc.data(), sizeof(int) * desc.size());
+    if (!rc) {
+      const int n1 = m.nb + 1;
+      cpx* H = (cpx*)b.d_dio_H;
+      hipStream_t st = b.ctx->stream;
+      if (m.lc_conv == 2048)
+        hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(1), dim3(64), 0, st, b.d_dio_lowcut, d_desc, d_desc + n1,
+                           d_desc + 2 * n1, H);
+      else if (m.lc_conv == 4096)
+        hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(1), dim3(64), 0, st, b.d_dio_lowcut, d_desc, d_desc + n1,
+                           d_desc + 2 * n1, H);
+      if (m.band_conv)
+        hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(m.nb), dim3(64), 0, st, b.d_dio_win, d_desc + 1,
+                           d_desc + n1 + 1, d_desc + 2 * n1 + 1, H + n_lc);
+      rc = wm_check(hipGetLastError());
+      if (!rc) rc = wm_check(hipStreamSynchronize(st));
+    }
+    if (d_desc) (void)hipFree(d_desc);
+  }
   if (rc) {
     // nothing half-built stays behind: a retry starts from scratch instead of leaking H and the buffers above
     dio_release(b);
@@ -528,7 +666,16 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     if (!small && ntap > zc_max_taps<kZcStrideLong>()) return WM_ERR_UNSUPPORTED;
     const size_t lds = sizeof(double) * (size_t)((small ? kZcStrideHarvest : kZcStrideLong) * kBandK + zc_pad16(ntap));
     TimedScope ts_(b.ctx, "dio_lowcut_kernel");
-    if (small)
+    if (m.lc_conv) {
+      const int V = m.lc_conv - ntap + 1;
+      const dim3 grid((total_max + V - 1) / V, b.n_utt);
+      if (m.lc_conv == 2048)
+        hipLaunchKernelGGL(dio_lowcut_fft_kernel<2048>, grid, dim3(64), 0, st, src, src_off, src_len, b.d_dio_ylen,
+                           b.d_dio_mean, b.d_dio_fft, (const cpx*)b.d_dio_H, m, b.d_dio_z_off, b.d_dio_z);
+      else
+        hipLaunchKernelGGL(dio_lowcut_fft_kernel<4096>, grid, dim3(64), 0, st, src, src_off, src_len, b.d_dio_ylen,
+                           b.d_dio_mean, b.d_dio_fft, (const cpx*)b.d_dio_H, m, b.d_dio_z_off, b.d_dio_z);
+    } else if (small)
       hipLaunchKernelGGL(dio_lowcut_kernel<kZcStrideHarvest>, dim3(tiles, b.n_utt), dim3(256), lds, st, src, src_off,
                          src_len, b.d_dio_ylen, b.d_dio_mean, b.d_dio_fft, b.d_dio_lowcut, m, b.d_dio_z_off,
                          b.d_dio_z);
@@ -544,9 +691,18 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     if (!small && ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
     const size_t lds = sizeof(double) * (size_t)(small ? zc_lds_doubles<kZcStrideDio>(ntap_max)
                                                        : zc_lds_doubles<kZcStrideHarvest>(ntap_max));
-    const int tiles_max = zc_tiles(b.max_x_len / m.ratio + 1);
+    const int tiles_max = dio_tiles(b.max_x_len / m.ratio + 1, m.step);
     TimedScope ts_(b.ctx, "dio_band_kernel");
-    if (small)
+    if (m.band_conv) {
+      const cpx* Hb = (const cpx*)b.d_dio_H + (m.lc_conv ? m.lc_conv / 2 + 1 : 0);
+      static const bool attr_ = (hipFuncSetAttribute((const void*)dio_band_fft_kernel<2048>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)ConvCfg<2048>::kLdsBytes) == hipSuccess);
+      (void)attr_;
+      hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), ConvCfg<2048>::kLdsBytes, st,
+                         b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
+                         b.d_dio_slots);
+    } else if (small)
       hipLaunchKernelGGL((dio_band_kernel<kZcStrideDio>), dim3(tiles_max, m.nb, b.n_utt), dim3(256), lds, st,
                          b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, b.d_dio_win, m, tiles_max, b.d_dio_tile_cnt,
                          b.d_dio_slot_off, b.d_dio_slots);
