@@ -29,6 +29,7 @@
 #include "common.hpp"
 #include "decimate.hpp"
 #include "fft.hpp"
+#include "fftconv.hpp"
 #include "zcfilter.hpp"
 
 namespace wm {
@@ -43,7 +44,13 @@ struct HvMeta {
   int cpf;          // candidates per frame before overlap = matlab_round(nch / 10.0)
   int maxc;         // max_candidates = cpf * 7 (:1180-1181)
   int ntap_max;
+  int step;         // outputs per tile of the filter bank (tiles overlap by 2 samples of look-ahead)
+  int conv;         // block size of the FFT convolution of the filter bank (fftconv.hpp); 0: direct FIR
+  int half0;        // largest half window length: every channel is delayed to ntap0 = 2 half0 + 1, bias0 = half0 + 1
 };
+__host__ __device__ inline int hv_tiles(int ylen, int step) { return (ylen + step - 1) / step; }
+constexpr int kHvConvC = 28;        // samples per lane of a block's event passes
+constexpr int kHvChGroup = 19;      // channels per wavefront of the FFT filter bank (152 = 8 x 19)
 
 struct HarvestWs {
   HvMeta m;
@@ -58,6 +65,7 @@ struct HarvestWs {
   double* d_y = nullptr; double* d_tmp = nullptr;
   double* d_events = nullptr; int* d_evcnt = nullptr;
   int* d_tile_cnt = nullptr; int tiles_max = 0;
+  void* d_H = nullptr;                         // channel spectra of the FFT filter bank
   double* d_slots = nullptr; int64_t* d_slot_off = nullptr;
   double* d_raw = nullptr; double* d_offc = nullptr; int* d_cnt = nullptr; int* d_ncand1 = nullptr;
   double *d_rc = nullptr, *d_rs = nullptr, *d_rc2 = nullptr, *d_rs2 = nullptr;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256) void hv_band_kernel(const int64_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int u = blockIdx.z, ch = blockIdx.y, tile = blockIdx.x;
   const int ylen = ylen_a[u];
-  const int nt = zc_tiles(ylen);
+  const int nt = hv_tiles(ylen, kZcStep);
   if (tile >= nt) return;
   const int hf = half[ch];
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
@@ -118,21 +126,76 @@ __global__ __launch_bounds__(256) void hv_band_kernel(const int64_t* __restrict_
                                        slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, lds);
 }
 
-__global__ __launch_bounds__(64) void hv_band_scan_kernel(const int* __restrict__ ylen_a, int nch, int tiles_max,
+// The same filter bank by block FFT convolution (fftconv.hpp): one wavefront per (block, channel group,
+// utterance) transforms the block once and applies the group's channels one after another.
+template <int B>
+__global__ __launch_bounds__(64, 2) void hv_band_fft_kernel(const int64_t* __restrict__ yoff,
+                                                            const int* __restrict__ ylen_a,
+                                                            const double* __restrict__ y, const cpx* __restrict__ H,
+                                                            int nch, int half0, int step, int tiles_max,
+                                                            int* __restrict__ tile_cnt,
+                                                            const int64_t* __restrict__ slot_off,
+                                                            double* __restrict__ slots) {
+  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  cpx* img = reinterpret_cast<cpx*>(lds);
+  double* s = lds;
+  unsigned short* lists = reinterpret_cast<unsigned short*>(lds + ConvCfg<B>::kImg);
+  const int u = blockIdx.z, grp = blockIdx.y, tile = blockIdx.x, lane_k = threadIdx.x, lane = lane_k;
+  const int ylen = ylen_a[u];
+  const int nt = hv_tiles(ylen, step);
+  if (tile >= nt) return;
+  FftTw<N> tw;
+  tw.init(lane);
+  const int ntap0 = 2 * half0 + 1, bias0 = half0 + 1;
+  const int n0 = tile * step;
+  const int base = n0 + bias0 - (ntap0 - 1);                     // block element i is y[base + i], zero outside
+  const double* yu = y + yoff[u];
+  cpx v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = base + 2 * (lane + 64 * m), i1 = i0 + 1;
+    const double a = yu[imin(ylen - 1, imax(0, i0))], c = yu[imin(ylen - 1, imax(0, i1))];
+    v[m] = make_double2(i0 >= 0 && i0 < ylen ? a : 0.0, i1 >= 0 && i1 < ylen ? c : 0.0);
+  }
+  cpx zr[M + 1];
+  conv_forward<B>(v, img, tw, lane, zr);
+  const int64_t slot_cap = (int64_t)nt * kZcSlot;
+  const int ch_end = imin(nch, (grp + 1) * kHvChGroup);
+#pragma unroll 1
+  for (int ch = grp * kHvChGroup; ch < ch_end; ++ch) {
+    const int lane = opaque_lane(lane_k);
+    tw.fence();
+    conv_apply<B>(zr, H + (int64_t)ch * (N + 1), img, tw, lane, v);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int j = 2 * (lane + 64 * m) - (ntap0 - 1);
+      if (j >= 0) s[j] = v[m].x;
+      if (j + 1 >= 0) s[j + 1] = v[m].y;
+    }
+    wave_sync();
+    conv_block_events<kHvConvC>(s, n0, step, ylen, tile, lists, ConvCfg<B>::kListCap,
+                                tile_cnt + (((int64_t)u * nch + ch) * (tiles_max + 1) + tile) * 4,
+                                slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, lane);
+  }
+}
+
+__global__ __launch_bounds__(64) void hv_band_scan_kernel(const int* __restrict__ ylen_a, int nch, int step, int tiles_max,
                                                           int* __restrict__ tile_cnt, int* __restrict__ evcnt) {
   const int u = blockIdx.y, ch = blockIdx.x;
   const int ylen = ylen_a[u];
-  zc_scan_tiles(tile_cnt + ((int64_t)u * nch + ch) * (tiles_max + 1) * 4, zc_tiles(ylen), ylen / 2 + 2,
+  zc_scan_tiles(tile_cnt + ((int64_t)u * nch + ch) * (tiles_max + 1) * 4, hv_tiles(ylen, step), ylen / 2 + 2,
                 evcnt + ((int64_t)u * nch + ch) * 4, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void hv_band_compact_kernel(
-    const int* __restrict__ ylen_a, int nch, int tiles_max, const int* __restrict__ tile_cnt,
+    const int* __restrict__ ylen_a, int nch, int step, int tiles_max, const int* __restrict__ tile_cnt,
     const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ evoff,
     double* __restrict__ events) {
   const int u = blockIdx.z, ch = blockIdx.y, tile = blockIdx.x;
   const int ylen = ylen_a[u];
-  const int nt = zc_tiles(ylen);
+  const int nt = hv_tiles(ylen, step);
   if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
@@ -1030,6 +1093,9 @@ static int hv_setup(Batch& b) {
     }
     m.ntap_max = imax(m.ntap_max, n);
   }
+  m.half0 = (m.ntap_max - 1) / 2;
+  m.conv = m.ntap_max <= 1024 ? 2048 : 0;        // block FFT convolution where the longest filter fits half a block
+  m.step = m.conv ? imin(m.conv - m.ntap_max + 1 - 2, 64 * kHvConvC) : kZcStep;
   const int n_utt = b.n_utt;
   W->ylen.resize((size_t)n_utt); W->nb1.resize((size_t)n_utt);
   W->yoff.assign((size_t)n_utt + 1, 0); W->toff.assign((size_t)n_utt + 1, 0); W->evoff.assign((size_t)n_utt + 1, 0);
@@ -1084,13 +1150,13 @@ static int hv_setup(Batch& b) {
   {
     int ymax = 1;
     for (int u = 0; u < n_utt; ++u) ymax = imax(ymax, W->ylen[(size_t)u]);
-    W->tiles_max = zc_tiles(ymax);
+    W->tiles_max = hv_tiles(ymax, m.step);
   }
   al((void**)&W->d_tile_cnt, sizeof(int) * (size_t)n_utt * m.nch * 4 * ((size_t)W->tiles_max + 1));
   {
     std::vector<int64_t> soff((size_t)n_utt + 1, 0);
     for (int u = 0; u < n_utt; ++u)
-      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nch * 4 * zc_tiles(W->ylen[(size_t)u]) * kZcSlot;
+      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nch * 4 * hv_tiles(W->ylen[(size_t)u], m.step) * kZcSlot;
     up((void**)&W->d_slot_off, soff.data(), sizeof(int64_t) * soff.size());
     al((void**)&W->d_slots, sizeof(double) * (size_t)soff[(size_t)n_utt]);
   }
@@ -1111,6 +1177,24 @@ static int hv_setup(Batch& b) {
   if (!rc) {
     hipLaunchKernelGGL(hv_twiddle_kernel, dim3(kHvTwid / 256), dim3(256), 0, b.ctx->stream, W->d_twid);
     rc = wm_check(hipGetLastError());
+  }
+  if (!rc && m.conv) {
+    // channel spectra of the FFT filter bank: channel i delayed by half0 - half[i] samples
+    std::vector<int> nt((size_t)m.nch), dl((size_t)m.nch);
+    for (int i = 0; i < m.nch; ++i) {
+      nt[(size_t)i] = 2 * half[(size_t)i] + 1;
+      dl[(size_t)i] = m.half0 - half[(size_t)i];
+    }
+    int *d_nt = nullptr, *d_dl = nullptr;
+    up((void**)&d_nt, nt.data(), sizeof(int) * nt.size());
+    up((void**)&d_dl, dl.data(), sizeof(int) * dl.size());
+    al((void**)&W->d_H, sizeof(cpx) * (size_t)m.nch * ((size_t)m.conv / 2 + 1));
+    if (!rc) {
+      hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(m.nch), dim3(64), 0, b.ctx->stream, W->d_taps, W->d_tapoff,
+                         d_nt, d_dl, (cpx*)W->d_H);
+      rc = wm_check(hipGetLastError());
+      if (!rc) rc = wm_check(hipStreamSynchronize(b.ctx->stream));
+    }
   }
   if (rc) {
     harvest_free(W);
@@ -1152,15 +1236,26 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   hipLaunchKernelGGL(hv_mean_kernel, dim3(n_utt), dim3(256), 0, st, W.d_yoff, W.d_ylen, W.d_y);
   {
     TimedScope ts_(b.ctx, "hv_band_kernel");
-    const size_t lds = sizeof(double) * (size_t)zc_lds_doubles<kZcStrideHarvest>(m.ntap_max);
-    if (m.ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(hv_band_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), lds, st, W.d_yoff, W.d_ylen,
-                       W.d_y, W.d_taps, W.d_tapoff, W.d_half, m.nch, W.tiles_max, W.d_tile_cnt, W.d_slot_off,
-                       W.d_slots);
-    hipLaunchKernelGGL(hv_band_scan_kernel, dim3(m.nch, n_utt), dim3(64), 0, st, W.d_ylen, m.nch, W.tiles_max,
+    if (m.conv) {
+      static const bool attr_ = (hipFuncSetAttribute((const void*)hv_band_fft_kernel<2048>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)ConvCfg<2048>::kLdsBytes) == hipSuccess);
+      (void)attr_;
+      const int groups = (m.nch + kHvChGroup - 1) / kHvChGroup;
+      hipLaunchKernelGGL(hv_band_fft_kernel<2048>, dim3(W.tiles_max, groups, n_utt), dim3(64),
+                         ConvCfg<2048>::kLdsBytes, st, W.d_yoff, W.d_ylen, W.d_y, (const cpx*)W.d_H, m.nch, m.half0,
+                         m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots);
+    } else {
+      const size_t lds = sizeof(double) * (size_t)zc_lds_doubles<kZcStrideHarvest>(m.ntap_max);
+      if (m.ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
+      hipLaunchKernelGGL(hv_band_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), lds, st, W.d_yoff, W.d_ylen,
+                         W.d_y, W.d_taps, W.d_tapoff, W.d_half, m.nch, W.tiles_max, W.d_tile_cnt, W.d_slot_off,
+                         W.d_slots);
+    }
+    hipLaunchKernelGGL(hv_band_scan_kernel, dim3(m.nch, n_utt), dim3(64), 0, st, W.d_ylen, m.nch, m.step, W.tiles_max,
                        W.d_tile_cnt, W.d_evcnt);
     hipLaunchKernelGGL(hv_band_compact_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
-                       W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
+                       m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
   }
   const int gx = (int)((W.tot_b + 255) / 256);
   {
