@@ -100,6 +100,7 @@ struct Batch {
   // D4C tables
   double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
   int* d_utt_total = nullptr;        // [n_utt] LoveTrain randn totals
+  double* d_d4c_big = nullptr;       // fft_size_d4c 4096: centroid quarters, centroid, group delay, coarse values per frame
   // DIO workspace
   bool dio_ready = false;
   void* dio_host = nullptr;          // DioHost (dio.hip)

@@ -60,6 +60,13 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 // Compiler fence for a kernel-uniform scalar (an argument such as fs) inside persistent frame loops: whatever is
 // derived from the returned value is recomputed per frame instead of being hoisted out of the loop, where it would
 // hold registers -- often vector registers, for FP64 quotients -- for the whole kernel.
+// The same for a per-lane double: what is derived from the returned value is not merged with what was derived from
+// the argument elsewhere (common subexpressions kept alive across a transform cost registers, recomputing is cheap).
+__device__ __forceinline__ double opaque_d(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 __device__ __forceinline__ int opaque_uniform(int v) {
   asm volatile("" : "+s"(v));
   return v;

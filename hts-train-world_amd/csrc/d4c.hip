@@ -502,7 +502,8 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
 // ~4 fs / FD): every frame behind Dio / Harvest + StoneMask at their default 71-800 Hz range from 12.8 kHz up.
 // The RARE one takes the rest of what the reference defines.
 __host__ __device__ inline bool d4c_is_usual(double cf0, int fd, int fs) {
-  return d4c_mirror_bins(cf0, fd, fs) <= fd / 16 && 2 * matlab_round(2.0 * fs / cf0) + 1 <= fd / 2;
+  // fd 4096 (d4c_big.hpp) takes any window length; the one-kernel form only windows of at most fd / 2 samples
+  return d4c_mirror_bins(cf0, fd, fs) <= fd / 16 && (fd >= 4096 || 2 * matlab_round(2.0 * fs / cf0) + 1 <= fd / 2);
 }
 struct D4cRunUsualPred {
   const double* f0;
@@ -528,6 +529,56 @@ struct D4cRunRarePred {
     return !d4c_is_usual(cf0, fd, fs) && d4c_mirror_bins(cf0, fd, fs) <= fd / 2;
   }
 };
+
+}  // namespace wm
+#include "d4c_big.hpp"
+namespace wm {
+
+// fft_size_d4c = 4096: the four-kernel form of d4c_big.hpp for the usual frames
+static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const double* d_f0, D4CTables tab,
+                          double* d_ap) {
+  constexpr int FD = 4096;
+  typedef D4cBig<FD> G;
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int64_t tf = b.total_f;
+  static const int g1 = persistent_grid(c, d4cb_centroid_kernel<FD>, 64, (int64_t)1 << 40);
+  static const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
+  static const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);
+  const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
+  const size_t ws_rows = (size_t)imax(g1, imax(g2, g3));           // one scratch row per workgroup of the widest grid
+  if (!b.d_d4c_big) {
+    const size_t per = (size_t)4 * G::kQ + 2 * (size_t)G::kRow + 8;
+    int rc = wm_check(hipMalloc((void**)&b.d_d4c_big, sizeof(double) * (per * (size_t)(tf > 0 ? tf : 1) +
+                                                                        ws_rows * D4cBigWs<FD>::kDoubles)));
+    if (rc) return rc;
+  }
+  double* C = b.d_d4c_big;
+  double* SC = C + (size_t)tf * 4 * G::kQ;
+  double* GD = SC + (size_t)tf * G::kRow;
+  double* COARSE = GD + (size_t)tf * G::kRow;
+  double* WS = COARSE + (size_t)tf * 8;
+  const int fs = b.p.fs;
+  const int* perm = (const int*)b.d_perm;
+  const int* nl = (const int*)b.d_part_n;
+  hipLaunchKernelGGL(d4cb_centroid_kernel<FD>, dim3(imin(cap, g1)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, WS, C);
+  hipLaunchKernelGGL(d4cb_spectrum_kernel<FD>, dim3(imin(cap, g2)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (const double*)C, WS, SC, GD);
+  const int64_t tasks = tf * tab.nap;
+  const int cap3 = (int)(tasks < (int64_t)c.frame_grid * 4 ? tasks : (int64_t)c.frame_grid * 4);
+  hipLaunchKernelGGL(d4cb_band_kernel<FD>, dim3(imax(1, imin(cap3, g3))), dim3(64), 0, st, d_f0, fs, tab, perm, nl,
+                     (const double*)GD, WS, COARSE);
+  const int64_t blocks = (tf + 3) / 4;
+  hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
+                     b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);
+  // the rare frames afterwards, over the default rows the output kernel has written for them
+  static const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
+  hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                     b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab,
+                     b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);
+  return wm_check(hipGetLastError());
+}
 
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
   Context& c = *b.ctx;
@@ -619,7 +670,10 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     switch (FD) {
       WM_D4C_CASE(1024, 2)
       WM_D4C_CASE(2048, 2)
-      WM_D4C_CASE(4096, 1)      // 32 complex values per lane and operand: one wave per SIMD, 512 registers
+      case 4096: {              // four kernels on the 1024-point transform (d4c_big.hpp)
+        rc = launch_d4c_big(b, d_x, d_t, d_f0, tab, d_ap);
+        if (rc) return rc;
+      } break;
     }
   }
 #undef WM_D4C_CASE

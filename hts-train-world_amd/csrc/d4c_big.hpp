@@ -1,0 +1,478 @@
+// d4c_big.hpp -- D4CGeneralBody for fft_size_d4c = 4096 (fs above 24 kHz: the recipe's own 48 kHz), as four
+// kernels on the 1024-point wavefront transform.  Included by d4c.hip.
+//
+// One wavefront per frame with a 2048-point complex engine (32 complex values per lane and operand) needs all 512
+// registers of a SIMD, i.e. one wave per SIMD with nothing to hide latency behind, and still keeps two 2049-bin
+// spectra in registers across five band analyses: 231 us per voiced frame against 29 us at fft 2048 for ~3.7 x the
+// arithmetic.  Here every transform of 4096 points is decomposed by hand into transforms of NS = 1024 complex
+// points -- the size the engine runs at two waves per SIMD -- and the frame's work is cut into kernels whose state
+// fits that budget, with the 2049-bin arrays passing through HBM (16 KB per frame and array):
+//
+//   d4cb_centroid_kernel   GetStaticCentroid (d4c.cpp:125-142).  z = s x + j (i + 1) x as in d4c.hip; the 4096-point
+//                          complex transform is one radix-4 decimation-in-frequency step (a window of at most 2048
+//                          samples fills two of the four quarters): Z[4 j + q] = FFT_NS(u_q)[j],
+//                          u_q[n] = (z[n] + (-j)^q z[n + NS]) W_4096^(n q).  The pairing Z[k] Z[4096 - k] couples
+//                          q = 0 and q = 2 with themselves and q = 1 with q = 3.  Output: C[frame][q][j], the
+//                          centroid at bin 4 j + q (both sides summed).
+//   d4cb_spectrum_kernel   GetSmoothedPowerSpectrum + GetStaticGroupDelay (:148-186).  The real transform of the
+//                          Hann frame: even bins are the real transform of 2048 points as it is (rfft_forward<NS>),
+//                          odd bins come from FFT_NS(v[n] W_2048^n) with the split pairing j <-> NS - 1 - j.
+//                          Output: GD[frame][0..2048].
+//   d4cb_band_kernel       GetCoarseAperiodicity (:192-223), one wavefront per (frame, band): the same even / odd
+//                          real transform of the windowed slice, the power spectrum's 2049 values sorted per lane,
+//                          the largest peeled.  Output: COARSE[frame][band].
+//   d4cb_output_kernel     GetAperiodicity (:325-333) for the listed frames, the default row for all others.
+//
+// Frames whose smoothing mirror exceeds 4096 / 16 bins or whose window exceeds 2048 samples (d4c_is_usual) stay
+// with the one-kernel form (d4c_kernel<4096, 1, true>).
+#pragma once
+
+namespace wm {
+
+template <int FD> struct D4cBig {
+  static constexpr int NS = FD / 4, MS = NS / 64, H = FD / 2;
+  static constexpr int kQ = NS / 2 + 1;                 // entries of C per quarter (q = 0 uses all, the others NS / 2)
+  static constexpr int kRow = ((H + 1 + 7) / 8) * 8;    // doubles per frame of the HBM arrays
+};
+
+// partner of lane-local element j = lane + 64 m in an NS-point spectrum held as v[m]: stores the upper half of
+// the registers in plain layout (as d4c_centroid)
+template <int NS>
+__device__ __forceinline__ void store_upper(const cpx (&v)[NS / 64], cpx* img, int lane) {
+  constexpr int MS = NS / 64;
+  wave_sync();
+#pragma unroll
+  for (int m = MS / 2; m < MS; ++m) img[lane + 64 * m] = v[m];
+  wave_sync();
+}
+template <int NS>
+__device__ __forceinline__ void store_all(const cpx (&v)[NS / 64], cpx* img, int lane) {
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < NS / 64; ++m) img[lane + 64 * m] = v[m];
+  wave_sync();
+}
+
+// (-j)^k z
+template <int K> __device__ __forceinline__ cpx mul_mj_pow(cpx z) {
+  if (K == 0) return z;
+  if (K == 1) return make_double2(z.y, -z.x);
+  if (K == 2) return make_double2(-z.x, -z.y);
+  return make_double2(-z.y, z.x);
+}
+
+// u_q[n] = (sum_p z[n + p NS] (-j)^(p q)) W_FD^(n q) for n = lane + 64 m, from the frame parked in the workgroup's
+// scratch row (xs[i] = sample i of the normalised-later frame): z[i] = xs[i] (s + j (i + 1)).  Quarters beyond the
+// window (p NS >= L) are skipped by wave-uniform branches.
+template <int FD, int Q>
+__device__ __forceinline__ void d4cb_quarter_input(const double* __restrict__ xs, int L, double s, cpx wl, int lane,
+                                                   cpx (&v)[D4cBig<FD>::MS]) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
+  const cpx w64 = cis64(4096 / FD);                               // W_FD^64
+  // fenced: the chain of twiddles is rebuilt per quarter instead of living through the transforms between them
+  cpx w = make_double2(opaque_d(wl.x), opaque_d(wl.y));
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    const int n = lane + 64 * m;
+    const double r = (double)(n + 1);
+    const double x0 = xs[n];
+    cpx acc = make_double2(s * x0, r * x0);
+    if (NS < L) {
+      const double x1 = xs[n + NS];
+      acc = cadd(acc, mul_mj_pow<(1 * Q) & 3>(make_double2(s * x1, (r + NS) * x1)));
+    }
+    if (2 * NS < L) {
+      const double x2 = xs[n + 2 * NS];
+      acc = cadd(acc, mul_mj_pow<(2 * Q) & 3>(make_double2(s * x2, (r + 2 * NS) * x2)));
+    }
+    if (3 * NS < L) {
+      const double x3 = xs[n + 3 * NS];
+      acc = cadd(acc, mul_mj_pow<(3 * Q) & 3>(make_double2(s * x3, (r + 3 * NS) * x3)));
+    }
+    if (Q == 0) v[m] = acc;
+    if (Q == 1) v[m] = cmul(acc, w);
+    if (Q == 2) v[m] = cmul(acc, cmul(w, w));
+    if (Q == 3) v[m] = cmul(acc, cmul(cmul(w, w), w));
+    w = cmul(w, w64);
+  }
+}
+
+// Scratch row of a workgroup (doubles): the frame (FD), then one NS-point complex spectrum (2 NS).
+template <int FD> struct D4cBigWs { static constexpr int kFrame = 0, kSpec = FD, kDoubles = FD + 2 * D4cBig<FD>::NS; };
+
+template <int FD>
+__global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
+    const int* __restrict__ n_listed, double* __restrict__ scratch, double* __restrict__ C) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kQ = D4cBig<FD>::kQ;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<NS>::kElems];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int lane0 = threadIdx.x;
+  FftTw<NS> tw;
+  tw.init(lane0);
+  double* ws = scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles;
+  double* xs = ws + D4cBigWs<FD>::kFrame;
+  cpx* e1 = reinterpret_cast<cpx*>(ws + D4cBigWs<FD>::kSpec);
+  const int n_run = *n_listed;
+  FramePipe pipe;
+  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    const int fs = opaque_uniform(fs_arg);
+    const double cf0 = uniform_d(sc.f0 > kFloorF0D4C ? sc.f0 : kFloorF0D4C);
+    const double pos = uniform_d(sc.tpos);
+    const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
+    double* Cf = C + sc.frame * (int64_t)(4 * kQ);
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const int lane = opaque_lane(lane0);
+      tw.fence();
+      const double cpos = uniform_d(side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0);
+      const FrameGeom fg = frame_geom(fs, cf0, cpos, 4.0);
+      // the frame goes to the workgroup's scratch row (L1 / L2 resident): each of the four sub-transforms re-reads
+      // it instead of holding it in registers across the transforms before it
+      const double pwr = frame_strided_to_memory<kBlackman, 4 * MS>(sc.xu, sc.xlen, fg, rtab, sc.roff + side * Lw,
+                                                                     lane, xs);
+      const double s = (double)(1 << (31 - __clz(fg.hw | 1)));
+      const double scale = uniform_d(1.0 / (2.0 * s * pwr));
+      const cpx wl = cis_neg2pi((double)lane / (double)FD);       // W_FD^lane
+      cpx v[MS];
+      auto put = [&](int q, int m, double val) {                  // C[q][lane + 64 m] (+)= val * scale
+        double* p = Cf + q * kQ + lane + 64 * m;
+        *p = side == 0 ? val * scale : *p + val * scale;
+      };
+      // ---- q = 0: pairs with itself, j <-> (NS - j) mod NS ----
+      d4cb_quarter_input<FD, 0>(xs, fg.L, s, wl, lane, v);
+      fft_forward<NS>(v, img, tw, lane);
+      store_upper<NS>(v, img, lane);
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        const int j = lane + 64 * m;
+        cpx pt = img[(NS - j) & (NS - 1)];
+        if (m == 0) {
+          pt.x = lane == 0 ? v[0].x : pt.x;
+          pt.y = lane == 0 ? v[0].y : pt.y;
+        }
+        put(0, m, v[m].x * pt.y + v[m].y * pt.x);
+      }
+      if (lane == 0) put(0, MS / 2, 2.0 * v[MS / 2].x * v[MS / 2].y);   // j = NS / 2 pairs with itself
+      // ---- q = 2: pairs with itself, j <-> NS - 1 - j ----
+      d4cb_quarter_input<FD, 2>(xs, fg.L, s, wl, lane, v);
+      fft_forward<NS>(v, img, tw, lane);
+      store_upper<NS>(v, img, lane);
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        const cpx pt = img[NS - 1 - (lane + 64 * m)];
+        put(2, m, v[m].x * pt.y + v[m].y * pt.x);
+      }
+      // ---- q = 1 and q = 3: bins 4 j + 1 pair E1[j] with E3[NS - 1 - j], bins 4 j + 3 pair E3[j] with E1[NS - 1 - j];
+      //      E1 waits in the scratch row while E3 is transformed ----
+      d4cb_quarter_input<FD, 1>(xs, fg.L, s, wl, lane, v);
+      fft_forward<NS>(v, img, tw, lane);
+#pragma unroll
+      for (int m = 0; m < MS; ++m) e1[lane + 64 * m] = v[m];
+      d4cb_quarter_input<FD, 3>(xs, fg.L, s, wl, lane, v);
+      fft_forward<NS>(v, img, tw, lane);
+      cpx v1[MS];                                                 // E1 back (every lane re-reads what it wrote itself)
+#pragma unroll
+      for (int m = 0; m < MS; ++m) v1[m] = e1[lane + 64 * m];
+      store_upper<NS>(v, img, lane);
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E3[NS - 1 - j]
+        put(1, m, v1[m].x * pt.y + v1[m].y * pt.x);
+      }
+      store_upper<NS>(v1, img, lane);
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E1[NS - 1 - j]
+        put(3, m, v[m].x * pt.y + v[m].y * pt.x);
+      }
+      wave_sync();
+    }
+  }
+}
+
+// Power spectrum |X[k]|^2, k = 0 .. FD / 2, of a real frame of FD samples given as packed pairs in two halves:
+// va[m] = (x[2 n], x[2 n + 1]), vb[m] the same NS pairs later (n = lane + 64 m < NS); `folded` says whether vb holds
+// anything (wave-uniform).  pe[m] = power at bin 2 (lane + 64 m), pe[MS] = power at bin FD / 2 (every lane),
+// po[m] = power at bin 2 (lane + 64 m) + 1.  `park` is a scratch row of 2 NS doubles in global memory; every lane
+// re-reads only what it wrote itself.  va / vb are consumed.
+template <int FD>
+__device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx (&vb)[D4cBig<FD>::MS], bool folded,
+                                                  cpx* __restrict__ park, cpx* img, const FftTw<D4cBig<FD>::NS>& tw,
+                                                  int lane, double (&pe)[D4cBig<FD>::MS + 1],
+                                                  double (&po)[D4cBig<FD>::MS]) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
+  // the packed sequence vp of 2 NS points splits into even bins FFT_NS(va + vb) and odd bins
+  // FFT_NS((va - vb) W_{2 NS}^n); the odd operand waits in the scratch row while the even one is transformed
+  {
+    cpx w = tw.wsplit;                                            // W_{2 NS}^lane
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      const cpx d = folded ? csub(va[m], vb[m]) : va[m];
+      park[lane + 64 * m] = cmul(d, w);
+      if (folded) va[m] = cadd(va[m], vb[m]);
+      w = cmul(w, tw.wstep());
+    }
+  }
+  // even bins: the real transform of 2 NS points as it is
+  rfft_forward<NS>(va, img, img, tw, lane);
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    const cpx s = img[lane + 64 * m];
+    pe[m] = s.x * s.x + s.y * s.y;
+  }
+  {
+    const cpx s = img[NS];
+    pe[MS] = s.x * s.x + s.y * s.y;
+  }
+  // odd bins: X[2 j + 1] from O[j] and O[NS - 1 - j] with the twiddle W_FD^(2 j + 1)
+#pragma unroll
+  for (int m = 0; m < MS; ++m) va[m] = park[lane + 64 * m];
+  fft_forward<NS>(va, img, tw, lane);
+  store_all<NS>(va, img, lane);
+  {
+    const cpx w1 = cis_neg2pi(1.0 / (double)FD);                  // W_FD
+    cpx w = cmul(tw.wsplit, w1);                                  // W_FD^(2 lane + 1)
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      const cpx a = va[m];
+      const cpx b = cconj(img[NS - 1 - (lane + 64 * m)]);
+      const cpx e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+      const cpx d = csub(a, b);
+      const cpx o = make_double2(0.5 * d.y, -0.5 * d.x);          // (a - b) / (2 i)
+      const cpx xk = cadd(e, cmul(w, o));
+      po[m] = xk.x * xk.x + xk.y * xk.y;
+      w = cmul(w, tw.wstep());                                    // W_FD^128 = W_{2 NS}^64
+    }
+  }
+  wave_sync();
+}
+
+template <int FD>
+__global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
+    const int* __restrict__ n_listed, const double* __restrict__ C, double* __restrict__ scratch,
+    double* __restrict__ SC, double* __restrict__ GD) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, H = D4cBig<FD>::H, kQ = D4cBig<FD>::kQ;
+  constexpr int kRow = D4cBig<FD>::kRow;
+  constexpr int kBM = FD / 16;
+  constexpr int kImg = 2 * FftLds<NS>::kElems;
+  constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
+  constexpr int kTot = kImg > kRegion ? kImg : kRegion;
+  constexpr int T = (H + 1 + 63) / 64;                           // strided elements per lane of a spectrum
+  __shared__ __attribute__((aligned(16))) double smem[kTot];
+  double* arr = smem + kBM;
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int lane0 = threadIdx.x;
+  FftTw<NS> tw;
+  tw.init(lane0);
+  cpx* park = reinterpret_cast<cpx*>(scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles + D4cBigWs<FD>::kSpec);
+  const int n_run = *n_listed;
+  FramePipe pipe;
+  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    const int lane = opaque_lane(lane0);
+    const int fs = opaque_uniform(fs_arg);
+    tw.fence();
+    const double cf0 = uniform_d(sc.f0 > kFloorF0D4C ? sc.f0 : kFloorF0D4C);
+    const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
+    const double* Cf = C + sc.frame * (int64_t)(4 * kQ);
+    double* SCf = SC + sc.frame * (int64_t)kRow;
+    double* GDf = GD + sc.frame * (int64_t)kRow;
+    // ---- static centroid: gather the four quarters, DCCorrection (d4c.cpp:139), keep it in HBM ----
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int j = lane; j < NS / 2; j += 64) arr[4 * j + q] = Cf[q * kQ + j];
+    if (lane == 0) arr[H] = Cf[NS / 2];                          // q = 0, j = NS / 2: bin FD / 2
+    wave_sync();
+    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    for (int i = lane; i <= H; i += 64) SCf[i] = arr[i];
+    wave_sync();
+    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
+    {
+      cpx va[MS], vb[MS];
+      const FrameGeom fg = frame_geom(fs, cf0, uniform_d(sc.tpos), 4.0);
+      {
+        cpx vp[2 * MS];
+        frame_packed<kHann, false, 2 * MS>(sc.xu, sc.xlen, fg, rtab, sc.roff + 2 * Lw, lane, vp);
+#pragma unroll
+        for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
+      }
+      double pe[MS + 1], po[MS];
+      real_power_halves<FD>(va, vb, fg.L > 2 * NS, park, img, tw, lane, pe, po);
+      cpx* arr2 = reinterpret_cast<cpx*>(arr);
+#pragma unroll
+      for (int m = 0; m < MS; ++m) arr2[lane + 64 * m] = make_double2(pe[m], po[m]);   // bins 2 j, 2 j + 1
+      if (lane == 0) arr[H] = pe[MS];
+      wave_sync();
+    }
+    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
+    asm volatile("" ::: "memory");                               // the centroid is fetched here, not before the smoothing
+#pragma unroll
+    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven quotients at a time
+      double scv[11];
+#pragma unroll
+      for (int t = 0; t < 11; ++t) scv[t] = t0 + t < T ? SCf[imin(lane + 64 * (t0 + t), H)] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 11; ++t)
+        if (t0 + t < T && lane + 64 * (t0 + t) <= H) arr[lane + 64 * (t0 + t)] = scv[t] / arr[lane + 64 * (t0 + t)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync();
+    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
+    for (int i = lane; i <= H; i += 64) GDf[i] = arr[i];
+    wave_sync();
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    {
+      double g1[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) g1[t] = GDf[imin(lane + 64 * t, H)];
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (lane + 64 * t <= H) GDf[lane + 64 * t] = g1[t] - arr[lane + 64 * t];
+    }
+    wave_sync();
+  }
+}
+
+// One wavefront per (listed frame, band).
+template <int FD>
+__global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restrict__ f0, int fs, D4CTables tab,
+                                                          const int* __restrict__ perm,
+                                                          const int* __restrict__ n_listed,
+                                                          const double* __restrict__ GD,
+                                                          double* __restrict__ scratch,
+                                                          double* __restrict__ COARSE) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kRow = D4cBig<FD>::kRow;
+  constexpr int NP = 2 * MS + 1;                                  // power values per lane
+  constexpr int kImg = 2 * FftLds<NS>::kElems;
+  constexpr int kHeads = (NP + 1) * 64;
+  __shared__ __attribute__((aligned(16))) double smem[kImg > kHeads ? kImg : kHeads];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int lane0 = threadIdx.x;
+  FftTw<NS> tw;
+  tw.init(lane0);
+  cpx* park = reinterpret_cast<cpx*>(scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles + D4cBigWs<FD>::kSpec);
+  const int64_t n_task = (int64_t)*n_listed * tab.nap;
+  const int wl = tab.window_length, hwl = wl / 2;
+  const int bnd = matlab_round(FD * 8.0 / wl);
+  for (int64_t task = blockIdx.x; task < n_task; task += gridDim.x) {
+    const int lane = opaque_lane(lane0);
+    tw.fence();
+    const int64_t li = task / tab.nap;
+    const int band = (int)(task - li * tab.nap);
+    const int frame = __builtin_amdgcn_readfirstlane(perm[li]);
+    const double f0v = f0[frame];
+    const double cf0 = uniform_d(f0v > kFloorF0D4C ? f0v : kFloorF0D4C);
+    const double* gd = GD + frame * (int64_t)kRow;
+    const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
+    cpx vp[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      vp[m] = make_double2(0.0, 0.0);
+      if (128 * m < wl) {                                         // wave-uniform
+        const int i0 = 2 * (lane + 64 * m);
+        double a0 = 0.0, a1 = 0.0;
+        if (i0 < wl) a0 = gd[center - hwl + i0] * tab.nuttall[i0];
+        if (i0 + 1 < wl) a1 = gd[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
+        vp[m] = make_double2(a0, a1);
+      }
+    }
+    double pe[MS + 1], po[MS];
+    cpx none[MS];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) none[m] = make_double2(0.0, 0.0);
+    real_power_halves<FD>(vp, none, false, park, img, tw, lane, pe, po);   // the window (FD / 8 + 1 taps) never folds
+    double p[NP];
+    double tot = 0.0;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      p[2 * m] = pe[m];
+      p[2 * m + 1] = po[m];
+      tot += pe[m] + po[m];
+    }
+    p[2 * MS] = -1.0;
+    if (lane == 0) {
+      p[2 * MS] = pe[MS];
+      tot += pe[MS];
+    }
+    tot = wave_sum(tot);
+    // the (bnd + 1) largest of the FD / 2 + 1 values are left out (d4c.cpp:215-220): see d4c_kernel
+    sort_desc<2 * MS>(p);
+#pragma unroll
+    for (int i = 2 * MS - 1; i >= 0; --i) {
+      const double hi = fmax(p[i], p[i + 1]), lo = fmin(p[i], p[i + 1]);
+      p[i] = hi;
+      p[i + 1] = lo;
+    }
+    double* heads = smem;                                         // [NP + 1][64]
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < NP; ++m) heads[m * 64 + lane] = p[m];
+    heads[NP * 64 + lane] = -1.0;
+    int taken = 0;
+    double cur = heads[lane];
+#pragma unroll 1
+    for (int it = 0; it <= bnd; ++it) {
+      const double wmx = wave_max(cur);
+      const unsigned long long vote = __ballot(cur == wmx);
+      const int winner = __ffsll((long long)vote) - 1;
+      taken += lane == winner ? 1 : 0;
+      cur = heads[taken * 64 + lane];
+    }
+    double low = 0.0;
+#pragma unroll
+    for (int m = 0; m < NP; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;
+    low = wave_sum(low);
+    double c = 10.0 * log10(low / tot);
+    c = c + (cf0 - 100.0) / 50.0;                                 // d4c.cpp:309-311
+    c = 0.0 < c ? 0.0 : c;                                        // MyMinDouble(0.0, c)
+    if (lane == 0) COARSE[(int64_t)frame * 8 + band] = c;
+    wave_sync();
+  }
+}
+
+// ap rows: interpolation of the coarse values (GetAperiodicity, d4c.cpp:325-333) for the listed frames, the
+// default 1 - 1e-12 for all others (:318-323).  One wavefront per frame, four per workgroup.
+__global__ __launch_bounds__(256) void d4cb_output_kernel(int fs, D4CTables tab, int out_fft, int64_t total_frames,
+                                                          const int* __restrict__ perm,
+                                                          const int* __restrict__ n_listed,
+                                                          const double* __restrict__ COARSE, double* __restrict__ ap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (int64_t)gridDim.x * 4;
+  const int out_bins = out_fft / 2 + 1;
+  const int n_run = *n_listed;
+  const double bin_hz = (double)fs / out_fft;
+  const double last_w = fs / 2.0 - tab.nap * kFreqInterval;
+  const double inv_last = 1.0 / last_w;
+  for (int64_t k = wave; k < total_frames; k += waves) {
+    const int frame = perm[k];
+    double* row = ap + frame * (int64_t)out_bins;
+    if (k >= n_run) {
+      for (int i = lane; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
+      continue;
+    }
+    const double* cz = COARSE + (int64_t)frame * 8;
+    for (int i = lane; i < out_bins; i += 64) {
+      const double f = (double)i * bin_hz;
+      int kk = (int)(f * (1.0 / kFreqInterval));
+      kk = kk > tab.nap ? tab.nap : kk;
+      const double x0 = kk * kFreqInterval;
+      const double sfr = (f - x0) * (kk == tab.nap ? inv_last : 1.0 / kFreqInterval);
+      const double y0 = kk == 0 ? -60.0 : cz[kk - 1];
+      const double y1 = kk == tab.nap ? -kSafe : cz[kk];
+      const double yi = y0 + sfr * (y1 - y0);
+      row[i] = exp(yi * (2.302585092994045684 / 20.0));          // 10^(yi/20), d4c.cpp:331-332
+    }
+  }
+}
+
+}  // namespace wm

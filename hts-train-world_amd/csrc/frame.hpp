@@ -114,6 +114,65 @@ __device__ __forceinline__ void frame_strided(const double* __restrict__ xu, int
   pwr = wave_sum(p);
 }
 
+// The same frame written to memory instead of registers: out[64 q + lane] = sample 64 q + lane for 64 q < L (nothing
+// beyond), in two passes over groups of 16 registers (long frames: 64 samples per lane would not leave room for
+// anything else).  Every lane re-reads only what it wrote itself.  Returns the sum of squares.
+template <int TYPE, int QX>
+__device__ __forceinline__ double frame_strided_to_memory(const double* __restrict__ xu, int xl, const FrameGeom& fg,
+                                                          const uint32_t* __restrict__ rtab, int roff, int lane,
+                                                          double* __restrict__ out) {
+  constexpr int G = 16;
+  static_assert(QX % G == 0, "QX is a multiple of the load group");
+  const int L = fg.L;
+  CosGen g;
+  g.init(fg.a, lane - fg.hw, 64);
+  const CosGen g0 = g;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+  for (int c = 0; c < QX / G; ++c) {
+    if (64 * G * c >= L) break;                          // wave-uniform
+    double xv[G];
+    uint32_t rv[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      const int ic = imin(64 * (c * G + r) + lane, L - 1);
+      xv[r] = xu[imin(xl - 1, imax(0, fg.origin + ic - fg.hw))];
+      rv[r] = rtab[roff + ic];
+    }
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      const int i = 64 * (c * G + r) + lane;
+      const bool in = i < L;
+      const double wv = window_value<TYPE>(g.c);
+      const double val = in ? xv[r] * wv + ((double)rv[r] / 268435456.0 - 6.0) * kSafe : 0.0;
+      s1 += val;
+      s2 += in ? wv : 0.0;
+      out[i] = val;
+      g.next();
+    }
+  }
+  const double coef = wave_sum(s1) / wave_sum(s2);
+  double p = 0.0;
+  g = g0;
+#pragma unroll 1
+  for (int c = 0; c < QX / G; ++c) {
+    if (64 * G * c >= L) break;
+    double v[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) v[r] = out[64 * (c * G + r) + lane];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      const int i = 64 * (c * G + r) + lane;
+      const double wv = i < L ? window_value<TYPE>(g.c) : 0.0;
+      const double val = v[r] - wv * coef;
+      p += val * val;
+      out[i] = val;
+      g.next();
+    }
+  }
+  return wave_sum(p);
+}
+
 // v[m] = (sample 2n, sample 2n + 1), n = 64 m + lane, m < M: the packed operand of a real FFT of 128 M points.
 // NORMALISE: CheapTrick's L2 normalisation of the window (cheaptrick.cpp:105-106), applied as a multiplication
 // by the reciprocal of sqrt(sum w^2).

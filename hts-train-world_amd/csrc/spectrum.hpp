@@ -92,18 +92,26 @@ __device__ __forceinline__ void linear_smoothing_margin(double* arr, double widt
   const double fl = c_lo - bl, fh = c_hi - bh;
   const double inv_width = 1.0 / width;
   const int i0 = lane * BI;
-  double lo[BI + 1], hi[BI + 1];
-#pragma unroll
-  for (int q = 0; q <= BI; ++q) {
-    lo[q] = ext[i0 + bl + q];
-    hi[q] = ext[i0 + bh + q];
-  }
+  // in chunks of at most 12 bins: the two runs of knots of a chunk are in flight together, the results of all
+  // chunks wait in registers (a lane's BI results; 33 at a half spectrum of 2048 bins)
+  constexpr int CK = BI <= 17 ? BI : (BI + 2) / 3;
   double out[BI];
 #pragma unroll
-  for (int q = 0; q < BI; ++q) {
-    const double l = lo[q] + (lo[q + 1] - lo[q]) * fl;
-    const double h = hi[q] + (hi[q + 1] - hi[q]) * fh;
-    out[q] = (h - l) * inv_width;
+  for (int c0 = 0; c0 < BI; c0 += CK) {
+    double lo[CK + 1], hi[CK + 1];
+#pragma unroll
+    for (int q = 0; q <= CK; ++q) {
+      lo[q] = ext[i0 + bl + c0 + q];
+      hi[q] = ext[i0 + bh + c0 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < CK; ++q) {
+      if (c0 + q < BI) {
+        const double l = lo[q] + (lo[q + 1] - lo[q]) * fl;
+        const double h = hi[q] + (hi[q + 1] - hi[q]) * fh;
+        out[c0 + q] = (h - l) * inv_width;
+      }
+    }
   }
   wave_sync();                                          // all knots read: the spectrum may be overwritten
   // unconditional: bins beyond HALF land in the right margin (rewritten by the next mirror fill)
