@@ -185,6 +185,52 @@ __device__ __forceinline__ void sort_desc(double (&a)[NS + 1]) {
   }
 }
 
+// Which entries of a wavefront's values are among the K largest, for lists sorted descending per lane and parked
+// as columns in LDS: heads[m * 64 + lane] = m-th largest of the lane, followed by at least THREE rows of -1 (values
+// are powers, >= 0).  Returns how many of its entries each lane gives up; the counts add up to K.  Only the sum
+// of what is left matters to the caller (d4c.cpp:215-220), so ties may be broken anyhow.
+//
+// Round 1 peeled one value per wave-wide maximum: K = 65 dependent steps of a 6-stage reduction and an LDS read,
+// 15 % of d4c_kernel's instructions at 16 kHz and 40 % of the band kernel's at 48 kHz.  Here a step takes every
+// value that provably beats all values below the lanes' first two entries: T = max over lanes of the THIRD entry;
+// whatever of a lane's first two entries is >= T is larger than every entry not looked at.  If that is more than
+// what is left to take, the same with the second entry (fewer candidates), and if that is still too many the
+// largest of those heads are taken one by one (they beat everything else, so no list advances).  On spectra
+// with a main lobe or a few peaks over noise that is 3-6 reductions plus about 5 single steps instead of 65.
+__device__ __forceinline__ int peel_largest(const double* heads, int K, int lane) {
+  int taken = 0, r = K;
+  while (r > 0) {                                               // every pass takes at least one value or leaves
+    const double* col = heads + taken * 64 + lane;
+    const double cur = col[0], nxt = col[64], thr = col[128];
+    double T = wave_max(thr);
+    bool a = cur >= T && cur >= 0.0, b = nxt >= T && nxt >= 0.0;
+    int c = __popcll(__ballot(a)) + __popcll(__ballot(b));
+    if (c > r) {
+      T = wave_max(nxt);
+      a = cur >= T && cur >= 0.0;
+      b = false;
+      c = __popcll(__ballot(a));
+    }
+    if (c == 0) break;                                          // NaNs only (the caller's total is NaN as well)
+    if (c <= r) {
+      taken += (a ? 1 : 0) + (b ? 1 : 0);
+      r -= c;
+      continue;
+    }
+    double cd = a ? cur : -1.0;
+#pragma unroll 1
+    for (int i = 0; i < r; ++i) {
+      const double mx = wave_max(cd);
+      const int winner = __ffsll((long long)__ballot(cd == mx)) - 1;
+      const bool me = lane == winner;
+      taken += me ? 1 : 0;
+      cd = me ? -1.0 : cd;
+    }
+    r = 0;
+  }
+  return taken;
+}
+
 struct D4CTables {
   const double* nuttall;    // [window_length] NuttallWindow(window_length) (d4c.cpp:356-359)
   int window_length;
@@ -287,7 +333,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
   constexpr int kBM = D4CMargin<FD, RARE>::kBM;
   constexpr int kImg = 2 * FftLds<N>::kElems;
   constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
-  constexpr int kHeads = (MB + 1) * 64;
+  constexpr int kHeads = (MB + 3) * 64;
   constexpr int kTot = kImg > kRegion ? (kImg > kHeads ? kImg : kHeads) : (kRegion > kHeads ? kRegion : kHeads);
   static_assert(kBM % 2 == 0, "the spectrum starts on a 16-byte boundary");
   __shared__ __attribute__((aligned(16))) double smem[kTot];
@@ -427,9 +473,8 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       tot = wave_sum(tot);
       // Sum of all but the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest
       // (d4c.cpp:215-220).  Each lane sorts its own bins once (Batcher network, static indices) and
-      // parks the sorted column in LDS (the FFT image is free again); the largest bins are then
-      // peeled by repeated wave-wide max over the lanes' current heads, and the winning lane
-      // advances its head with one LDS read.
+      // parks the sorted column in LDS (the FFT image is free again); peel_largest() says how many
+      // of its largest bins every lane gives up.
       wave_sync();
       sort_desc<M>(p);
 #pragma unroll
@@ -438,20 +483,12 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
         p[i] = hi;
         p[i + 1] = lo;
       }
-      double* heads = smem;                                   // [MB + 1][64]
+      double* heads = smem;                                   // [MB + 3][64]
 #pragma unroll
       for (int m = 0; m < MB; ++m) heads[m * 64 + lane] = p[m];
-      heads[MB * 64 + lane] = -1.0;                           // exhausted
-      int taken = 0;
-      double cur = heads[lane];                               // = p[0] (own column: no barrier needed)
-#pragma unroll 1
-      for (int it = 0; it <= bnd; ++it) {
-        const double wmx = wave_max(cur);
-        const unsigned long long vote = __ballot(cur == wmx);
-        const int winner = __ffsll((long long)vote) - 1;
-        taken += lane == winner ? 1 : 0;                      // branch-free: every lane re-reads its head
-        cur = heads[taken * 64 + lane];
-      }
+#pragma unroll
+      for (int m = MB; m < MB + 3; ++m) heads[m * 64 + lane] = -1.0;     // exhausted
+      const int taken = peel_largest(heads, bnd + 1, lane);   // own column only: no barrier needed
       double low = 0.0;
 #pragma unroll
       for (int m = 0; m < MB; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;

@@ -65,11 +65,14 @@ template <int K> __device__ __forceinline__ cpx mul_mj_pow(cpx z) {
 // scratch row (xs[i] = sample i of the normalised-later frame): z[i] = xs[i] (s + j (i + 1)).  Quarters beyond the
 // window (p NS >= L) are skipped by wave-uniform branches.
 template <int FD, int Q>
-__device__ __forceinline__ void d4cb_quarter_input(const double* __restrict__ xs, int L, double s, cpx wl, int lane,
+__device__ __forceinline__ void d4cb_quarter_input(const double* xs, int L, double s, cpx wl, int lane,
                                                    cpx (&v)[D4cBig<FD>::MS]) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
   const cpx w64 = cis64(4096 / FD);                               // W_FD^64
-  // fenced: the chain of twiddles is rebuilt per quarter instead of living through the transforms between them
+  // fenced: the frame is read from memory again (not forwarded from the registers that were stored, which would
+  // have to live through the transforms in between), and the chain of twiddles is rebuilt per quarter
+  asm volatile("" ::: "memory");
+  lane = opaque_lane(lane);                                       // ... and so are the sample numbers n + 1
   cpx w = make_double2(opaque_d(wl.x), opaque_d(wl.y));
 #pragma unroll
   for (int m = 0; m < MS; ++m) {
@@ -97,6 +100,23 @@ __device__ __forceinline__ void d4cb_quarter_input(const double* __restrict__ xs
   }
 }
 
+// u_0 from the frame still in registers (x[q] = sample lane + 64 q): no twiddles, and no trip to memory before the
+// first transform.
+template <int FD>
+__device__ __forceinline__ void d4cb_quarter0_input(const double (&x)[FD / 64], int L, double s, int lane,
+                                                    cpx (&v)[D4cBig<FD>::MS]) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
+#pragma unroll
+  for (int m = 0; m < MS; ++m) {
+    const double r = (double)(lane + 64 * m + 1);
+    cpx acc = make_double2(s * x[m], r * x[m]);
+    if (NS < L) acc = cadd(acc, make_double2(s * x[m + MS], (r + NS) * x[m + MS]));
+    if (2 * NS < L) acc = cadd(acc, make_double2(s * x[m + 2 * MS], (r + 2 * NS) * x[m + 2 * MS]));
+    if (3 * NS < L) acc = cadd(acc, make_double2(s * x[m + 3 * MS], (r + 3 * NS) * x[m + 3 * MS]));
+    v[m] = acc;
+  }
+}
+
 // Scratch row of a workgroup (doubles): the frame (FD), then one NS-point complex spectrum (2 NS).
 template <int FD> struct D4cBigWs { static constexpr int kFrame = 0, kSpec = FD, kDoubles = FD + 2 * D4cBig<FD>::NS; };
 
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, double* __restrict__ scratch, double* __restrict__ C) {
+    const int* __restrict__ n_listed, double* scratch, double* __restrict__ C) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kQ = D4cBig<FD>::kQ;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<NS>::kElems];
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -130,20 +150,38 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
       tw.fence();
       const double cpos = uniform_d(side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0);
       const FrameGeom fg = frame_geom(fs, cf0, cpos, 4.0);
-      // the frame goes to the workgroup's scratch row (L1 / L2 resident): each of the four sub-transforms re-reads
-      // it instead of holding it in registers across the transforms before it
-      const double pwr = frame_strided_to_memory<kBlackman, 4 * MS>(sc.xu, sc.xlen, fg, rtab, sc.roff + side * Lw,
-                                                                     lane, xs);
+      // the frame is built in registers; the first sub-transform takes it from there, the other three re-read it
+      // from the workgroup's scratch row (every lane what it stored itself) instead of holding 128 registers
+      // across the transforms before them
+      cpx v[MS];
+      double pwr;
       const double s = (double)(1 << (31 - __clz(fg.hw | 1)));
+      {
+        double xr[4 * MS];
+        frame_strided<kBlackman, 4 * MS, false>(sc.xu, sc.xlen, fg, rtab, sc.roff + side * Lw, lane, xr, pwr);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (g * NS < fg.L) {                                    // wave-uniform
+#pragma unroll
+            for (int m = 0; m < MS; ++m) xs[lane + 64 * (m + MS * g)] = xr[m + MS * g];
+          }
+        d4cb_quarter0_input<FD>(xr, fg.L, s, lane, v);
+      }
       const double scale = uniform_d(1.0 / (2.0 * s * pwr));
       const cpx wl = cis_neg2pi((double)lane / (double)FD);       // W_FD^lane
-      cpx v[MS];
-      auto put = [&](int q, int m, double val) {                  // C[q][lane + 64 m] (+)= val * scale
-        double* p = Cf + q * kQ + lane + 64 * m;
-        *p = side == 0 ? val * scale : *p + val * scale;
+      // C[q][lane + 64 m] (+)= val * scale.  The second side adds to what the first one stored: those values are
+      // fetched (prev) BEFORE the transform whose results they meet, not one by one when they are needed -- a
+      // dependent load per value was 33 round trips to memory per frame.
+      double prev[MS / 2];
+      auto fetch = [&](int q, double (&pv)[MS / 2]) {
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) pv[m] = side == 0 ? 0.0 : Cf[q * kQ + lane + 64 * m];
       };
+      auto put = [&](int q, int m, double val, double before) { Cf[q * kQ + lane + 64 * m] = before + val * scale; };
       // ---- q = 0: pairs with itself, j <-> (NS - j) mod NS ----
-      d4cb_quarter_input<FD, 0>(xs, fg.L, s, wl, lane, v);
+      fetch(0, prev);
+      double prev_mid = 0.0;
+      if (side != 0 && lane == 0) prev_mid = Cf[NS / 2];
       fft_forward<NS>(v, img, tw, lane);
       store_upper<NS>(v, img, lane);
 #pragma unroll
@@ -154,40 +192,42 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
           pt.x = lane == 0 ? v[0].x : pt.x;
           pt.y = lane == 0 ? v[0].y : pt.y;
         }
-        put(0, m, v[m].x * pt.y + v[m].y * pt.x);
+        put(0, m, v[m].x * pt.y + v[m].y * pt.x, prev[m]);
       }
-      if (lane == 0) put(0, MS / 2, 2.0 * v[MS / 2].x * v[MS / 2].y);   // j = NS / 2 pairs with itself
+      if (lane == 0) put(0, MS / 2, 2.0 * v[MS / 2].x * v[MS / 2].y, prev_mid);   // j = NS / 2 pairs with itself
       // ---- q = 2: pairs with itself, j <-> NS - 1 - j ----
       d4cb_quarter_input<FD, 2>(xs, fg.L, s, wl, lane, v);
+      fetch(2, prev);
       fft_forward<NS>(v, img, tw, lane);
       store_upper<NS>(v, img, lane);
 #pragma unroll
       for (int m = 0; m < MS / 2; ++m) {
         const cpx pt = img[NS - 1 - (lane + 64 * m)];
-        put(2, m, v[m].x * pt.y + v[m].y * pt.x);
+        put(2, m, v[m].x * pt.y + v[m].y * pt.x, prev[m]);
       }
       // ---- q = 1 and q = 3: bins 4 j + 1 pair E1[j] with E3[NS - 1 - j], bins 4 j + 3 pair E3[j] with E1[NS - 1 - j];
       //      E1 waits in the scratch row while E3 is transformed ----
       d4cb_quarter_input<FD, 1>(xs, fg.L, s, wl, lane, v);
       fft_forward<NS>(v, img, tw, lane);
+      cpx v1[MS];
 #pragma unroll
-      for (int m = 0; m < MS; ++m) e1[lane + 64 * m] = v[m];
+      for (int m = 0; m < MS; ++m) v1[m] = v[m];
       d4cb_quarter_input<FD, 3>(xs, fg.L, s, wl, lane, v);
+      fetch(1, prev);
       fft_forward<NS>(v, img, tw, lane);
-      cpx v1[MS];                                                 // E1 back (every lane re-reads what it wrote itself)
-#pragma unroll
-      for (int m = 0; m < MS; ++m) v1[m] = e1[lane + 64 * m];
+      double prev3[MS / 2];
+      fetch(3, prev3);
       store_upper<NS>(v, img, lane);
 #pragma unroll
       for (int m = 0; m < MS / 2; ++m) {
         const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E3[NS - 1 - j]
-        put(1, m, v1[m].x * pt.y + v1[m].y * pt.x);
+        put(1, m, v1[m].x * pt.y + v1[m].y * pt.x, prev[m]);
       }
       store_upper<NS>(v1, img, lane);
 #pragma unroll
       for (int m = 0; m < MS / 2; ++m) {
         const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E1[NS - 1 - j]
-        put(3, m, v[m].x * pt.y + v[m].y * pt.x);
+        put(3, m, v[m].x * pt.y + v[m].y * pt.x, prev3[m]);
       }
       wave_sync();
     }
@@ -198,8 +238,9 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
 // va[m] = (x[2 n], x[2 n + 1]), vb[m] the same NS pairs later (n = lane + 64 m < NS); `folded` says whether vb holds
 // anything (wave-uniform).  pe[m] = power at bin 2 (lane + 64 m), pe[MS] = power at bin FD / 2 (every lane),
 // po[m] = power at bin 2 (lane + 64 m) + 1.  `park` is a scratch row of 2 NS doubles in global memory; every lane
-// re-reads only what it wrote itself.  va / vb are consumed.
-template <int FD>
+// re-reads only what it wrote itself; with PARK = false the odd operand stays in registers instead (64 more during
+// the first transform: a caller that has them saves 32 KB of memory traffic per call).  va / vb are consumed.
+template <int FD, bool PARK>
 __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx (&vb)[D4cBig<FD>::MS], bool folded,
                                                   cpx* __restrict__ park, cpx* img, const FftTw<D4cBig<FD>::NS>& tw,
                                                   int lane, double (&pe)[D4cBig<FD>::MS + 1],
@@ -207,12 +248,14 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
   // the packed sequence vp of 2 NS points splits into even bins FFT_NS(va + vb) and odd bins
   // FFT_NS((va - vb) W_{2 NS}^n); the odd operand waits in the scratch row while the even one is transformed
+  cpx odd[PARK ? 1 : MS];
   {
     cpx w = tw.wsplit;                                            // W_{2 NS}^lane
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
       const cpx d = folded ? csub(va[m], vb[m]) : va[m];
-      park[lane + 64 * m] = cmul(d, w);
+      if (PARK) park[lane + 64 * m] = cmul(d, w);
+      else odd[PARK ? 0 : m] = cmul(d, w);
       if (folded) va[m] = cadd(va[m], vb[m]);
       w = cmul(w, tw.wstep());
     }
@@ -230,7 +273,7 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
   }
   // odd bins: X[2 j + 1] from O[j] and O[NS - 1 - j] with the twiddle W_FD^(2 j + 1)
 #pragma unroll
-  for (int m = 0; m < MS; ++m) va[m] = park[lane + 64 * m];
+  for (int m = 0; m < MS; ++m) va[m] = PARK ? park[lane + 64 * m] : odd[PARK ? 0 : m];
   fft_forward<NS>(va, img, tw, lane);
   store_all<NS>(va, img, lane);
   {
@@ -256,7 +299,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, const double* __restrict__ C, double* __restrict__ scratch,
+    const int* __restrict__ n_listed, const double* __restrict__ C, double* scratch,
     double* __restrict__ SC, double* __restrict__ GD) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, H = D4cBig<FD>::H, kQ = D4cBig<FD>::kQ;
   constexpr int kRow = D4cBig<FD>::kRow;
@@ -286,13 +329,30 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     double* GDf = GD + sc.frame * (int64_t)kRow;
     // ---- static centroid: gather the four quarters, DCCorrection (d4c.cpp:139), keep it in HBM ----
     wave_sync();
+    {
+      double cq[4][MS / 2];                                      // all 32 loads in flight, then the LDS stores
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      for (int j = lane; j < NS / 2; j += 64) arr[4 * j + q] = Cf[q * kQ + j];
-    if (lane == 0) arr[H] = Cf[NS / 2];                          // q = 0, j = NS / 2: bin FD / 2
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) cq[q][m] = Cf[q * kQ + lane + 64 * m];
+      const double mid = Cf[NS / 2];
+      cpx* arr2 = reinterpret_cast<cpx*>(arr);                   // bins 4 j .. 4 j + 3 as two 16-byte stores
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        arr2[2 * (lane + 64 * m)] = make_double2(cq[0][m], cq[1][m]);
+        arr2[2 * (lane + 64 * m) + 1] = make_double2(cq[2][m], cq[3][m]);
+      }
+      if (lane == 0) arr[H] = mid;                               // q = 0, j = NS / 2: bin FD / 2
+    }
     wave_sync();
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    for (int i = lane; i <= H; i += 64) SCf[i] = arr[i];
+#pragma unroll
+    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven LDS reads in flight
+#pragma unroll
+      for (int t = t0; t < t0 + 11 && t < T; ++t)
+        if (lane + 64 * t <= H) SCf[lane + 64 * t] = arr[lane + 64 * t];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     wave_sync();
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
     {
@@ -305,7 +365,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
         for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
       }
       double pe[MS + 1], po[MS];
-      real_power_halves<FD>(va, vb, fg.L > 2 * NS, park, img, tw, lane, pe, po);
+      real_power_halves<FD, false>(va, vb, fg.L > 2 * NS, park, img, tw, lane, pe, po);
       cpx* arr2 = reinterpret_cast<cpx*>(arr);
 #pragma unroll
       for (int m = 0; m < MS; ++m) arr2[lane + 64 * m] = make_double2(pe[m], po[m]);   // bins 2 j, 2 j + 1
@@ -328,7 +388,13 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     }
     wave_sync();
     linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
-    for (int i = lane; i <= H; i += 64) GDf[i] = arr[i];
+#pragma unroll
+    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven LDS reads in flight
+#pragma unroll
+      for (int t = t0; t < t0 + 11 && t < T; ++t)
+        if (lane + 64 * t <= H) GDf[lane + 64 * t] = arr[lane + 64 * t];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     wave_sync();
     linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
     {
@@ -349,12 +415,12 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
                                                           const int* __restrict__ perm,
                                                           const int* __restrict__ n_listed,
                                                           const double* __restrict__ GD,
-                                                          double* __restrict__ scratch,
+                                                          double* scratch,
                                                           double* __restrict__ COARSE) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kRow = D4cBig<FD>::kRow;
   constexpr int NP = 2 * MS + 1;                                  // power values per lane
   constexpr int kImg = 2 * FftLds<NS>::kElems;
-  constexpr int kHeads = (NP + 1) * 64;
+  constexpr int kHeads = (NP + 3) * 64;
   __shared__ __attribute__((aligned(16))) double smem[kImg > kHeads ? kImg : kHeads];
   cpx* img = reinterpret_cast<cpx*>(smem);
   const int lane0 = threadIdx.x;
@@ -390,14 +456,21 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
     cpx none[MS];
 #pragma unroll
     for (int m = 0; m < MS; ++m) none[m] = make_double2(0.0, 0.0);
-    real_power_halves<FD>(vp, none, false, park, img, tw, lane, pe, po);   // the window (FD / 8 + 1 taps) never folds
+    real_power_halves<FD, false>(vp, none, false, park, img, tw, lane, pe, po);   // the window never folds
+    // through LDS into strided order (p[t] = bin lane + 64 t): the main lobe the peel removes is a run of
+    // neighbouring bins, which then sit in different lanes and go in one or two steps of peel_largest()
     double p[NP];
     double tot = 0.0;
+    {
+      cpx* flat2 = reinterpret_cast<cpx*>(smem);
 #pragma unroll
-    for (int m = 0; m < MS; ++m) {
-      p[2 * m] = pe[m];
-      p[2 * m + 1] = po[m];
-      tot += pe[m] + po[m];
+      for (int m = 0; m < MS; ++m) flat2[lane + 64 * m] = make_double2(pe[m], po[m]);     // bins 2 j, 2 j + 1
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < 2 * MS; ++t) {
+        p[t] = smem[lane + 64 * t];
+        tot += p[t];
+      }
     }
     p[2 * MS] = -1.0;
     if (lane == 0) {
@@ -413,21 +486,13 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
       p[i] = hi;
       p[i + 1] = lo;
     }
-    double* heads = smem;                                         // [NP + 1][64]
+    double* heads = smem;                                         // [NP + 3][64]
     wave_sync();
 #pragma unroll
     for (int m = 0; m < NP; ++m) heads[m * 64 + lane] = p[m];
-    heads[NP * 64 + lane] = -1.0;
-    int taken = 0;
-    double cur = heads[lane];
-#pragma unroll 1
-    for (int it = 0; it <= bnd; ++it) {
-      const double wmx = wave_max(cur);
-      const unsigned long long vote = __ballot(cur == wmx);
-      const int winner = __ffsll((long long)vote) - 1;
-      taken += lane == winner ? 1 : 0;
-      cur = heads[taken * 64 + lane];
-    }
+#pragma unroll
+    for (int m = NP; m < NP + 3; ++m) heads[m * 64 + lane] = -1.0;
+    const int taken = peel_largest(heads, bnd + 1, lane);
     double low = 0.0;
 #pragma unroll
     for (int m = 0; m < NP; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;
