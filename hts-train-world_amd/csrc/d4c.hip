@@ -579,6 +579,7 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int64_t tf = b.total_f;
+  if (tab.window_length >= FD / 4) return WM_ERR_UNSUPPORTED;    // d4cb_band_kernel: taps fill half the packed operand at most
   static const int g1 = persistent_grid(c, d4cb_centroid_kernel<FD>, 64, (int64_t)1 << 40);
   static const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
   static const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);

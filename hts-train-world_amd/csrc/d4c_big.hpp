@@ -62,42 +62,54 @@ template <int K> __device__ __forceinline__ cpx mul_mj_pow(cpx z) {
 }
 
 // u_q[n] = (sum_p z[n + p NS] (-j)^(p q)) W_FD^(n q) for n = lane + 64 m, from the frame parked in the workgroup's
-// scratch row (xs[i] = sample i of the normalised-later frame): z[i] = xs[i] (s + j (i + 1)).  Quarters beyond the
-// window (p NS >= L) are skipped by wave-uniform branches.
+// scratch row (xs[i] = sample i of the normalised-later frame): z[i] = xs[i] (s + j (i + 1)).  P = the number of
+// quarters the window reaches into (ceil(L / NS)), a template argument so that the loads of a group of elements
+// are issued together: with a branch per quarter inside the element loop every load sits in its own block next
+// to its use, and an element costs up to three dependent trips to memory (48 per sub-transform).
+template <int FD, int Q, int P>
+__device__ __forceinline__ void d4cb_quarter_input_p(const double* xs, double s, cpx wl, int lane,
+                                                     cpx (&v)[D4cBig<FD>::MS]) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
+  constexpr int G = P == 1 ? MS : (P == 2 ? MS / 2 : MS / 4);     // elements per group: 12 to 16 loads in flight
+  const cpx w64 = cis64(4096 / FD);                               // W_FD^64
+  cpx w = wl;
+#pragma unroll
+  for (int g0 = 0; g0 < MS; g0 += G) {
+    double xv[P][G];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int m = 0; m < G; ++m) xv[p][m] = xs[lane + 64 * (g0 + m) + p * NS];
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      const double r = (double)(lane + 64 * (g0 + m) + 1);
+      cpx acc = make_double2(s * xv[0][m], r * xv[0][m]);
+      if (P > 1) acc = cadd(acc, mul_mj_pow<(1 * Q) & 3>(make_double2(s * xv[P > 1 ? 1 : 0][m], (r + NS) * xv[P > 1 ? 1 : 0][m])));
+      if (P > 2) acc = cadd(acc, mul_mj_pow<(2 * Q) & 3>(make_double2(s * xv[P > 2 ? 2 : 0][m], (r + 2 * NS) * xv[P > 2 ? 2 : 0][m])));
+      if (P > 3) acc = cadd(acc, mul_mj_pow<(3 * Q) & 3>(make_double2(s * xv[P > 3 ? 3 : 0][m], (r + 3 * NS) * xv[P > 3 ? 3 : 0][m])));
+      if (Q == 0) v[g0 + m] = acc;
+      if (Q == 1) v[g0 + m] = cmul(acc, w);
+      if (Q == 2) v[g0 + m] = cmul(acc, cmul(w, w));
+      if (Q == 3) v[g0 + m] = cmul(acc, cmul(cmul(w, w), w));
+      w = cmul(w, w64);
+    }
+  }
+}
+
 template <int FD, int Q>
 __device__ __forceinline__ void d4cb_quarter_input(const double* xs, int L, double s, cpx wl, int lane,
                                                    cpx (&v)[D4cBig<FD>::MS]) {
-  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
-  const cpx w64 = cis64(4096 / FD);                               // W_FD^64
+  constexpr int NS = D4cBig<FD>::NS;
   // fenced: the frame is read from memory again (not forwarded from the registers that were stored, which would
-  // have to live through the transforms in between), and the chain of twiddles is rebuilt per quarter
+  // have to live through the transforms in between), and the sample numbers and the chain of twiddles are
+  // rebuilt per quarter
   asm volatile("" ::: "memory");
-  lane = opaque_lane(lane);                                       // ... and so are the sample numbers n + 1
-  cpx w = make_double2(opaque_d(wl.x), opaque_d(wl.y));
-#pragma unroll
-  for (int m = 0; m < MS; ++m) {
-    const int n = lane + 64 * m;
-    const double r = (double)(n + 1);
-    const double x0 = xs[n];
-    cpx acc = make_double2(s * x0, r * x0);
-    if (NS < L) {
-      const double x1 = xs[n + NS];
-      acc = cadd(acc, mul_mj_pow<(1 * Q) & 3>(make_double2(s * x1, (r + NS) * x1)));
-    }
-    if (2 * NS < L) {
-      const double x2 = xs[n + 2 * NS];
-      acc = cadd(acc, mul_mj_pow<(2 * Q) & 3>(make_double2(s * x2, (r + 2 * NS) * x2)));
-    }
-    if (3 * NS < L) {
-      const double x3 = xs[n + 3 * NS];
-      acc = cadd(acc, mul_mj_pow<(3 * Q) & 3>(make_double2(s * x3, (r + 3 * NS) * x3)));
-    }
-    if (Q == 0) v[m] = acc;
-    if (Q == 1) v[m] = cmul(acc, w);
-    if (Q == 2) v[m] = cmul(acc, cmul(w, w));
-    if (Q == 3) v[m] = cmul(acc, cmul(cmul(w, w), w));
-    w = cmul(w, w64);
-  }
+  lane = opaque_lane(lane);
+  wl = make_double2(opaque_d(wl.x), opaque_d(wl.y));
+  if (L <= NS) d4cb_quarter_input_p<FD, Q, 1>(xs, s, wl, lane, v);           // wave-uniform
+  else if (L <= 2 * NS) d4cb_quarter_input_p<FD, Q, 2>(xs, s, wl, lane, v);
+  else if (L <= 3 * NS) d4cb_quarter_input_p<FD, Q, 3>(xs, s, wl, lane, v);
+  else d4cb_quarter_input_p<FD, Q, 4>(xs, s, wl, lane, v);
 }
 
 // u_0 from the frame still in registers (x[q] = sample lane + 64 q): no twiddles, and no trip to memory before the
@@ -440,17 +452,26 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
     const double cf0 = uniform_d(f0v > kFloorF0D4C ? f0v : kFloorF0D4C);
     const double* gd = GD + frame * (int64_t)kRow;
     const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
+    // the window has at most FD / 4 - 1 taps (launch_d4c_big checks): the upper half of the packed operand is zero.
+    // All loads are issued together with clamped indices (a branch per pair would make every pair a trip to memory).
     cpx vp[MS];
+    {
+      double ga[MS / 2], gb[MS / 2], na[MS / 2], nb[MS / 2];
 #pragma unroll
-    for (int m = 0; m < MS; ++m) {
-      vp[m] = make_double2(0.0, 0.0);
-      if (128 * m < wl) {                                         // wave-uniform
-        const int i0 = 2 * (lane + 64 * m);
-        double a0 = 0.0, a1 = 0.0;
-        if (i0 < wl) a0 = gd[center - hwl + i0] * tab.nuttall[i0];
-        if (i0 + 1 < wl) a1 = gd[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
-        vp[m] = make_double2(a0, a1);
+      for (int m = 0; m < MS / 2; ++m) {
+        const int i0 = imin(2 * (lane + 64 * m), wl - 1), i1 = imin(2 * (lane + 64 * m) + 1, wl - 1);
+        ga[m] = gd[center - hwl + i0];
+        gb[m] = gd[center - hwl + i1];
+        na[m] = tab.nuttall[i0];
+        nb[m] = tab.nuttall[i1];
       }
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        const int i0 = 2 * (lane + 64 * m);
+        vp[m] = make_double2(i0 < wl ? ga[m] * na[m] : 0.0, i0 + 1 < wl ? gb[m] * nb[m] : 0.0);
+      }
+#pragma unroll
+      for (int m = MS / 2; m < MS; ++m) vp[m] = make_double2(0.0, 0.0);
     }
     double pe[MS + 1], po[MS];
     cpx none[MS];
