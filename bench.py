@@ -20,6 +20,7 @@ from __future__ import annotations
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -58,7 +59,8 @@ def d4c_flops_per_voiced_frame(fs):
 # HBM-side bytes of the dominant kernel come from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # runs, tools/pmc_hbm.sh) stored in profiles/pmc_traffic.json together with a hash of the kernel's sources: when the
 # sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
-D4C_SOURCES = ("d4c.hip", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp", "partition.hpp", "wavesync.hpp")
+D4C_SOURCES = ("d4c.hip", "d4c_big.hpp", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp", "partition.hpp",
+               "wavesync.hpp")
 
 
 def kernel_source_hash():
@@ -372,8 +374,10 @@ def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps):
     per_frame, note = measured_traffic(fs)
     flops = d4c_flops_per_voiced_frame(fs)
     ok = d4c_avg_s > 0
+    fd = 2 ** (1 + int(math.log2(4.0 * fs / 47.0 + 1.0)))          # fft_size_d4c (d4c.cpp:341-343)
+    name = "d4c_kernel" if fd <= 2048 else "d4c_kernel scope = d4cb_centroid + d4cb_spectrum + d4cb_band + d4cb_output (fft %d)" % fd
     return {
-        "bound": "hbm", "kernel": "d4c_kernel",
+        "bound": "hbm", "kernel": name,
         "achieved": round(frames * bm["d4c"] / d4c_avg_s / 1e9, 3) if ok else None,
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(frames * bm["d4c"] / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if ok else None,
