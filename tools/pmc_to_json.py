@@ -45,7 +45,10 @@ def main():
     fkb, fl, name = total(fdir, "FETCH_SIZE")
     wkb, wl, _ = total(wdir, "WRITE_SIZE")
     assert fl and fl == wl, (fl, wl)
-    rec = {"kernel": (name or "d4c_kernel").split("(")[0], "fs": fs, "frames": frames, "launches": fl,
+    kname = (name or "d4c_kernel").split("(")[0]
+    if "d4cb_" in kname:
+        kname = "d4cb_centroid_kernel + d4cb_spectrum_kernel + d4cb_band_kernel (the D4C scope at fft 4096)"
+    rec = {"kernel": kname, "fs": fs, "frames": frames, "launches": fl,
            "fetch_kb": fkb / fl, "write_kb": wkb / wl, "source_sha": bench.kernel_source_hash(), "tag": tag,
            "files": "profiles/%s_pmc_fetch.csv, profiles/%s_pmc_write.csv" % (tag, tag),
            "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); 8-byte-per-lane accesses, not the 16-byte streaming "
