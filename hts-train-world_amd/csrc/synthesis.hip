@@ -324,6 +324,7 @@ template <int N>
 __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const FftTw<N>& tw, int lane,
                                               cpx (&mp)[N / 64 + 1]) {
   constexpr int M = N / 64, F = 2 * N, H = N;
+  lane = opaque_lane(lane);                    // the mirrored indices are rebuilt per call, not kept from the last one
   cpx v[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -395,14 +396,20 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
 
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
+__global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
     int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
-  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + H + 2];
+  // LEAN (fft_size 2048: 16 complex values per lane and array): to run two waves per SIMD nothing of a spectrum's
+  // size lives through a transform -- the interpolated envelope and aperiodicity are fetched again for the aperiodic
+  // half instead of being kept (68 registers), the periodic response waits in the response row it is headed for
+  // (32), and the log spectrum shares the LDS image of the transform that consumes it (8 KB: 9 workgroups per CU
+  // instead of 6).  One wave per SIMD had nothing to hide the LDS round trips of its transforms behind.
+  constexpr bool LEAN = F == 2048;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + (LEAN ? 0 : H + 2)];
   cpx* img = reinterpret_cast<cpx*>(smem);
-  double* ls = smem + 2 * FftLds<N>::kElems;
+  double* ls = LEAN ? smem : smem + 2 * FftLds<N>::kElems;
   const int lane0 = threadIdx.x;
   FftTw<N> tw;
   tw.init(lane0);
@@ -428,36 +435,55 @@ __global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
     const double* s1 = sp + (r.fbase + fc) * (int64_t)(H + 1);
     const double* a0 = ap + (r.fbase + ff) * (int64_t)(H + 1);
     const double* a1 = ap + (r.fbase + fc) * (int64_t)(H + 1);
-    double env[MB], rat[MB];
+    auto spectral = [&](double (&env)[MB], double (&rat)[MB]) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int k = m < M ? lane + 64 * m : H;
-      if (ff == fc) {
-        env[m] = fabs(s0[k]);
-        const double a = safe_ap(a0[k]);
-        rat[m] = a * a;
-      } else {
-        env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
-        const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
-        rat[m] = a * a;
+      for (int m = 0; m < MB; ++m) {
+        const int k = m < M ? lane + 64 * m : H;
+        if (ff == fc) {
+          env[m] = fabs(s0[k]);
+          const double a = safe_ap(a0[k]);
+          rat[m] = a * a;
+        } else {
+          env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
+          const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
+          rat[m] = a * a;
+        }
       }
+    };
+    double env_keep[LEAN ? 1 : MB], rat_keep[LEAN ? 1 : MB];
+    double rat0;
+    if constexpr (LEAN) {
+      const double a = ff == fc ? safe_ap(a0[0]) : (1.0 - wgt) * safe_ap(a0[0]) + wgt * safe_ap(a1[0]);   // bin 0, every lane
+      rat0 = uniform_d(a * a);
+    } else {
+      spectral(env_keep, rat_keep);
+      rat0 = __shfl(rat_keep[0], 0, 64);
     }
-    const double rat0 = __shfl(rat[0], 0, 64);
+    double* out = resp + (p - p_begin) * (int64_t)F;
 
     // ---- GetPeriodicResponse (:105-138) ----
-    double xp[M];                       // periodic c2r output, x-index i = 2n + c for n < N/2 (first half)
+    double xp[LEAN ? 1 : M];            // periodic c2r output, x-index i = 2n + c for n < N/2 (first half)
     double dc = 0.0;
     const bool periodic = !(cvuv <= 0.5 || rat0 > 0.999);
 #pragma unroll
-    for (int m = 0; m < M; ++m) xp[m] = 0.0;
+    for (int m = 0; m < (LEAN ? 1 : M); ++m) xp[m] = 0.0;
     if (periodic) {
       wave_sync();
+      auto log_periodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < M; ++m) {
+          ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
+      };
+      if constexpr (LEAN) {
+        double env[MB], rat[MB];
+        spectral(env, rat);
+        log_periodic(env, rat);
+      } else {
+        log_periodic(env_keep, rat_keep);
       }
-      if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
       wave_sync();
       cpx mp[MB];
       minimum_phase<N>(ls, img, tw, lane, mp);
@@ -487,22 +513,39 @@ __global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
       // fftshift + RemoveDCComponent (:73-82, :135-137): dc = sum of the shifted second half = x[0..H)
 #pragma unroll
       for (int m = 0; m < M / 2; ++m) {
-        xp[2 * m] = v[m].x;
-        xp[2 * m + 1] = v[m].y;
+        if constexpr (LEAN) {                                       // waits where it is headed for (every lane re-reads its own)
+          const int i0 = 2 * (lane + 64 * m);
+          *reinterpret_cast<cpx*>(out + i0 + H) = v[m];
+        } else {
+          xp[2 * m] = v[m].x;
+          xp[2 * m + 1] = v[m].y;
+        }
         dc += v[m].x + v[m].y;
       }
       dc = wave_sum(dc);
+      if constexpr (LEAN) dc = uniform_d(dc);
       wave_sync();
     }
 
     // ---- GetAperiodicResponse (:38-68) ----
     wave_sync();
+    {
+      auto log_aperiodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int k = m < M ? lane + 64 * m : H;
-      const double val = log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
-      if (m < M || lane == 0) ls[k] = val;
-      __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < MB; ++m) {
+          const int k = m < M ? lane + 64 * m : H;
+          const double val = log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
+          if (m < M || lane == 0) ls[k] = val;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if constexpr (LEAN) {
+        double env[MB], rat[MB];
+        spectral(env, rat);
+        log_aperiodic(env, rat);
+      } else {
+        log_aperiodic(env_keep, rat_keep);
+      }
     }
     wave_sync();
     cpx mp[MB];
@@ -510,11 +553,13 @@ __global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
     // GetNoiseSpectrum (:19-33)
     cpx v[M];
     {
+      // LEAN: the draws are fetched here (their addresses hang on a fenced lane), not ahead of the transforms above
+      const int ln = LEAN ? opaque_lane(lane) : lane;
       const int roff = r.roff;
       double sum = 0.0;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const int i0 = 2 * (lane + 64 * m);
+        const int i0 = 2 * (ln + 64 * m);
         const double n0 = i0 < noise_size ? randn_at(rtab, roff + i0) : 0.0;
         const double n1 = i0 + 1 < noise_size ? randn_at(rtab, roff + i0 + 1) : 0.0;
         v[m] = make_double2(n0, n1);
@@ -523,7 +568,7 @@ __global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
       const double avg = wave_sum(sum) / noise_size;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const int i0 = 2 * (lane + 64 * m);
+        const int i0 = 2 * (ln + 64 * m);
         if (i0 < noise_size) v[m].x -= avg;
         if (i0 + 1 < noise_size) v[m].y -= avg;
       }
@@ -540,15 +585,23 @@ __global__ __launch_bounds__(64, F > 1024 ? 1 : 2) void synth_pulse_kernel(
 
     // ---- response = (periodic * sqrt(noise_size) + aperiodic) / fft_size (:211-215), fftshifted ----
     const double sq = sqrt((double)noise_size);
-    double* out = resp + (p - p_begin) * (int64_t)F;
+    cpx xq[LEAN ? M / 2 : 1];
+    const int lo = LEAN ? opaque_lane(lane) : lane;   // LEAN: the DC remover's table is fetched here, not ahead of the transforms
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int m = 0; m < M / 2; ++m)
+        xq[m] = periodic ? *reinterpret_cast<const cpx*>(out + 2 * (lo + 64 * m) + H) : make_double2(0.0, 0.0);
+    }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const int n = lane + 64 * m;
+      const int n = lo + 64 * m;
       const int i0 = 2 * n;                           // x-index; shifted position j = (i + H) mod F
       double r0, r1;
       if (m < M / 2) {                                // i < H  ->  j = i + H (second half)
-        const double p0 = periodic ? xp[2 * m] - dc * dcr[i0 + H] : 0.0;
-        const double p1 = periodic ? xp[2 * m + 1] - dc * dcr[i0 + 1 + H] : 0.0;
+        const double x0 = LEAN ? xq[LEAN ? m : 0].x : xp[LEAN ? 0 : 2 * m];
+        const double x1 = LEAN ? xq[LEAN ? m : 0].y : xp[LEAN ? 0 : 2 * m + 1];
+        const double p0 = periodic ? x0 - dc * dcr[i0 + H] : 0.0;
+        const double p1 = periodic ? x1 - dc * dcr[i0 + 1 + H] : 0.0;
         r0 = (p0 * sq + v[m].x) / F;
         r1 = (p1 * sq + v[m].y) / F;
         out[i0 + H] = r0;
