@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
 
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
+__global__ __launch_bounds__(64, F == 1024 ? 3 : 2) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
     int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64, 2) void synth_pulse_kernel(
   // half instead of being kept (68 registers), the periodic response waits in the response row it is headed for
   // (32), and the log spectrum shares the LDS image of the transform that consumes it (8 KB: 9 workgroups per CU
   // instead of 6).  One wave per SIMD had nothing to hide the LDS round trips of its transforms behind.
-  constexpr bool LEAN = F == 2048;
+  constexpr bool LEAN = F == 2048 || F == 1024;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + (LEAN ? 0 : H + 2)];
   cpx* img = reinterpret_cast<cpx*>(smem);
   double* ls = LEAN ? smem : smem + 2 * FftLds<N>::kElems;
