@@ -112,7 +112,19 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : 3) void cheaptrick_kernel(
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
     linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane);
-    for (int i = lane; i <= H; i += 64) pw[i] = log(pw[i] + fabs(randn_at(rtab, roff + fg.L + i)) * kEps);
+    {
+      // the draws of all bins first (one trip to memory; a rolled loop made each bin wait for its own)
+      uint32_t rv[M + 1];
+#pragma unroll
+      for (int m = 0; m <= M; ++m) rv[m] = rtab[roff + fg.L + imin(lane + 64 * m, H)];
+#pragma unroll
+      for (int m = 0; m <= M; ++m) {
+        const int i = lane + 64 * m;
+        const double val = log(pw[imin(i, H)] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
+        if (m < M || lane == 0) pw[i] = val;
+        __builtin_amdgcn_sched_barrier(0);                        // one bin at a time: keeps the register peak low
+      }
+    }
     wave_sync();
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
