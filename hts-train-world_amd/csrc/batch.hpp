@@ -20,6 +20,16 @@ namespace wm {
 
 int wm_check(hipError_t e);   // maps to WM_ERR_HIP and records the message
 
+// Device memory of batches and stage workspaces comes from a process-wide cache of freed blocks (context.cpp):
+// the drop-in C API builds a batch per call signature, and hipMalloc / hipFree (which also synchronises the
+// device) per utterance were a third of its latency.  A block goes back to the cache when it is freed and is
+// handed out again for a request of its size class; callers free only memory whose users have finished or are
+// ordered on the stream that will use it next (DestroyBatch synchronises its context's stream first).
+hipError_t dev_alloc_bytes(void** p, size_t bytes);
+void dev_free(void* p);
+void dev_cache_trim(size_t keep_bytes);       // hipFree cached blocks until at most keep_bytes stay cached
+template <class T> inline hipError_t dev_alloc(T** p, size_t bytes) { return dev_alloc_bytes((void**)p, bytes); }
+
 struct Context {
   int device = 0;
   hipStream_t stream = nullptr;

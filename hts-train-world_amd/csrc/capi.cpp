@@ -37,12 +37,12 @@ using namespace wm;
 struct WorldMi355Context { Context c; };
 struct WorldMi355Batch { Batch b; };
 
-template <typename T> static int dev_alloc(T** p, size_t count) {
+template <typename T> static int alloc_items(T** p, size_t count) {
   *p = nullptr;
-  return wm_check(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+  return wm_check(wm::dev_alloc(p, sizeof(T) * (count ? count : 1)));
 }
 template <typename T> static int upload(T** p, const std::vector<T>& v) {
-  int rc = dev_alloc(p, v.size());
+  int rc = alloc_items(p, v.size());
   if (rc) return rc;
   if (v.empty()) return WM_OK;
   return wm_check(hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
@@ -96,8 +96,8 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   Context& c = h->c;
   hipStreamSynchronize(c.stream);
   c.timing_clear();
-  if (c.d_rng) hipFree(c.d_rng);
-  if (c.d_scratch) hipFree(c.d_scratch);
+  if (c.d_rng) wm::dev_free(c.d_rng);
+  if (c.d_scratch) wm::dev_free(c.d_scratch);
   if (c.h_pulse_info) hipHostFree(c.h_pulse_info);
   if (c.own_stream) hipStreamDestroy(c.stream);
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
@@ -180,10 +180,10 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
       for (int64_t i = b.f_off[u]; i < b.f_off[u + 1]; ++i) fu[i] = u;
   }
   unsigned char* base = nullptr;
-  int rc = wm_check(hipMalloc((void**)&base, at));
+  int rc = wm_check(wm::dev_alloc(&base, at));
   if (!rc) rc = wm_check(hipMemcpy(base, img.data(), init_bytes, hipMemcpyHostToDevice));
   if (rc) {
-    if (base) (void)hipFree(base);
+    if (base) wm::dev_free(base);
     delete hb;
     return rc;
   }
@@ -366,24 +366,50 @@ struct Workspace {
     const size_t bytes = sizeof(double) * (n ? n : 1);
     if (bytes > dev_cap[s]) {
       if (s == kX) x_valid = false;
-      if (dev[s]) (void)hipFree(dev[s]);
+      if (dev[s]) wm::dev_free(dev[s]);
       dev[s] = nullptr;
       const size_t cap = bytes + bytes / 4;
-      if (hipMalloc(&dev[s], cap) != hipSuccess) die("hipMalloc", WM_ERR_HIP);
+      if (wm::dev_alloc(&dev[s], cap) != hipSuccess) die("hipMalloc", WM_ERR_HIP);
       dev_cap[s] = cap;
     }
     return (double*)dev[s];
   }
+  // Pinned staging of one API call: regions are handed out one after another (no region is reused inside a call,
+  // so no copy has to be waited for before the next argument is staged) and the call ends with finish(): ONE
+  // stream synchronisation, then the host-side copies of the results.  Growing moves what the call has staged.
+  size_t stage_at = 0;                   // doubles in use by the current call
+  struct Pending { size_t off; double* flat; double** rows; size_t n; int n_rows, width; };
+  std::vector<Pending> pending;
   double* stage(size_t n) {
-    const size_t bytes = sizeof(double) * (n ? n : 1);
-    if (bytes > pinned_cap) {
-      if (pinned) (void)hipHostFree(pinned);
-      pinned = nullptr;
-      const size_t cap = bytes + bytes / 4;
-      if (hipHostMalloc(&pinned, cap, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc", WM_ERR_HIP);
+    const size_t need = sizeof(double) * (stage_at + n + 8);
+    if (need > pinned_cap) {
+      if (hipStreamSynchronize(default_context()->c.stream) != hipSuccess) die("staging", WM_ERR_HIP);
+      void* grown = nullptr;
+      const size_t cap = need + need / 2;
+      if (hipHostMalloc(&grown, cap, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc", WM_ERR_HIP);
+      if (pinned) {
+        memcpy(grown, pinned, sizeof(double) * stage_at);
+        (void)hipHostFree(pinned);
+      }
+      pinned = grown;
       pinned_cap = cap;
     }
-    return (double*)pinned;
+    double* r = (double*)pinned + stage_at;
+    stage_at += (n + 7) & ~(size_t)7;
+    return r;
+  }
+  void finish() {
+    if (hipStreamSynchronize(default_context()->c.stream) != hipSuccess) die("finish", WM_ERR_HIP);
+    for (const Pending& q : pending) {
+      const double* st = (const double*)pinned + q.off;
+      if (q.flat) {
+        if (q.n) memcpy(q.flat, st, sizeof(double) * q.n);
+      } else {
+        for (int i = 0; i < q.n_rows; ++i) memcpy(q.rows[i], st + (size_t)i * q.width, sizeof(double) * q.width);
+      }
+    }
+    pending.clear();
+    stage_at = 0;
   }
   WorldMi355Batch* batch(const WorldMi355Params& p, int xl, int fl, int yl) {
     ++clock;
@@ -417,14 +443,12 @@ void h2d(double* dst, const double* staged, size_t n) {
   if (n && hipMemcpyAsync(dst, staged, sizeof(double) * n, hipMemcpyHostToDevice, ws_stream()) != hipSuccess)
     die("H2D", WM_ERR_HIP);
 }
-// contiguous host array -> device slot (through the pinned staging buffer; waits for the copy: the staging buffer
-// is reused by the next argument)
+// contiguous host array -> device slot through a staging region of this call (asynchronous: see Workspace::stage)
 double* put(Slot s, const double* h, size_t n) {
   double* d = g_ws.device(s, n);
   double* st = g_ws.stage(n);
   if (n) memcpy(st, h, sizeof(double) * n);
   h2d(d, st, n);
-  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("H2D", WM_ERR_HIP);
   return d;
 }
 double* put_x(const double* x, size_t n) {
@@ -442,24 +466,23 @@ double* put_rows(Slot s, const double* const* rows, int n_rows, int width) {
   double* st = g_ws.stage(n);
   for (int i = 0; i < n_rows; ++i) memcpy(st + (size_t)i * width, rows[i], sizeof(double) * width);
   h2d(d, st, n);
-  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("H2D", WM_ERR_HIP);
   return d;
 }
-// device -> pinned staging (after the kernels on the stream); returns the staged data
-const double* fetch(const double* d, size_t n) {
+// device -> a staging region (after the kernels on the stream); the host copy happens in finish()
+size_t fetch(const double* d, size_t n) {
   double* st = g_ws.stage(n);
+  const size_t off = (size_t)(st - (double*)g_ws.pinned);
   if (n && hipMemcpyAsync(st, d, sizeof(double) * n, hipMemcpyDeviceToHost, ws_stream()) != hipSuccess)
     die("D2H", WM_ERR_HIP);
-  if (hipStreamSynchronize(ws_stream()) != hipSuccess) die("D2H", WM_ERR_HIP);
-  return st;
+  return off;
 }
 void get(const double* d, double* h, size_t n) {
-  const double* st = fetch(d, n);
-  if (n) memcpy(h, st, sizeof(double) * n);
+  const size_t off = fetch(d, n);
+  g_ws.pending.push_back({off, h, nullptr, n, 0, 0});
 }
 void get_rows(const double* d, double** rows, int n_rows, int width) {
-  const double* st = fetch(d, (size_t)n_rows * width);
-  for (int i = 0; i < n_rows; ++i) memcpy(rows[i], st + (size_t)i * width, sizeof(double) * width);
+  const size_t off = fetch(d, (size_t)n_rows * width);
+  g_ws.pending.push_back({off, nullptr, rows, 0, n_rows, width});
 }
 void run_or_die(const char* where, int rc) {
   if (rc) die(where, rc);
@@ -497,6 +520,7 @@ void Dio(const double* x, int x_length, int fs, const DioOption* option, double*
   run_or_die("Dio", WorldMi355Dio(b, dx, dt, df));
   get(dt, temporal_positions, nf);
   get(df, f0, nf);
+  g_ws.finish();
 }
 
 int GetSamplesForHarvest(int fs, int x_length, double frame_period) {  // harvest.cpp:1219-1221
@@ -522,6 +546,7 @@ void Harvest(const double* x, int x_length, int fs, const HarvestOption* option,
   run_or_die("Harvest", WorldMi355Harvest(b, dx, dt, df));
   get(dt, temporal_positions, nf);
   get(df, f0, nf);
+  g_ws.finish();
 }
 
 void StoneMask(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
@@ -537,6 +562,7 @@ void StoneMask(const double* x, int x_length, int fs, const double* temporal_pos
   double* dr = g_ws.device(kOut, (size_t)f0_length);
   run_or_die("StoneMask", WorldMi355StoneMask(b, dx, dt, df, dr));
   get(dr, refined_f0, (size_t)f0_length);
+  g_ws.finish();
 }
 
 int GetFFTSizeForCheapTrick(int fs, const CheapTrickOption* option) {   // cheaptrick.cpp:191-194
@@ -565,6 +591,7 @@ void CheapTrick(const double* x, int x_length, int fs, const double* temporal_po
   double* ds = g_ws.device(kSp, (size_t)f0_length * w);
   run_or_die("CheapTrick", WorldMi355CheapTrick(b, dx, dt, df, ds));
   get_rows(ds, spectrogram, f0_length, w);
+  g_ws.finish();
 }
 
 void InitializeD4COption(D4COption* option) { option->threshold = 0.85; }   // d4c.cpp:399-401
@@ -583,6 +610,7 @@ void D4C(const double* x, int x_length, int fs, const double* temporal_positions
   double* da = g_ws.device(kAp, (size_t)f0_length * w);
   run_or_die("D4C", WorldMi355D4C(b, dx, dt, df, da));
   get_rows(da, aperiodicity, f0_length, w);
+  g_ws.finish();
 }
 
 // ---- world/codec.h --------------------------------------------------------------------------------
@@ -607,6 +635,7 @@ void CodeSpectralEnvelope(const double* const* spectrogram, int f0_length, int f
   double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_dimensions);
   run_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(b, ds, number_of_dimensions, dc));
   get_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
+  g_ws.finish();
 }
 
 void DecodeSpectralEnvelope(const double* const* coded_spectral_envelope, int f0_length, int fs, int fft_size,
@@ -618,6 +647,7 @@ void DecodeSpectralEnvelope(const double* const* coded_spectral_envelope, int f0
   double* ds = g_ws.device(kSp, (size_t)f0_length * w);
   run_or_die("DecodeSpectralEnvelope", WorldMi355DecodeSpectralEnvelope(b, dc, number_of_dimensions, ds));
   get_rows(ds, spectrogram, f0_length, w);
+  g_ws.finish();
 }
 
 void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, int fft_size,
@@ -631,6 +661,7 @@ void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, 
   double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_aperiodicities);
   run_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(b, da, dc));
   get_rows(dc, coded_aperiodicity, f0_length, number_of_aperiodicities);
+  g_ws.finish();
 }
 
 // Positional meaning of the reference's DEFINITION (codec.cpp:237-238): the 4th argument is the number
@@ -647,6 +678,7 @@ void DecodeAperiodicity(const double* const* coded_aperiodicity, int f0_length, 
   double* da = g_ws.device(kAp, (size_t)f0_length * w);
   run_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(b, dc, da));
   get_rows(da, aperiodicity, f0_length, w);
+  g_ws.finish();
 }
 
 void Synthesis(const double* f0, int f0_length, const double* const* spectrogram,
@@ -664,6 +696,7 @@ void Synthesis(const double* f0, int f0_length, const double* const* spectrogram
   double* dy = g_ws.device(kY, (size_t)y_length);
   run_or_die("Synthesis", WorldMi355Synthesis(b, df, ds, da, dy));
   get(dy, y, (size_t)y_length);
+  g_ws.finish();
 }
 
 }  // extern "C"

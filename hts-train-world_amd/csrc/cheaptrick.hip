@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
 }
 
 template <int F>
-__global__ __launch_bounds__(64, F >= 4096 ? 1 : 3) void cheaptrick_kernel(
+__global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, double q1,

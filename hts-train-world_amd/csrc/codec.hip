@@ -245,7 +245,7 @@ static int codec_setup(Batch& b) {
   int rc = WM_OK;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
     if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   };
   {   // coding: frequency axis in mel (knots) -> uniform mel axis (queries), GetParametersForCoding :161-180
@@ -287,7 +287,7 @@ void codec_free(void* p) {
   if (!T) return;
   void* ptrs[] = {T->d_code_k, T->d_code_s, T->d_code_w, T->d_dec_k, T->d_dec_s, T->d_dec_w};
   for (void* q : ptrs)
-    if (q) (void)hipFree(q);
+    if (q) dev_free(q);
   delete T;
 }
 

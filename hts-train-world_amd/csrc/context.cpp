@@ -5,6 +5,10 @@
 
 #include <string>
 
+#include <mutex>
+#include <unordered_map>
+#include <iterator>
+
 #include "batch.hpp"
 #include "common.hpp"
 
@@ -16,6 +20,92 @@ int wm_check(hipError_t e) {
   if (e == hipSuccess) return WM_OK;
   g_last_error = std::string("HIP: ") + hipGetErrorString(e);
   return WM_ERR_HIP;
+}
+
+namespace {
+struct DevCache {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;          // size class -> block
+  std::unordered_map<void*, size_t> size_of;         // every live or cached block -> size class
+  size_t cached = 0;
+  size_t limit = (size_t)8 << 30;                    // cached (idle) bytes kept at most; WORLD_MI355_CACHE_MB
+  DevCache() {
+    if (const char* e = getenv("WORLD_MI355_CACHE_MB")) limit = (size_t)strtoull(e, nullptr, 10) << 20;
+  }
+};
+DevCache& dev_cache() {
+  static DevCache* c = new DevCache;                 // never destroyed: frees may come from static destructors
+  return *c;
+}
+// size classes: powers of two up to 1 MiB, eighths of a power of two above (at most 12.5 % over-allocation)
+size_t size_class(size_t bytes) {
+  if (bytes < 256) bytes = 256;
+  size_t p2 = 256;
+  while (p2 < bytes) p2 <<= 1;
+  if (p2 <= ((size_t)1 << 20)) return p2;
+  const size_t step = p2 >> 4;                       // p2/2 < bytes <= p2: steps of p2/16
+  return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+hipError_t dev_alloc_bytes(void** p, size_t bytes) {
+  DevCache& c = dev_cache();
+  const size_t cls = size_class(bytes);
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.free_blocks.find(cls);
+    if (it != c.free_blocks.end()) {
+      *p = it->second;
+      c.free_blocks.erase(it);
+      c.cached -= cls;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, cls);
+  if (e != hipSuccess) {                             // out of memory with idle blocks around: give them back and retry
+    (void)hipGetLastError();
+    dev_cache_trim(0);
+    e = hipMalloc(p, cls);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> g(c.mu);
+    c.size_of[*p] = cls;
+  }
+  return e;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  DevCache& c = dev_cache();
+  size_t over = 0;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.size_of.find(p);
+    if (it == c.size_of.end()) {                     // not ours (should not happen): plain free
+      (void)hipFree(p);
+      return;
+    }
+    c.free_blocks.emplace(it->second, p);
+    c.cached += it->second;
+    over = c.cached > c.limit ? c.limit / 2 : (size_t)-1;
+  }
+  if (over != (size_t)-1) dev_cache_trim(over);
+}
+
+void dev_cache_trim(size_t keep_bytes) {
+  DevCache& c = dev_cache();
+  std::vector<void*> victims;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    while (c.cached > keep_bytes && !c.free_blocks.empty()) {
+      auto it = std::prev(c.free_blocks.end());      // largest first
+      victims.push_back(it->second);
+      c.cached -= it->first;
+      c.size_of.erase(it->second);
+      c.free_blocks.erase(it);
+    }
+  }
+  for (void* q : victims) (void)hipFree(q);
 }
 const char* last_error() { return g_last_error.c_str(); }
 void set_error(const char* msg) { g_last_error = msg; }
@@ -57,14 +147,14 @@ int Context::ensure_rng(int64_t count) {
   int rc = wm_check(hipStreamSynchronize(stream));
   if (rc) return rc;
   uint32_t* grown = nullptr;
-  rc = wm_check(hipMalloc((void**)&grown, sizeof(uint32_t) * (size_t)cap));
+  rc = wm_check(dev_alloc(&grown, sizeof(uint32_t) * (size_t)cap));
   if (rc) return rc;
   if (rng_cap > 0)
     rc = wm_check(hipMemcpy(grown, d_rng, sizeof(uint32_t) * (size_t)rng_cap, hipMemcpyDeviceToDevice));
   if (!rc)
     rc = wm_check(hipMemcpy(grown + rng_cap, host.data(), sizeof(uint32_t) * (size_t)add, hipMemcpyHostToDevice));
-  if (rc) { (void)hipFree(grown); return rc; }
-  if (d_rng) (void)hipFree(d_rng);
+  if (rc) { dev_free(grown); return rc; }
+  if (d_rng) dev_free(d_rng);
   d_rng = grown;
   rng_cap = cap;
   return WM_OK;
@@ -74,10 +164,10 @@ int Context::ensure_scratch(int64_t doubles) {
   if (doubles <= scratch_cap) return WM_OK;
   int rc = wm_check(hipStreamSynchronize(stream));
   if (rc) return rc;
-  if (d_scratch) hipFree(d_scratch);
+  if (d_scratch) dev_free(d_scratch);
   d_scratch = nullptr;
   scratch_cap = 0;
-  rc = wm_check(hipMalloc((void**)&d_scratch, sizeof(double) * (size_t)doubles));
+  rc = wm_check(dev_alloc(&d_scratch, sizeof(double) * (size_t)doubles));
   if (rc) return rc;
   scratch_cap = doubles;
   return WM_OK;
@@ -163,7 +253,7 @@ void free_batch_buffers(Batch& b) {
                   b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_slot_off, b.d_dio_cand,
                   b.d_dio_score, b.d_syn_arena, b.d_pulse_rec, b.d_pulse_perm};
   for (void* p : ptrs)
-    if (p) hipFree(p);
+    if (p) dev_free(p);
   if (b.dio_host) dio_free_host(b.dio_host);
   b.dio_host = nullptr;
   if (b.harvest_ws) harvest_free(b.harvest_ws);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void d4c_offsets_kernel(const double* __restri
 // D4CLoveTrainSub (d4c.cpp:225-250): aperiodicity0 = cum[boundary1] / cum[boundary2]
 // over the power spectrum with bins <= boundary0 zeroed.
 template <int FL>
-__global__ __launch_bounds__(64, 2) void d4c_lovetrain_kernel(
+__global__ __launch_bounds__(64, FL >= 4096 ? 1 : 2) void d4c_lovetrain_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, int64_t total_frames,
@@ -584,10 +584,10 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   static const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
   static const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);
   const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
-  const size_t ws_rows = (size_t)imax(g1, imax(g2, g3));           // one scratch row per workgroup of the widest grid
+  const size_t ws_rows = (size_t)g1;                               // one scratch row per workgroup of the centroid kernel
   if (!b.d_d4c_big) {
     const size_t per = (size_t)4 * G::kQ + 2 * (size_t)G::kRow + 8;
-    int rc = wm_check(hipMalloc((void**)&b.d_d4c_big, sizeof(double) * (per * (size_t)(tf > 0 ? tf : 1) +
+    int rc = wm_check(dev_alloc(&b.d_d4c_big, sizeof(double) * (per * (size_t)(tf > 0 ? tf : 1) +
                                                                         ws_rows * D4cBigWs<FD>::kDoubles)));
     if (rc) return rc;
   }
@@ -602,11 +602,11 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   hipLaunchKernelGGL(d4cb_centroid_kernel<FD>, dim3(imin(cap, g1)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
                      b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, WS, C);
   hipLaunchKernelGGL(d4cb_spectrum_kernel<FD>, dim3(imin(cap, g2)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (const double*)C, WS, SC, GD);
+                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (const double*)C, SC, GD);
   const int64_t tasks = tf * tab.nap;
   const int cap3 = (int)(tasks < (int64_t)c.frame_grid * 4 ? tasks : (int64_t)c.frame_grid * 4);
   hipLaunchKernelGGL(d4cb_band_kernel<FD>, dim3(imax(1, imin(cap3, g3))), dim3(64), 0, st, d_f0, fs, tab, perm, nl,
-                     (const double*)GD, WS, COARSE);
+                     (const double*)GD, COARSE);
   const int64_t blocks = (tf + 3) / 4;
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
                      b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);
@@ -638,13 +638,13 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
                      0.012604 * cos(6.0 * kPi * tmp);
     }
     double* dw = nullptr;
-    rc = wm_check(hipMalloc((void**)&dw, sizeof(double) * (size_t)wl));
+    rc = wm_check(dev_alloc(&dw, sizeof(double) * (size_t)wl));
     if (rc) return rc;
     rc = wm_check(hipMemcpyAsync(dw, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
     if (!rc) rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
-    if (!rc) rc = wm_check(hipMalloc((void**)&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
-    if (!rc) rc = wm_check(hipMalloc((void**)&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
-    if (rc) { (void)hipFree(dw); return rc; }
+    if (!rc) rc = wm_check(dev_alloc(&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
+    if (!rc) rc = wm_check(dev_alloc(&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
+    if (rc) { dev_free(dw); return rc; }
     b.d_d4c_window = dw;
   }
   D4CTables tab;

@@ -9,22 +9,33 @@
 // fits that budget, with the 2049-bin arrays passing through HBM (16 KB per frame and array):
 //
 //   d4cb_centroid_kernel   GetStaticCentroid (d4c.cpp:125-142).  z = s x + j (i + 1) x as in d4c.hip; the 4096-point
-//                          complex transform is one radix-4 decimation-in-frequency step (a window of at most 2048
-//                          samples fills two of the four quarters): Z[4 j + q] = FFT_NS(u_q)[j],
-//                          u_q[n] = (z[n] + (-j)^q z[n + NS]) W_4096^(n q).  The pairing Z[k] Z[4096 - k] couples
-//                          q = 0 and q = 2 with themselves and q = 1 with q = 3.  Output: C[frame][q][j], the
-//                          centroid at bin 4 j + q (both sides summed).
+//                          complex transform is one radix-4 decimation-in-frequency step: Z[4 j + q] = FFT_NS(u_q)[j],
+//                          u_q[n] = (sum_p (-j)^(p q) z[n + p NS]) W_4096^(n q), p over the quarters the window
+//                          reaches into (typically one or two).  The pairing Z[k] Z[4096 - k] couples q = 0 and
+//                          q = 2 with themselves and q = 1 with q = 3.  The frame is built in registers, feeds u_0
+//                          from there and is re-read for u_2, u_1, u_3 from a scratch row of the workgroup (every
+//                          lane what it stored itself); E1 stays in registers while E3 is transformed.
+//                          Output: C[frame][q][j], the centroid at bin 4 j + q (both sides summed).
 //   d4cb_spectrum_kernel   GetSmoothedPowerSpectrum + GetStaticGroupDelay (:148-186).  The real transform of the
 //                          Hann frame: even bins are the real transform of 2048 points as it is (rfft_forward<NS>),
 //                          odd bins come from FFT_NS(v[n] W_2048^n) with the split pairing j <-> NS - 1 - j.
 //                          Output: GD[frame][0..2048].
 //   d4cb_band_kernel       GetCoarseAperiodicity (:192-223), one wavefront per (frame, band): the same even / odd
 //                          real transform of the windowed slice, the power spectrum's 2049 values sorted per lane,
-//                          the largest peeled.  Output: COARSE[frame][band].
+//                          the largest peeled (peel_largest, d4c.hip).  Output: COARSE[frame][band].
 //   d4cb_output_kernel     GetAperiodicity (:325-333) for the listed frames, the default row for all others.
 //
-// Frames whose smoothing mirror exceeds 4096 / 16 bins or whose window exceeds 2048 samples (d4c_is_usual) stay
-// with the one-kernel form (d4c_kernel<4096, 1, true>).
+// What these kernels were bound by, in the order it was found (MI355X, 256 utterances at 48 kHz, 272 794 frames;
+// rocprofv3 SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY per wave): memory round trips, not arithmetic.  A load that sits in a
+// wave-uniform `if` next to its use is a dependent trip to memory per element (48 per sub-transform in the first
+// version); values derived from the lane number or from a shared twiddle base are common subexpressions of all
+// four sub-transforms and were kept alive across them (spilled); a parked spectrum is two more trips.  With
+// loads issued in groups by window class, per-quarter fences on the lane and the twiddle base, and nothing
+// parked, centroid / spectrum / band take 8.2 / 6.8 / 8.8 ms (first version 12.9 / 8.7 / 13.5) and issue
+// instructions 85-100 % of the time at two waves per SIMD.
+//
+// Frames whose smoothing mirror exceeds 4096 / 16 bins (f0 >= fs / 16, d4c_is_usual) stay with the one-kernel form
+// (d4c_kernel<4096, 1, true>); any window length up to 4096 samples is handled here.
 #pragma once
 
 namespace wm {
@@ -129,8 +140,8 @@ __device__ __forceinline__ void d4cb_quarter0_input(const double (&x)[FD / 64], 
   }
 }
 
-// Scratch row of a workgroup (doubles): the frame (FD), then one NS-point complex spectrum (2 NS).
-template <int FD> struct D4cBigWs { static constexpr int kFrame = 0, kSpec = FD, kDoubles = FD + 2 * D4cBig<FD>::NS; };
+// Scratch row of a workgroup of the centroid kernel (doubles): the frame.
+template <int FD> struct D4cBigWs { static constexpr int kFrame = 0, kDoubles = FD; };
 
 template <int FD>
 __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
@@ -146,7 +157,6 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
   tw.init(lane0);
   double* ws = scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles;
   double* xs = ws + D4cBigWs<FD>::kFrame;
-  cpx* e1 = reinterpret_cast<cpx*>(ws + D4cBigWs<FD>::kSpec);
   const int n_run = *n_listed;
   FramePipe pipe;
   pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
         put(2, m, v[m].x * pt.y + v[m].y * pt.x, prev[m]);
       }
       // ---- q = 1 and q = 3: bins 4 j + 1 pair E1[j] with E3[NS - 1 - j], bins 4 j + 3 pair E3[j] with E1[NS - 1 - j];
-      //      E1 waits in the scratch row while E3 is transformed ----
+      //      E1 waits in registers while E3 is transformed ----
       d4cb_quarter_input<FD, 1>(xs, fg.L, s, wl, lane, v);
       fft_forward<NS>(v, img, tw, lane);
       cpx v1[MS];
@@ -249,25 +259,23 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
 // Power spectrum |X[k]|^2, k = 0 .. FD / 2, of a real frame of FD samples given as packed pairs in two halves:
 // va[m] = (x[2 n], x[2 n + 1]), vb[m] the same NS pairs later (n = lane + 64 m < NS); `folded` says whether vb holds
 // anything (wave-uniform).  pe[m] = power at bin 2 (lane + 64 m), pe[MS] = power at bin FD / 2 (every lane),
-// po[m] = power at bin 2 (lane + 64 m) + 1.  `park` is a scratch row of 2 NS doubles in global memory; every lane
-// re-reads only what it wrote itself; with PARK = false the odd operand stays in registers instead (64 more during
-// the first transform: a caller that has them saves 32 KB of memory traffic per call).  va / vb are consumed.
-template <int FD, bool PARK>
+// po[m] = power at bin 2 (lane + 64 m) + 1.  The operand of the odd bins waits in registers while the even bins are
+// transformed (64 registers; parking it in memory cost 32 KB of traffic per call and a trip there and back).
+// va / vb are consumed.
+template <int FD>
 __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx (&vb)[D4cBig<FD>::MS], bool folded,
-                                                  cpx* __restrict__ park, cpx* img, const FftTw<D4cBig<FD>::NS>& tw,
-                                                  int lane, double (&pe)[D4cBig<FD>::MS + 1],
-                                                  double (&po)[D4cBig<FD>::MS]) {
+                                                  cpx* img, const FftTw<D4cBig<FD>::NS>& tw, int lane,
+                                                  double (&pe)[D4cBig<FD>::MS + 1], double (&po)[D4cBig<FD>::MS]) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
   // the packed sequence vp of 2 NS points splits into even bins FFT_NS(va + vb) and odd bins
-  // FFT_NS((va - vb) W_{2 NS}^n); the odd operand waits in the scratch row while the even one is transformed
-  cpx odd[PARK ? 1 : MS];
+  // FFT_NS((va - vb) W_{2 NS}^n)
+  cpx odd[MS];
   {
     cpx w = tw.wsplit;                                            // W_{2 NS}^lane
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
       const cpx d = folded ? csub(va[m], vb[m]) : va[m];
-      if (PARK) park[lane + 64 * m] = cmul(d, w);
-      else odd[PARK ? 0 : m] = cmul(d, w);
+      odd[m] = cmul(d, w);
       if (folded) va[m] = cadd(va[m], vb[m]);
       w = cmul(w, tw.wstep());
     }
@@ -284,16 +292,14 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
     pe[MS] = s.x * s.x + s.y * s.y;
   }
   // odd bins: X[2 j + 1] from O[j] and O[NS - 1 - j] with the twiddle W_FD^(2 j + 1)
-#pragma unroll
-  for (int m = 0; m < MS; ++m) va[m] = PARK ? park[lane + 64 * m] : odd[PARK ? 0 : m];
-  fft_forward<NS>(va, img, tw, lane);
-  store_all<NS>(va, img, lane);
+  fft_forward<NS>(odd, img, tw, lane);
+  store_all<NS>(odd, img, lane);
   {
     const cpx w1 = cis_neg2pi(1.0 / (double)FD);                  // W_FD
     cpx w = cmul(tw.wsplit, w1);                                  // W_FD^(2 lane + 1)
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
-      const cpx a = va[m];
+      const cpx a = odd[m];
       const cpx b = cconj(img[NS - 1 - (lane + 64 * m)]);
       const cpx e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
       const cpx d = csub(a, b);
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, const double* __restrict__ C, double* scratch,
-    double* __restrict__ SC, double* __restrict__ GD) {
+    const int* __restrict__ n_listed, const double* __restrict__ C, double* __restrict__ SC,
+    double* __restrict__ GD) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, H = D4cBig<FD>::H, kQ = D4cBig<FD>::kQ;
   constexpr int kRow = D4cBig<FD>::kRow;
   constexpr int kBM = FD / 16;
@@ -326,7 +332,6 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
   const int lane0 = threadIdx.x;
   FftTw<NS> tw;
   tw.init(lane0);
-  cpx* park = reinterpret_cast<cpx*>(scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles + D4cBigWs<FD>::kSpec);
   const int n_run = *n_listed;
   FramePipe pipe;
   pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
         for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
       }
       double pe[MS + 1], po[MS];
-      real_power_halves<FD, false>(va, vb, fg.L > 2 * NS, park, img, tw, lane, pe, po);
+      real_power_halves<FD>(va, vb, fg.L > 2 * NS, img, tw, lane, pe, po);
       cpx* arr2 = reinterpret_cast<cpx*>(arr);
 #pragma unroll
       for (int m = 0; m < MS; ++m) arr2[lane + 64 * m] = make_double2(pe[m], po[m]);   // bins 2 j, 2 j + 1
@@ -427,7 +432,6 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
                                                           const int* __restrict__ perm,
                                                           const int* __restrict__ n_listed,
                                                           const double* __restrict__ GD,
-                                                          double* scratch,
                                                           double* __restrict__ COARSE) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kRow = D4cBig<FD>::kRow;
   constexpr int NP = 2 * MS + 1;                                  // power values per lane
@@ -438,7 +442,6 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
   const int lane0 = threadIdx.x;
   FftTw<NS> tw;
   tw.init(lane0);
-  cpx* park = reinterpret_cast<cpx*>(scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles + D4cBigWs<FD>::kSpec);
   const int64_t n_task = (int64_t)*n_listed * tab.nap;
   const int wl = tab.window_length, hwl = wl / 2;
   const int bnd = matlab_round(FD * 8.0 / wl);
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
     cpx none[MS];
 #pragma unroll
     for (int m = 0; m < MS; ++m) none[m] = make_double2(0.0, 0.0);
-    real_power_halves<FD, false>(vp, none, false, park, img, tw, lane, pe, po);   // the window never folds
+    real_power_halves<FD>(vp, none, false, img, tw, lane, pe, po);   // the window never folds
     // through LDS into strided order (p[t] = bin lane + 64 t): the main lobe the peel removes is a run of
     // neighbouring bins, which then sit in different lanes and go in one or two steps of peel_largest()
     double p[NP];

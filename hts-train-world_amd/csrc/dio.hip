@@ -479,7 +479,7 @@ static void dio_release(Batch& b) {
                    (void**)&b.d_dio_slot_off, (void**)&b.d_dio_slots, (void**)&b.d_dio_cand, (void**)&b.d_dio_score,
                    (void**)&b.d_dio_ws, (void**)&b.d_dio_H};
   for (void** p : ptrs) {
-    if (*p) (void)hipFree(*p);
+    if (*p) dev_free(*p);
     *p = nullptr;
   }
 }
@@ -546,7 +546,7 @@ static int dio_setup(Batch& b) {
   int rc = WM_OK;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
     if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   };
   up((void**)&b.d_dio_lowcut, H->lowcut.data(), sizeof(double) * H->lowcut.size());
@@ -562,7 +562,7 @@ static int dio_setup(Batch& b) {
   up((void**)&b.d_dio_ev_off, b.dio_ev_off.data(), sizeof(int64_t) * b.dio_ev_off.size());
   auto al = [&](void** dst, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
   };
   al((void**)&b.d_dio_mean, sizeof(double) * (size_t)b.n_utt);
   al((void**)&b.d_dio_mean_part, sizeof(double) * (size_t)b.n_utt * kMeanTiles);
@@ -618,7 +618,7 @@ static int dio_setup(Batch& b) {
       rc = wm_check(hipGetLastError());
       if (!rc) rc = wm_check(hipStreamSynchronize(st));
     }
-    if (d_desc) (void)hipFree(d_desc);
+    if (d_desc) dev_free(d_desc);
   }
   if (rc) {
     // nothing half-built stays behind: a retry starts from scratch instead of leaking H and the buffers above
@@ -733,7 +733,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        (int*)nullptr, d_t, d_f0);
   } else {
     if (!b.d_dio_edges) {
-      rc = wm_check(hipMalloc((void**)&b.d_dio_edges, sizeof(int) * 2 * (size_t)edge_cap * (size_t)b.n_utt));
+      rc = wm_check(dev_alloc(&b.d_dio_edges, sizeof(int) * 2 * (size_t)edge_cap * (size_t)b.n_utt));
       if (rc) return rc;
     }
     hipLaunchKernelGGL(dio_fix_kernel<false>, dim3(b.n_utt), dim3(256), 0, st, b.d_f_off, b.d_dio_cand, b.d_dio_score,

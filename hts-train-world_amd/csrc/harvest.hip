@@ -1121,13 +1121,13 @@ static int hv_setup(Batch& b) {
   int rc = WM_OK;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
     if (!rc) W->owned.push_back(*dst);
     if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   };
   auto al = [&](void** dst, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
     if (!rc) W->owned.push_back(*dst);
   };
   up((void**)&W->d_ylen, W->ylen.data(), sizeof(int) * (size_t)n_utt);
@@ -1207,7 +1207,7 @@ static int hv_setup(Batch& b) {
 void harvest_free(void* p) {
   HarvestWs* W = (HarvestWs*)p;
   if (!W) return;
-  for (void* q : W->owned) (void)hipFree(q);
+  for (void* q : W->owned) dev_free(q);
   delete W;
 }
 

@@ -222,7 +222,7 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   const int64_t resident = (int64_t)c.num_cu * per_cu;
   const int grid = (int)(tf < resident ? tf : resident);
   if (!b.d_sm_twid) {
-    int rc = wm_check(hipMalloc(&b.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
+    int rc = wm_check(dev_alloc(&b.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
     if (rc) return rc;
     hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)b.d_sm_twid);
   }

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
 
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64, F == 1024 ? 3 : 2) void synth_pulse_kernel(
+__global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
     int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
@@ -699,12 +699,12 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
     const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
     unsigned char* base = nullptr;
-    rc = wm_check(hipMalloc((void**)&base, at));
+    rc = wm_check(dev_alloc(&base, at));
     if (rc) return rc;
     if (!c.h_pulse_info) {            // per context: two pinned, device-visible integers
       rc = wm_check(hipHostMalloc((void**)&c.h_pulse_info, sizeof(int64_t) * 2, hipHostMallocMapped));
       if (!rc) rc = wm_check(hipHostGetDevicePointer((void**)&c.d_pulse_info, c.h_pulse_info, 0));
-      if (rc) { (void)hipFree(base); return rc; }
+      if (rc) { dev_free(base); return rc; }
     }
     b.d_syn_arena = base;
     b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
@@ -757,15 +757,15 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   rc = c.ensure_scratch(chunk * F);
   if (rc) return rc;
   if (total_p > b.pulse_rec_cap) {
-    if (b.d_pulse_rec) (void)hipFree(b.d_pulse_rec);
+    if (b.d_pulse_rec) dev_free(b.d_pulse_rec);
     b.d_pulse_rec = nullptr;
     b.pulse_rec_cap = 0;
-    if (b.d_pulse_perm) (void)hipFree(b.d_pulse_perm);
+    if (b.d_pulse_perm) dev_free(b.d_pulse_perm);
     b.d_pulse_perm = nullptr;
     const int64_t cap = total_p + total_p / 8 + 64;
-    rc = wm_check(hipMalloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
+    rc = wm_check(dev_alloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
     if (rc) return rc;
-    rc = wm_check(hipMalloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
+    rc = wm_check(dev_alloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
     if (rc) return rc;
     b.pulse_rec_cap = cap;
   }

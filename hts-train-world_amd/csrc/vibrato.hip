@@ -270,7 +270,7 @@ struct VibWs {
 void vibrato_free(void* p) {
   VibWs* W = (VibWs*)p;
   if (!W) return;
-  for (void* q : W->owned) (void)hipFree(q);
+  for (void* q : W->owned) dev_free(q);
   delete W;
 }
 
@@ -289,7 +289,7 @@ int launch_vibrato(Batch& b, const float* d_lf0, const int* seg_utt_off, const i
       for (int64_t s = soff[(size_t)u]; s < soff[(size_t)u + 1]; ++s) sutt[(size_t)s] = u;
     auto al = [&](void** dst, size_t bytes) {
       if (rc) return;
-      rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+      rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
       if (!rc) W->owned.push_back(*dst);
     };
     const size_t tf = (size_t)b.total_f;
@@ -317,7 +317,7 @@ int launch_vibrato(Batch& b, const float* d_lf0, const int* seg_utt_off, const i
   double* d_sp = nullptr;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (rc) return;
-    rc = wm_check(hipMalloc(dst, bytes ? bytes : 8));
+    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
     if (!rc && bytes) rc = wm_check(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
   };
   up((void**)&d_soff, seg_utt_off, sizeof(int) * ((size_t)b.n_utt + 1));
@@ -341,7 +341,7 @@ int launch_vibrato(Batch& b, const float* d_lf0, const int* seg_utt_off, const i
   if (!rc) rc = wm_check(hipMemcpyAsync(&too_long, W.d_too_long, sizeof(int), hipMemcpyDeviceToHost, st));
   if (!rc) rc = wm_check(hipStreamSynchronize(st));       // the segment arrays are call-local
   for (void* p : {(void*)d_soff, (void*)d_ss, (void*)d_se, (void*)d_sp})
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p);
   if (n_too_long) *n_too_long = too_long;
   return rc;
 }
