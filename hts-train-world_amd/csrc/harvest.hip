@@ -240,11 +240,17 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bfr
   }
   __shared__ int sAB[8];
   if (staged && ok) {                                           // uniform: one utterance, same lists
-    // eight searches per workgroup (four lists, first and last query time), one lane each
-    if (threadIdx.x < 8) {
-      const int ty = threadIdx.x >> 1;
-      const int64_t fq = (threadIdx.x & 1) ? frl : fr0;
-      sAB[threadIdx.x] = zc_upper(ev + (int64_t)ty * cap, nint[ty], m.afs, (int)(fq - boff[u0]) * 1 / 1000.0);
+    // eight searches per workgroup (four lists, first and last query time), 32 lanes each (zc_upper_group32:
+    // three dependent loads per search; one lane per search walked fifteen, the kernel's whole latency)
+    {
+      const int sr = threadIdx.x >> 5, ty = sr >> 1;
+      const int64_t fq = (sr & 1) ? frl : fr0;
+      int nty = nint[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) nty = ty == q ? nint[q] : nty;
+      const int r = zc_upper_group32(ev + (int64_t)ty * cap, nty, m.afs, (int)(fq - boff[u0]) * 1 / 1000.0,
+                                     threadIdx.x & 31, (threadIdx.x & 32) != 0);
+      if ((threadIdx.x & 31) == 0) sAB[sr] = r;
     }
   }
   __syncthreads();
