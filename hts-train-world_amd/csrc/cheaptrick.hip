@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "fft.hpp"
 #include "frame.hpp"
+#include "partition.hpp"
 #include "spectrum.hpp"
 
 namespace wm {
@@ -53,16 +54,31 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
   }
 }
 
-template <int F>
+// Mirror margin of the spectrum array: LinearSmoothing (width 2 f0 / 3) mirrors int(width F / fs) + 1 bins and
+// DCCorrection touches 2 + int(f0 F / fs).  Sized for any f0 up to fs / 2 (F / 3 + 2 bins) the array is 25 KB at
+// fft 2048 and holds the kernel at 1.5 waves per SIMD, so the frames are split as in D4C: the usual ones
+// (f0 below (F / 8 - 2) fs / F: 1.97 kHz at 16 kHz, 5.95 kHz at 48 kHz) run with F / 8 bins of margin, i.e. within
+// the FFT image's own LDS, the others (WIDE) with the full margin.  Same code, same results.
+template <int F, bool WIDE> struct CtMargin { static constexpr int kBM = WIDE ? (((F / 3 + 2) + 1) & ~1) : F / 8; };
+__host__ __device__ inline double ct_frame_f0(double f0v, int fs, int F) {
+  const double f0_floor = 3.0 * fs / (F - 3.0);              // cheaptrick.cpp:196-198
+  return !(f0v > f0_floor) ? kDefaultF0 : f0v;               // f0 <= floor (cheaptrick.cpp:217); NaN too
+}
+struct CtUsualPred {
+  const double* f0;
+  int fs, F;
+  __device__ bool operator()(int i) const { return 2 + (int)(ct_frame_f0(f0[i], fs, F) * F / fs) <= F / 8; }
+};
+
+template <int F, bool WIDE>
 __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, double q1,
-    int64_t total_frames, double* __restrict__ sp) {
+    int64_t total_frames, const int* __restrict__ perm, const int* __restrict__ n_usual,
+    double* __restrict__ sp) {
   constexpr int N = F / 2, M = N / 64, H = F / 2;
-  // mirror margin of the smoothing (width 2 f0 / 3: int(width F / fs) + 1 bins) and of DCCorrection
-  // (2 + int(f0 F / fs) bins) for any f0 up to fs / 2
-  constexpr int kBM = ((F / 3 + 2) + 1) & ~1;
+  constexpr int kBM = CtMargin<F, WIDE>::kBM;
   constexpr int kImg = 2 * FftLds<N>::kElems;                 // doubles
   constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
   constexpr int kTot = kImg > kRegion ? kImg : kRegion;
@@ -74,14 +90,15 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
   FftTw<N> tw;
   tw.init(lane0);
 
-  WM_FOR_EACH_FRAME(frame, total_frames) {
+  const int n_us = *n_usual;
+  const int* list = WIDE ? perm + n_us : perm;                 // usual frames first, then the wide ones
+  const int64_t n_list = WIDE ? total_frames - n_us : n_us;
+  WM_FOR_EACH_LISTED(frame, list, n_list) {
     const int lane = opaque_lane(lane0);
     const int fs = opaque_uniform(fs_arg);
     tw.fence();
-    const double f0_floor = 3.0 * fs / (F - 3.0);              // cheaptrick.cpp:196-198
     const int u = frame_utt[frame];
-    const double f0v = f0[frame];
-    const double cf0 = uniform_d(!(f0v > f0_floor) ? kDefaultF0 : f0v);   // f0 <= floor (cheaptrick.cpp:217); NaN too
+    const double cf0 = uniform_d(ct_frame_f0(f0[frame], fs, F));
     const int roff = rng_off[frame];
     cpx v[M];
 
@@ -175,13 +192,18 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
   if (grid <= 0) return 0;
 #define WM_CT_CASE(FF)                                                                                   \
   case FF: {                                                                                             \
-    static const int per_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF>, 64, (int64_t)1 << 40);        \
-    hipLaunchKernelGGL(cheaptrick_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,   \
-                       b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng, b.p.fs, b.p.q1,   \
-                       tf, d_sp);                                                                        \
+    static const int per_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, false>, 64, (int64_t)1 << 40); \
+    static const int perw_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, true>, 64, (int64_t)1 << 40); \
+    hipLaunchKernelGGL((cheaptrick_kernel<FF, false>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,     \
+                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng,        \
+                       b.p.fs, b.p.q1, tf, (const int*)b.d_perm, (const int*)b.d_part_n, d_sp);          \
+    hipLaunchKernelGGL((cheaptrick_kernel<FF, true>), dim3(imin(grid, perw_)), dim3(64), 0, st, d_x,     \
+                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng,        \
+                       b.p.fs, b.p.q1, tf, (const int*)b.d_perm, (const int*)b.d_part_n, d_sp);          \
   } break;
   {
   TimedScope ts_(b.ctx, "cheaptrick_kernel");
+  launch_partition(st, CtUsualPred{d_f0, b.p.fs, F}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
   switch (F) {
     WM_CT_CASE(512)       // fs <= 12.8 kHz (GetFFTSizeForCheapTrick, cheaptrick.cpp:191-194)
     WM_CT_CASE(1024)

@@ -348,6 +348,34 @@ def test_d4c_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
     np.testing.assert_array_equal(got2, got)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_cheaptrick_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
+    """CheapTrick takes any f0 the caller hands it (cheaptrick.cpp:217 only replaces values at or below its floor).
+    Frames whose smoothing mirror fits fft/8 bins run with the small margins, the others (f0 of a few kHz: a raised
+    f0_ceil, or another estimator's output) with the full ones; both beside each other in one call."""
+    torch, W, ctx = gpu
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    x = sd.make_utterance(71, fs, duration=0.6)
+    t, _ = oracle.dio(x, fs)
+    nf = len(t)
+    F = oracle.cheaptrick_fft_size(fs)
+    edge = (F // 8 - 2) * fs / F               # the largest f0 of the usual instantiation
+    f0 = np.full(nf, 200.0)
+    f0[0::6] = edge - 1.0
+    f0[1::6] = edge + 1.0
+    f0[2::6] = fs / 4.0
+    f0[3::6] = fs / 3.0                # (towards fs / 2 DCCorrection reads past the half spectrum: undefined in the reference)
+    f0[4::6] = 0.0
+    want = oracle.cheaptrick(x, fs, t, f0)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    got = b.cheaptrick(dev(x), dev(t), dev(f0)).cpu().numpy()
+    b.close()
+    sp_close(got, want)
+    got2 = pkg.capi.cheaptrick(x, fs, t, f0)
+    np.testing.assert_array_equal(got2, got)
+
+
 @pytest.mark.parametrize("thr", [0.0, -1.0])
 def test_d4c_threshold_zero_with_bad_samples(gpu, oracle, thr):
     """With a threshold <= 0 D4CLoveTrain cannot skip a voiced frame (its ratio is >= 0, zero is ruled out by the
