@@ -99,6 +99,10 @@ def parse():
                          "--gpus N > 1 the script itself starts N rank processes before anything touches the GPU")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prewarm", type=float, default=10.0,
+                    help="seconds of the same step run untimed before the warm-up steps (0 = none): an MI355X takes "
+                         "about ten seconds of load to reach its sustained clock (tools/step_trace.py: 16.9 ms per step, "
+                         "then 16.0); the first steps are timed as well and reported as clock_ramp.cold_ms_per_step")
     ap.add_argument("--utts", type=int, default=0, help="utterances per GPU (sweep: of the whole corpus); 0 = the workload's own")
     ap.add_argument("--dur", type=float, nargs=2, default=(2.0, 8.0))
     ap.add_argument("--fs", type=int, default=16000, choices=(16000, 48000),
@@ -254,6 +258,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp = clock_ramp(step, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
     for _ in range(args.warmup):
         step()
     barrier()
@@ -296,6 +301,8 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if ramp:
+            line["clock_ramp"] = ramp
         if shared_gpu or (world > 1 and args.backend == "gloo"):
             line["config"]["note"] = "rehearsal: %d ranks over gloo on %d GPU(s)" % (world, torch.cuda.device_count())
         line["host_inclusive"] = hi
@@ -347,6 +354,27 @@ def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world):
             "layout": "pinned host int16 waveforms up (%d B/frame), float32 f0/sp/ap + int16 resynthesis down (%d B/frame); "
                       "two slots, uploads / kernels / downloads on three streams" % (up // max(1, frames), down // max(1, frames)),
             "pcie_gbs": round((up + down) * steps / dt / 1e9, 2)}
+
+
+def clock_ramp(step, barrier, seconds, steps):
+    """Time the first `steps` steps as they come (after one untimed step that takes the first-call allocations),
+    then keep stepping untimed until `seconds` have passed.  Returns the `clock_ramp` object of the JSON line."""
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    n = max(1, min(steps, 5))
+    for _ in range(n):
+        step()
+    barrier()
+    cold = (time.perf_counter() - t0) / n
+    t1 = time.perf_counter()
+    while time.perf_counter() - t1 < seconds:
+        for _ in range(8):
+            step()
+        barrier()
+    return {"prewarm_s": seconds, "cold_ms_per_step": round(cold * 1e3, 3),
+            "note": "value is measured after prewarm_s seconds of the same step (sustained clock); cold_ms_per_step is "
+                    "the first %d steps of the process" % n}
 
 
 ANALYSIS_KERNELS = ("dio_lowcut_kernel", "dio_band_kernel", "dio_candidate_kernel", "dio_fix_kernel", "stonemask_kernel",
@@ -565,6 +593,7 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp = clock_ramp(step, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
     for _ in range(args.warmup):
         step()
     barrier()
@@ -612,6 +641,8 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
                              "unit": "GB/s", "frac": round(value / world * bpf / 1e9 / HBM_PEAK_GBS, 7),
                              "traffic": None, "bytes_per_unit": bpf, "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
                 "cpu_baseline": None}
+        if ramp:
+            line["clock_ramp"] = ramp
         if world == 1 and not args.no_cpu_baseline and args.workload == "harvest":
             from oracle.bindings import Oracle, Reference
             lib = Reference() if Reference.available() else Oracle()

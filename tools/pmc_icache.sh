@@ -4,7 +4,7 @@ fs=${2:-16000}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcic_$tag
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_IFETCH -d gpurun_out/pmcic_$tag -o ic --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline $BENCH_ARGS > gpurun_out/${tag}_pmc_ic.json 2> gpurun_out/${tag}_pmc_ic.err && echo ic ok
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_IFETCH -d gpurun_out/pmcic_$tag -o ic --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline --prewarm 0 $BENCH_ARGS > gpurun_out/${tag}_pmc_ic.json 2> gpurun_out/${tag}_pmc_ic.err && echo ic ok
 find gpurun_out/pmcic_$tag -name "*counter_collection.csv" -exec cp {} gpurun_out/${tag}_pmc_ic.csv \;
 python3 - <<PY
 import csv, collections

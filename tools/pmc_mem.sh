@@ -4,7 +4,7 @@ fs=${2:-16000}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcmem_$tag
-timeout -k 10 150 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCC_HIT TCC_MISS -d gpurun_out/pmcmem_$tag -o m --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline $BENCH_ARGS > gpurun_out/${tag}_pmc_mem.json 2> gpurun_out/${tag}_pmc_mem.err && echo mem ok
+timeout -k 10 150 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCC_HIT TCC_MISS -d gpurun_out/pmcmem_$tag -o m --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline --prewarm 0 $BENCH_ARGS > gpurun_out/${tag}_pmc_mem.json 2> gpurun_out/${tag}_pmc_mem.err && echo mem ok
 find gpurun_out/pmcmem_$tag -name "*counter_collection.csv" -exec cp {} gpurun_out/${tag}_pmc_mem.csv \;
 python3 - <<PY
 import csv, collections

@@ -5,7 +5,7 @@ fs=${2:-16000}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcsq_$tag
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d gpurun_out/pmcsq_$tag -o sq --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline $BENCH_ARGS > gpurun_out/${tag}_pmc_sq.json 2> gpurun_out/${tag}_pmc_sq.err && echo sq ok
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d gpurun_out/pmcsq_$tag -o sq --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline --prewarm 0 $BENCH_ARGS > gpurun_out/${tag}_pmc_sq.json 2> gpurun_out/${tag}_pmc_sq.err && echo sq ok
 find gpurun_out/pmcsq_$tag -name "*counter_collection.csv" -exec cp {} gpurun_out/${tag}_pmc_sq.csv \;
 python3 - <<PY
 import csv, collections

@@ -4,7 +4,7 @@ fs=${2:-16000}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcsq2_$tag
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d gpurun_out/pmcsq2_$tag -o sq --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline $BENCH_ARGS > gpurun_out/${tag}_pmc_sq2.json 2> gpurun_out/${tag}_pmc_sq2.err && echo sq2 ok
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d gpurun_out/pmcsq2_$tag -o sq --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts ${UTTS:-64} --no-cpu-baseline --prewarm 0 $BENCH_ARGS > gpurun_out/${tag}_pmc_sq2.json 2> gpurun_out/${tag}_pmc_sq2.err && echo sq2 ok
 find gpurun_out/pmcsq2_$tag -name "*counter_collection.csv" -exec cp {} gpurun_out/${tag}_pmc_sq2.csv \;
 python3 - <<PY
 import csv, collections

@@ -8,9 +8,9 @@ fs=${2:-16000}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag gpurun_out/pmcf_$tag gpurun_out/pmcw_$tag
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o ks --output-format csv -- python3 bench.py --fs $fs --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err && echo stats ok && \
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmcf_$tag -o f --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts 64 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.json 2> gpurun_out/${tag}_pmc_fetch.err && echo fetch ok && \
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmcw_$tag -o w --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts 64 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.json 2> gpurun_out/${tag}_pmc_write.err && echo write ok
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o ks --output-format csv -- python3 bench.py --fs $fs --steps 3 --warmup 1 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err && echo stats ok && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmcf_$tag -o f --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts 64 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_pmc_fetch.json 2> gpurun_out/${tag}_pmc_fetch.err && echo fetch ok && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmcw_$tag -o w --output-format csv -- python3 bench.py --fs $fs --steps 1 --warmup 0 --utts 64 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_pmc_write.json 2> gpurun_out/${tag}_pmc_write.err && echo write ok
 find gpurun_out/prof_$tag -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;
 find gpurun_out/prof_$tag -name "*kernel_trace.csv" -exec cp {} gpurun_out/${tag}_kernel_trace.csv \;
 find gpurun_out/pmcf_$tag -name "*counter_collection.csv" -exec cp {} gpurun_out/${tag}_pmc_fetch.csv \;
