@@ -272,6 +272,7 @@ def main():
     ctx.timing_enable(False)
     elapsed_max, total_frames = reduce_over_ranks(torch, dist, world, args.backend, elapsed, frames)
     hi = host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world)
+    hic = host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=(50, 25))
 
     if rank == 0:
         value = total_frames * args.steps / elapsed_max
@@ -306,6 +307,7 @@ def main():
         if shared_gpu or (world > 1 and args.backend == "gloo"):
             line["config"]["note"] = "rehearsal: %d ranks over gloo on %d GPU(s)" % (world, torch.cuda.device_count())
         line["host_inclusive"] = hi
+        line["host_inclusive_coded"] = hic
         if cpu_all:
             line["cpu_baseline_all_cores"] = cpu_all
         if parity:
@@ -316,13 +318,13 @@ def main():
         dist.destroy_process_group()
 
 
-def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world):
+def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=None):
     """The same step fed from and drained to pinned HOST memory in the on-disk types (int16 samples up; float32
     f0 / sp / ap and int16 resynthesised samples down), double-buffered on copy streams beside the kernels
     (hts-train-world_amd/pipeline.py).  Reported beside `value`, never as it (the metric
     "including H2D of waveforms and D2H of features")."""
     pl = pkg.pipeline
-    pipe = pl.HostPipeline(ctx, pkg.world.default_params(fs, fp), [len(x) for x in xs], synthesis=True)
+    pipe = pl.HostPipeline(ctx, pkg.world.default_params(fs, fp), [len(x) for x in xs], synthesis=True, coded=coded)
     x16 = pl.to_int16(np.concatenate(xs))
     for xb in pipe.x_pinned:                        # the waveforms wait in pinned memory, as decoded wav payloads would
         xb.numpy()[:] = x16
@@ -351,8 +353,10 @@ def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world):
     dt_max, total = reduce_over_ranks(torch, dist, world, args.backend, dt, frames)
     return {"value": round(total * steps / dt_max, 1), "unit": "frames/s", "ms_per_step": round(dt_max / steps * 1e3, 3),
             "overlapped": True, "steps": steps,
-            "layout": "pinned host int16 waveforms up (%d B/frame), float32 f0/sp/ap + int16 resynthesis down (%d B/frame); "
-                      "two slots, uploads / kernels / downloads on three streams" % (up // max(1, frames), down // max(1, frames)),
+            "layout": "pinned host int16 waveforms up (%d B/frame), float32 %s + int16 resynthesis down (%d B/frame); "
+                      "two slots, uploads / kernels / downloads on three streams"
+                      % (up // max(1, frames), "lf0/mgc[%d]/bap[%d] (the recipe's coded features)" % coded if coded else "f0/sp/ap",
+                         down // max(1, frames)),
             "pcie_gbs": round((up + down) * steps / dt / 1e9, 2)}
 
 

@@ -5,6 +5,8 @@ pinned copies.  The types on the wire are the on-disk ones of the reference's CL
 
     in   int16 samples (the wav payload; x = s / 32768 is formed on the device, test/audioio.cpp:236-249)   2 B/sample
     out  float32 f0 [T], sp [T][F/2+1], ap [T][F/2+1] (test/analysis.cpp:360-390)                            4 B/value
+         -- or, coded=(spec_dim, ap_dim), what the recipe's own call `analysis ... 5 2048 50 25` writes
+         (data/Makefile.in:214): float32 lf0 [T], mgc [T][50], bap [T][25] (analysis.cpp:292-366) --
          int16 resynthesised samples (test/audioio.cpp:160-167), when synthesis is on
 
 Three HIP streams: uploads, kernels (the context's), downloads; two slots of device and pinned buffers.  While the
@@ -37,12 +39,14 @@ class HostPipeline:
 
     SLOTS = 2
 
-    def __init__(self, ctx, params, x_lengths, synthesis=True):
+    def __init__(self, ctx, params, x_lengths, synthesis=True, coded=None):
         import torch
         self.torch = torch
         self.batch = b = W.WorldBatch(ctx, params, x_lengths=x_lengths)
         self.synthesis = synthesis
+        self.coded = coded
         T, bins, n, ny = int(b.total_frames), b.bins, int(b.total_samples), int(b.total_out)
+        w_sp, w_ap = (coded if coded else (bins, bins))       # widths of the two downloaded feature arrays
         dev = lambda *shape, dtype: torch.empty(*shape, dtype=dtype, device="cuda")
         pin = lambda *shape, dtype: torch.empty(*shape, dtype=dtype, pin_memory=True)
         f32, f64, i16 = torch.float32, torch.float64, torch.int16
@@ -50,9 +54,9 @@ class HostPipeline:
         self.x_dev = [dev(n, dtype=i16) for _ in range(self.SLOTS)]
         self.out64 = (dev(T, dtype=f64), dev(T, dtype=f64), dev(T, bins, dtype=f64), dev(T, bins, dtype=f64))
         self.y64 = dev(ny, dtype=f64)
-        self.out32 = [(dev(T, dtype=f32), dev(T, bins, dtype=f32), dev(T, bins, dtype=f32), dev(ny, dtype=i16))
+        self.out32 = [(dev(T, dtype=f32), dev(T, w_sp, dtype=f32), dev(T, w_ap, dtype=f32), dev(ny, dtype=i16))
                       for _ in range(self.SLOTS)]
-        self.host = [(pin(T, dtype=f32), pin(T, bins, dtype=f32), pin(T, bins, dtype=f32), pin(ny, dtype=i16))
+        self.host = [(pin(T, dtype=f32), pin(T, w_sp, dtype=f32), pin(T, w_ap, dtype=f32), pin(ny, dtype=i16))
                      for _ in range(self.SLOTS)]
         self.compute = torch.cuda.current_stream()
         self.up, self.down = torch.cuda.Stream(), torch.cuda.Stream()
@@ -100,9 +104,15 @@ class HostPipeline:
             b.analyze(x, out=self.out64)
         self.compute.wait_event(self.ev_down[s])                           # slot s's previous download has finished
         o = self.out32[s]
-        o[0].copy_(f0)
-        o[1].copy_(sp)
-        o[2].copy_(ap)
+        if self.coded:
+            lf0, mgc, bap = b.recipe_features(f0, sp, ap, self.coded[0], self.coded[1])
+            o[0].copy_(lf0)
+            o[1].copy_(mgc)
+            o[2].copy_(bap)
+        else:
+            o[0].copy_(f0)
+            o[1].copy_(sp)
+            o[2].copy_(ap)
         if y is not None:                                                  # wavwrite: clip(trunc(y * 32767))
             o[3].copy_(torch.clamp(torch.trunc(y * 32767.0), -32768.0, 32767.0))
         self.ev_done[s].record(self.compute)
@@ -115,15 +125,16 @@ class HostPipeline:
         return s
 
     def result(self, slot):
-        """Wait for the download of `slot`; returns numpy views (f0, sp, ap, y_int16) of its pinned buffers, valid
-        until that slot is submitted again."""
+        """Wait for the download of `slot`; returns numpy views (f0, sp, ap, y_int16) -- (lf0, mgc, bap, y_int16) when
+        coded -- of its pinned buffers, valid until that slot is submitted again."""
         self.ev_down[slot].synchronize()
         return tuple(h.numpy() for h in self.host[slot])
 
     def bytes_per_step(self):
         b = self.batch
         up = 2 * int(b.total_samples)
-        down = 4 * int(b.total_frames) * (1 + 2 * b.bins) + (2 * int(b.total_out) if self.synthesis else 0)
+        widths = sum(self.coded) if self.coded else 2 * b.bins
+        down = 4 * int(b.total_frames) * (1 + widths) + (2 * int(b.total_out) if self.synthesis else 0)
         return up, down
 
     def close(self):

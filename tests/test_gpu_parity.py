@@ -843,3 +843,35 @@ def test_host_pipeline_gives_the_device_results(gpu, pkg):
     assert up == 2 * sum(lens) and down > 4 * int(b.total_frames) * 2 * b.bins
     pipe.close()
     b.close()
+
+
+def test_host_pipeline_coded_features(gpu, pkg):
+    """The same pipeline handing down what the recipe's own call writes (`analysis ... 5 F 50 25`): float32 lf0 /
+    mgc[50] / bap[25] -- the resident coder's numbers, 300 B per frame on the wire instead of 4104."""
+    torch, W, ctx = gpu
+    pl = pkg.pipeline
+    fs = 16000
+    sets = [[sd.make_utterance(140 + 3 * k + j, fs, duration=d) for j, d in enumerate((0.6, 0.8))] for k in range(3)]
+    lens = [len(x) for x in sets[0]]
+    pipe = pl.HostPipeline(ctx, W.default_params(fs, 5.0), lens, synthesis=True, coded=(50, 25))
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+    prev, got = None, []
+    for xs in sets:
+        pipe.input_buffer()[:] = pl.to_int16(np.concatenate(xs))
+        slot = pipe.submit()
+        if prev is not None:
+            got.append(tuple(a.copy() for a in pipe.result(prev)))
+        prev = slot
+    got.append(tuple(a.copy() for a in pipe.result(prev)))
+    for xs, g in zip(sets, got):
+        x = torch.from_numpy(pl.to_int16(np.concatenate(xs))).cuda().to(torch.float64) / 32768.0
+        t, f0, sp, ap, y = b.analyze_synthesize(x)
+        lf0, mgc, bap = b.recipe_features(f0, sp, ap, 50, 25)
+        np.testing.assert_array_equal(g[0], lf0.cpu().numpy())
+        np.testing.assert_array_equal(g[1], mgc.cpu().numpy())
+        np.testing.assert_array_equal(g[2], bap.cpu().numpy())
+        assert g[1].shape[1] == 50 and g[2].shape[1] == 25
+    up, down = pipe.bytes_per_step()
+    assert down == 4 * int(b.total_frames) * 76 + 2 * int(b.total_out)
+    pipe.close()
+    b.close()
