@@ -403,6 +403,10 @@ def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps):
     duration of its launches on the launch stream, against the HBM peak; FP64 figures (what binds it) beside it."""
     d4c_ms, d4c_n = kernel_ms["d4c_kernel"]
     d4c_avg_s = d4c_ms / max(1, d4c_n) * 1e-3
+    # a step may launch the kernel several times (the sweep analyses its shard in batches): per-launch units
+    per_step = max(1, round(d4c_n / max(1, steps)))
+    frames = frames / per_step
+    voiced = voiced / per_step
     per_frame, note = measured_traffic(fs)
     flops = d4c_flops_per_voiced_frame(fs)
     ok = d4c_avg_s > 0
@@ -414,8 +418,9 @@ def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps):
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(frames * bm["d4c"] / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if ok else None,
         "traffic": round(frames * per_frame) if per_frame is not None else None,
+        "launches_per_step": per_step,
         "traffic_note": note,
-        "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": frames,
+        "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": round(frames),
         "bytes_per_unit": bm["d4c"],
         "note": "FP64-FFT/LDS bound, not HBM bound (SURVEY.md 8d); fp64 figures beside it",
         "fp64": {"achieved_tflops": round(voiced * flops / d4c_avg_s / 1e12, 3) if ok else None,
