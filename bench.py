@@ -239,13 +239,17 @@ def main():
     frame_counts = np.diff(batch.frame_offsets).tolist()
     bm = byte_model(fs, fp, batch.fft_size)
 
-    def step():
+    def compute():
         if args.separate_calls:
             t, f0, sp, ap = batch.analyze(x, out=outs)
             batch.synthesize(f0, sp, ap, out=y)
         else:
             # the same launches as one call: Synthesis' f0-only first part runs beside CheapTrick / D4C
             t, f0, sp, ap, _ = batch.analyze_synthesize(x, out=outs, y=y)
+        return f0, sp, ap
+
+    def step():
+        f0, sp, ap = compute()
         if args.gather and world > 1:
             # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
             feats = [f0.float(), sp.float(), ap.float()]
@@ -258,7 +262,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ramp = clock_ramp(step, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
+    # the ramp runs the rank-local part only: its length is set by each rank's clock, so it must not hold a collective
+    ramp = clock_ramp(compute, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
     for _ in range(args.warmup):
         step()
     barrier()
@@ -371,11 +376,13 @@ def clock_ramp(step, barrier, seconds, steps):
         step()
     barrier()
     cold = (time.perf_counter() - t0) / n
+    import torch
     t1 = time.perf_counter()
-    while time.perf_counter() - t1 < seconds:
+    while time.perf_counter() - t1 < seconds:      # per rank by the clock: device synchronisation only, no collective
         for _ in range(8):
             step()
-        barrier()
+        torch.cuda.synchronize()
+    barrier()
     return {"prewarm_s": seconds, "cold_ms_per_step": round(cold * 1e3, 3),
             "note": "value is measured after prewarm_s seconds of the same step (sustained clock); cold_ms_per_step is "
                     "the first %d steps of the process" % n}
