@@ -7,11 +7,13 @@ summation orders differ): |dF0| < 1e-6 Hz with identical V/UV, sp relative 1e-6,
 """
 import importlib
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 sd = importlib.import_module("hts-train-world_amd.synth_data")
@@ -875,3 +877,42 @@ def test_host_pipeline_coded_features(gpu, pkg):
     assert down == 4 * int(b.total_frames) * 76 + 2 * int(b.total_out)
     pipe.close()
     b.close()
+
+
+def test_device_memory_is_bounded_over_many_batches(tmp_path):
+    """Batches of ever different sizes (what the drop-in API creates, one per call signature) take their device
+    memory from the library's cache of freed blocks: with the cache limited to 64 MB, two hundred batches at 16 and
+    48 kHz, each analysed, resynthesised and destroyed, must leave the device where it was -- no leak in any stage
+    workspace, nothing kept beyond the limit."""
+    code = r'''
+import importlib, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+pkg = importlib.import_module("hts-train-world_amd")
+W, sd = pkg.world, pkg.synth_data
+ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+rng = np.random.default_rng(5)
+def cycle(k):
+    fs = 48000 if k %% 5 == 0 else 16000
+    lens = [int(fs * d) for d in rng.uniform(0.3, 1.2, size=int(rng.integers(1, 4)))]
+    x = torch.from_numpy(np.concatenate([sd.make_utterance(300 + k, fs, duration=n / fs)[:n] for n in lens])).cuda()
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=lens)
+    t, f0, sp, ap, y = b.analyze_synthesize(x)
+    assert torch.isfinite(y).all()
+    b.harvest(x)
+    b.close()
+for k in range(20):
+    cycle(k)
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+free0 = torch.cuda.mem_get_info()[0]
+for k in range(20, 220):
+    cycle(k)
+torch.cuda.synchronize(); torch.cuda.empty_cache()
+free1 = torch.cuda.mem_get_info()[0]
+print("DELTA_MB", (free0 - free1) / 2**20)
+''' % ROOT
+    env = dict(os.environ, WORLD_MI355_CACHE_MB="64")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    delta = float([l for l in r.stdout.splitlines() if l.startswith("DELTA_MB")][0].split()[1])
+    assert delta < 512.0, "device memory grew by %.0f MB over 200 batches" % delta
