@@ -59,8 +59,8 @@ def d4c_flops_per_voiced_frame(fs):
 # HBM-side bytes of the dominant kernel come from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
 # runs, tools/pmc_hbm.sh) stored in profiles/pmc_traffic.json together with a hash of the kernel's sources: when the
 # sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
-D4C_SOURCES = ("d4c.hip", "d4c_big.hpp", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp", "partition.hpp",
-               "wavesync.hpp")
+D4C_SOURCES = ("d4c.hip", "d4c_big.hpp", "peel.hpp", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp",
+               "partition.hpp", "wavesync.hpp")
 
 
 def kernel_source_hash():

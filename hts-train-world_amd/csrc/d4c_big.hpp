@@ -22,7 +22,7 @@
 //                          Output: GD[frame][0..2048].
 //   d4cb_band_kernel       GetCoarseAperiodicity (:192-223), one wavefront per (frame, band): the same even / odd
 //                          real transform of the windowed slice, the power spectrum's 2049 values sorted per lane,
-//                          the largest peeled (peel_largest, d4c.hip).  Output: COARSE[frame][band].
+//                          the largest peeled (peel_largest, peel.hpp).  Output: COARSE[frame][band].
 //   d4cb_output_kernel     GetAperiodicity (:325-333) for the listed frames, the default row for all others.
 //
 // What these kernels were bound by, in the order it was found (MI355X, 256 utterances at 48 kHz, 272 794 frames;

@@ -916,3 +916,43 @@ print("DELTA_MB", (free0 - free1) / 2**20)
     assert r.returncode == 0, r.stderr[-2000:]
     delta = float([l for l in r.stdout.splitlines() if l.startswith("DELTA_MB")][0].split()[1])
     assert delta < 512.0, "device memory grew by %.0f MB over 200 batches" % delta
+
+
+@pytest.mark.parametrize("m", [16, 32])
+def test_peel_largest_against_numpy(gpu, m):
+    """csrc/peel.hpp as d4c_kernel uses it (tests/hooks/libpeel_hook.so): the sum of all but the K largest of
+    64 x (m + 1) values, on noise, on a main lobe of neighbouring bins, on ties (all equal, blocks of equal values,
+    zeros) and with fewer values than K -- compared with a full sort; the per-lane counts add up to K."""
+    import ctypes as C
+    torch, W, ctx = gpu
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libpeel_hook.so"))
+    lib.PeelHook.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    n = 64 * m + 1                                   # values of a case: bins 0 .. fft/2
+    cases = []
+    for _ in range(40):
+        cases.append(rng.exponential(size=n))
+    for _ in range(20):
+        cases.append(100.0 * np.exp(-np.arange(n) / rng.uniform(3, 30)) + rng.exponential(size=n))
+    for _ in range(10):
+        cases.append(rng.exponential(size=n) + 50.0 * (np.arange(n) % rng.integers(40, 200) < 3))
+    cases.append(np.full(n, 0.25))                   # all equal
+    cases.append(np.zeros(n))
+    cases.append(np.repeat(rng.exponential(size=(n + 63) // 64), 64)[:n])        # runs of 64 equal values
+    cases.append(np.round(rng.exponential(size=n) * 4) / 4)                      # few distinct values
+    cases.append(np.concatenate([np.full(70, 7.0), np.full(n - 70, 1.0)]))       # more ties at the top than K
+    vals = np.full((len(cases), 64, m + 1), -1.0)
+    for c, v in enumerate(cases):                    # lane l holds bins l + 64 k (k < m); bin 64 m on lane 0
+        vals[c, :, :m] = v[:64 * m].reshape(m, 64).T
+        vals[c, 0, m] = v[64 * m]
+    d_vals = torch.from_numpy(vals).cuda()
+    for K in (65, 1, 64, 200):
+        low = torch.empty(len(cases), dtype=torch.float64, device="cuda")
+        taken = torch.empty(len(cases), 64, dtype=torch.int32, device="cuda")
+        rc = lib.PeelHook(C.c_void_p(torch.cuda.current_stream().cuda_stream), m, len(cases), K,
+                          C.c_void_p(d_vals.data_ptr()), C.c_void_p(low.data_ptr()), C.c_void_p(taken.data_ptr()))
+        assert rc == 0
+        torch.cuda.synchronize()
+        want = np.array([np.sort(v)[:n - K].sum() for v in cases])
+        np.testing.assert_allclose(low.cpu().numpy(), want, rtol=1e-12, atol=1e-300)
+        assert np.all(taken.cpu().numpy().sum(axis=1) == K)

@@ -1,4 +1,4 @@
-"""Rounds and single steps of peel_largest() (csrc/d4c.hip) on synthetic power spectra: python tools/peel_sim.py
+"""Rounds and single steps of peel_largest() (csrc/peel.hpp) on synthetic power spectra: python tools/peel_sim.py
 Lane-sorted columns of 1025 / 2049 values, K = 65 taken; D = look-ahead depth of the first attempt per round."""
 import numpy as np
 rng=np.random.default_rng(0)
