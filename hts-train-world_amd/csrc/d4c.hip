@@ -575,7 +575,8 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     rc = wm_check(hipMemcpyAsync(dw, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
     if (!rc) rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
     if (!rc) rc = wm_check(dev_alloc(&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
-    if (!rc) rc = wm_check(dev_alloc(&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
+    if (!rc && !b.d_perm2)                               // StoneMask may have taken it already
+      rc = wm_check(dev_alloc(&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
     if (rc) { dev_free(dw); return rc; }
     b.d_d4c_window = dw;
   }

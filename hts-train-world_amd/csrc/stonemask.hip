@@ -120,8 +120,12 @@ struct StoneMaskPred {
   const double* f0;
   double upper;
   double lower;        // kFloorF0StoneMask, or the caller's tighter guarantee (frames below it are not expected)
+  int fs, l_above, l_upto;   // window lengths of this list: l_above < 2 hw + 1 <= l_upto (launch_stonemask)
   __device__ bool operator()(int i) const {
-    return !(f0[i] <= kFloorF0StoneMask || f0[i] > upper) && f0[i] >= lower * (1.0 - 1e-9);
+    const double f = f0[i];
+    if ((f <= kFloorF0StoneMask || f > upper) || !(f >= lower * (1.0 - 1e-9))) return false;
+    const int L = 2 * (int)(1.5 * fs / f + 1.0) + 1;            // stonemask.cpp:189
+    return L > l_above && L <= l_upto;
   }
 };
 
@@ -216,21 +220,40 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   const int64_t tf = b.total_f;
   if (tf <= 0) return WM_OK;
   hipFuncSetAttribute((const void*)stonemask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stonemask_kernel, 64, lds) != hipSuccess || per_cu < 1)
-    per_cu = 4;
-  const int64_t resident = (int64_t)c.num_cu * per_cu;
-  const int grid = (int)(tf < resident ? tf : resident);
   if (!b.d_sm_twid) {
     int rc = wm_check(dev_alloc(&b.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
     if (rc) return rc;
     hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)b.d_sm_twid);
   }
-  launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0, f_low > kFloorF0StoneMask ? f_low : 0.0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
+  if (!b.d_perm2) {
+    int rc = wm_check(dev_alloc(&b.d_perm2, sizeof(int) * (size_t)tf));
+    if (rc) return rc;
+  }
+  // Two lists by window length.  The window scratch is sized by the LONGEST window a launch may meet: at 48 kHz and
+  // a 71 Hz floor that is 32 KB, 1.25 waves per SIMD, while two thirds of the frames (f0 above twice the floor) need
+  // half of it.  The frames with windows of at most half the maximum run with half the scratch, the rest as before.
+  const int lhalf = lmax / 2;
+  const double lower = f_low > kFloorF0StoneMask ? f_low : 0.0;
+  int rc = wm_check(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)tf, c.stream));    // stonemask.cpp:186-187
+  if (rc) return rc;
   TimedScope ts_(b.ctx, "stonemask_kernel");
-  hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds, c.stream, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, fs, lmax, tf, (const int*)b.d_perm, (const int*)b.d_part_n,
-                     (const cpx*)b.d_sm_twid, d_out);
+  for (int cls = 0; cls < 2; ++cls) {
+    const int lcap = cls == 0 ? lhalf : lmax;
+    const size_t lds_c = sizeof(double) * 2 * (size_t)(lcap + 2);
+    int* perm = cls == 0 ? b.d_perm : b.d_perm2;
+    int* n_listed = b.d_part_n + cls;
+    launch_partition(c.stream, StoneMaskPred{d_f0, fs / 12.0, lower, fs, cls == 0 ? 0 : lhalf, lcap}, (int)tf,
+                     b.d_part_cnt, perm, n_listed);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stonemask_kernel, 64, lds_c) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    const int64_t resident = (int64_t)c.num_cu * per_cu;
+    const int grid = (int)(tf < resident ? tf : resident);
+    // total_frames = 0: the rows of the frames that are not refined were zeroed above, not by the kernel
+    hipLaunchKernelGGL(stonemask_kernel, dim3(grid), dim3(64), lds_c, c.stream, d_x, b.d_x_off, b.d_x_len,
+                       b.d_frame_utt, d_t, d_f0, fs, lcap, (int64_t)0, (const int*)perm, (const int*)n_listed,
+                       (const cpx*)b.d_sm_twid, d_out);
+  }
   return wm_check(hipGetLastError());
 }
 
