@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64, 2) void dio_band_fft_kernel(
   extern __shared__ __attribute__((aligned(16))) double lds[];
   cpx* img = reinterpret_cast<cpx*>(lds);
   double* s = lds;                                               // the filtered block, after the inverse transform
-  unsigned short* lists = reinterpret_cast<unsigned short*>(lds + ConvCfg<B>::kImg);
+  unsigned short* lists = ConvEvCfg<B, kDioConvC>::lists(lds);
   const int u = blockIdx.y, tile = blockIdx.x, lane_k = threadIdx.x, lane = lane_k;
   const int ylen = ylen_a[u];
   const int nt = dio_tiles(ylen, meta.step);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64, 2) void dio_band_fft_kernel(
       if (j + 1 >= 0) s[j + 1] = v[m].y;
     }
     wave_sync();
-    conv_block_events<kDioConvC>(s, n0, meta.step, ylen, tile, lists, ConvCfg<B>::kListCap,
+    conv_block_events<kDioConvC>(s, n0, meta.step, ylen, tile, lists, ConvEvCfg<B, kDioConvC>::kListCap,
                       tile_cnt + (((int64_t)u * meta.nb + band) * (tiles_max + 1) + tile) * 4,
                       slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, lane);
   }
@@ -697,9 +697,9 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
       const cpx* Hb = (const cpx*)b.d_dio_H + (m.lc_conv ? m.lc_conv / 2 + 1 : 0);
       static const bool attr_ = (hipFuncSetAttribute((const void*)dio_band_fft_kernel<2048>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)ConvCfg<2048>::kLdsBytes) == hipSuccess);
+                                                     (int)(ConvEvCfg<2048, kDioConvC>::kLdsBytes)) == hipSuccess);
       (void)attr_;
-      hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), ConvCfg<2048>::kLdsBytes, st,
+      hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), (ConvEvCfg<2048, kDioConvC>::kLdsBytes), st,
                          b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
                          b.d_dio_slots);
     } else if (small)

@@ -29,9 +29,21 @@ namespace wm {
 template <int B> struct ConvCfg {
   static constexpr int N = B / 2, M = N / 64;
   static constexpr int kImg = 2 * FftLds<N>::kElems;           // doubles: FFT image, then the filtered block
-  static constexpr int kListCap = 1024;                        // events of a kind per block (they cannot fire on
-                                                               // consecutive samples: <= (B - 2) / 2)
-  static constexpr size_t kLdsBytes = sizeof(double) * kImg + sizeof(unsigned short) * 4 * kListCap;
+};
+
+// LDS of a band kernel that also extracts events (conv_block_events): the FFT image, whose first 64 CMAX + 2 doubles
+// hold the filtered block while the events are extracted, and the four ordered index lists, which start right
+// behind the block -- inside what is left of the image -- and end at 20 KB, so that eight workgroups (two waves per
+// SIMD) fit a CU; with lists of their own behind the image (25.6 KB) it was six.  A list then holds 766 indices;
+// a block can have up to 64 CMAX / 2 events of a kind (they cannot fire on consecutive samples), so blocks with
+// more than the lists hold -- signals that alternate around zero nearly every sample -- take a direct path.
+template <int B, int CMAX> struct ConvEvCfg {
+  static constexpr int kSDoubles = (64 * CMAX + 2 + 1) & ~1;
+  static constexpr size_t kImgBytes = sizeof(double) * ConvCfg<B>::kImg;
+  static constexpr size_t kLdsBytes = kImgBytes > 20480 ? kImgBytes + 4096 : 20480;
+  static constexpr int kListCap = (int)((kLdsBytes - sizeof(double) * kSDoubles) / (4 * sizeof(unsigned short)));
+  static_assert(kListCap >= 256, "room for the event lists");
+  __device__ static unsigned short* lists(double* lds) { return reinterpret_cast<unsigned short*>(lds + kSDoubles); }
 };
 
 // H[f][k] = FFT_B(g_f)[k] / B, k = 0 .. B/2, where g_f[k'] = taps[off[f] + k' - delay[f]] for
@@ -123,13 +135,43 @@ __device__ __forceinline__ void conv_block_events(const double* s, int n0, int s
     mask[2] |= (f2 ? 1u : 0u) << r;
     mask[3] |= (f3 ? 1u : 0u) << r;
   }
-  int total[4];
+  int total[4], first[4];
 #pragma unroll
   for (int ty = 0; ty < 4; ++ty) {
     const int cnt = __popc(mask[ty]);
     const int incl = wave_scan_incl_i(cnt);
-    int at = incl - cnt;
+    first[ty] = incl - cnt;
     total[ty] = __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane < 4) tile_cnt4[lane] = lane == 0 ? total[0] : (lane == 1 ? total[1] : (lane == 2 ? total[2] : total[3]));
+  if (imax(imax(total[0], total[1]), imax(total[2], total[3])) > list_cap) {        // wave-uniform, rare
+    // more events than the lists hold: every lane computes the positions of its own events where they are found
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+      int at = first[ty];
+      unsigned m = mask[ty];
+      while (m) {
+        const int r = __ffs((int)m) - 1;
+        const int li = lo + r, i = n0 + li;
+        const double x0 = s[li], x1 = s[li + 1];
+        double fine;
+        if (ty < 2) {
+          fine = (i + 1) - x0 / (x1 - x0);
+        } else {
+          const double x2 = s[li + 2];
+          const double p0 = x1 - x0, p1 = x2 - x1;
+          fine = (i + 1) - p0 / (p1 - p0);
+        }
+        slot[(int64_t)ty * slot_cap + (int64_t)tile * kZcSlot + at++] = fine;
+        m &= m - 1u;
+      }
+    }
+    wave_sync();
+    return;
+  }
+#pragma unroll
+  for (int ty = 0; ty < 4; ++ty) {
+    int at = first[ty];
     unsigned m = mask[ty];
     while (m) {                                                 // a few hits per lane and kind
       const int r = __ffs((int)m) - 1;
@@ -138,7 +180,6 @@ __device__ __forceinline__ void conv_block_events(const double* s, int n0, int s
     }
   }
   wave_sync();
-  if (lane < 4) tile_cnt4[lane] = lane == 0 ? total[0] : (lane == 1 ? total[1] : (lane == 2 ? total[2] : total[3]));
 #pragma unroll
   for (int ty = 0; ty < 4; ++ty) {
     for (int j = lane; j < total[ty]; j += 64) {

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, 2) void hv_band_fft_kernel(const int64_t* __res
   extern __shared__ __attribute__((aligned(16))) double lds[];
   cpx* img = reinterpret_cast<cpx*>(lds);
   double* s = lds;
-  unsigned short* lists = reinterpret_cast<unsigned short*>(lds + ConvCfg<B>::kImg);
+  unsigned short* lists = ConvEvCfg<B, kHvConvC>::lists(lds);
   const int u = blockIdx.z, grp = blockIdx.y, tile = blockIdx.x, lane_k = threadIdx.x, lane = lane_k;
   const int ylen = ylen_a[u];
   const int nt = hv_tiles(ylen, step);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64, 2) void hv_band_fft_kernel(const int64_t* __res
       if (j + 1 >= 0) s[j + 1] = v[m].y;
     }
     wave_sync();
-    conv_block_events<kHvConvC>(s, n0, step, ylen, tile, lists, ConvCfg<B>::kListCap,
+    conv_block_events<kHvConvC>(s, n0, step, ylen, tile, lists, ConvEvCfg<B, kHvConvC>::kListCap,
                                 tile_cnt + (((int64_t)u * nch + ch) * (tiles_max + 1) + tile) * 4,
                                 slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, lane);
   }
@@ -1245,11 +1245,11 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     if (m.conv) {
       static const bool attr_ = (hipFuncSetAttribute((const void*)hv_band_fft_kernel<2048>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)ConvCfg<2048>::kLdsBytes) == hipSuccess);
+                                                     (int)(ConvEvCfg<2048, kHvConvC>::kLdsBytes)) == hipSuccess);
       (void)attr_;
       const int groups = (m.nch + kHvChGroup - 1) / kHvChGroup;
       hipLaunchKernelGGL(hv_band_fft_kernel<2048>, dim3(W.tiles_max, groups, n_utt), dim3(64),
-                         ConvCfg<2048>::kLdsBytes, st, W.d_yoff, W.d_ylen, W.d_y, (const cpx*)W.d_H, m.nch, m.half0,
+                         (ConvEvCfg<2048, kHvConvC>::kLdsBytes), st, W.d_yoff, W.d_ylen, W.d_y, (const cpx*)W.d_H, m.nch, m.half0,
                          m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots);
     } else {
       const size_t lds = sizeof(double) * (size_t)zc_lds_doubles<kZcStrideHarvest>(m.ntap_max);

@@ -956,3 +956,55 @@ def test_peel_largest_against_numpy(gpu, m):
         want = np.array([np.sort(v)[:n - K].sum() for v in cases])
         np.testing.assert_allclose(low.cpu().numpy(), want, rtol=1e-12, atol=1e-300)
         assert np.all(taken.cpu().numpy().sum(axis=1) == K)
+
+
+def test_block_events_list_and_direct_paths(gpu):
+    """csrc/fftconv.hpp conv_block_events (tests/hooks/libevents_hook.so): the four zero-crossing passes of a filtered
+    block (dio.cpp:357-435) against numpy, through the ordered-list path, through the direct path that blocks with
+    more events than the lists hold take (forced with a small capacity, and reached for real by a signal that
+    alternates around zero every sample), bit for bit the same."""
+    import ctypes as C
+    torch, W, ctx = gpu
+    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libevents_hook.so"))
+    lib.EventsHook.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    slot, cap = lib.EventsHookSlot(), lib.EventsHookListCap()
+    rng = np.random.default_rng(3)
+    step, blocks = 1729, 6
+    ylen = step * blocks - 5
+    y = np.zeros(step * blocks + 2)
+    n = np.arange(len(y))
+    sigs = {"tones": np.sin(2 * np.pi * 0.013 * n) + 0.4 * np.sin(2 * np.pi * 0.071 * n + 1.0) + 0.01 * rng.standard_normal(len(y)),
+            "alternating": np.where(n % 2 == 0, 1.0, -1.0) * (1.0 + 0.3 * rng.random(len(y))),
+            "noise": rng.standard_normal(len(y))}
+
+    def numpy_events(y):
+        out = []
+        for ty in range(4):
+            v = y if ty == 0 else (-y if ty == 1 else (np.diff(y) if ty == 2 else -np.diff(y)))
+            lim = ylen - 1 if ty < 2 else ylen - 2
+            i = np.nonzero((v[:-1] > 0) & (v[1:] <= 0))[0]
+            i = i[i < lim]
+            out.append((i + 1) - v[i] / (v[i + 1] - v[i]))
+        return out
+
+    def run(y, list_cap):
+        s = np.stack([y[b * step:b * step + step + 2] for b in range(blocks)])
+        d_s = torch.from_numpy(np.ascontiguousarray(s)).cuda()
+        cnt = torch.zeros(blocks, 4, dtype=torch.int32, device="cuda")
+        slots = torch.zeros(4, blocks * slot, dtype=torch.float64, device="cuda")
+        rc = lib.EventsHook(C.c_void_p(torch.cuda.current_stream().cuda_stream), blocks, step, ylen, list_cap,
+                            C.c_void_p(d_s.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(slots.data_ptr()))
+        assert rc == 0
+        torch.cuda.synchronize()
+        cnt, slots = cnt.cpu().numpy(), slots.cpu().numpy()
+        return [np.concatenate([slots[ty, b * slot:b * slot + cnt[b, ty]] for b in range(blocks)]) for ty in range(4)], cnt
+
+    for name, y in sigs.items():
+        want = numpy_events(y)
+        got, cnt = run(y, cap)
+        forced, _ = run(y, 8)
+        if name == "alternating":
+            assert cnt.max() > cap                       # the real overflow: the direct path was taken
+        for ty in range(4):
+            np.testing.assert_array_equal(got[ty], want[ty], err_msg="%s kind %d" % (name, ty))
+            np.testing.assert_array_equal(forced[ty], want[ty], err_msg="%s kind %d (direct path)" % (name, ty))
