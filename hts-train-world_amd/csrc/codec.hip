@@ -49,9 +49,13 @@ __global__ __launch_bounds__(64) void codec_code_sp_kernel(const double* __restr
                                                            const cpx* __restrict__ weight, int ndim, CodeOpts o,
                                                            int64_t total_frames, OUT* __restrict__ out) {
   constexpr int MD = F / 2, BINS = F / 2 + 1, N = MD, M = N / 64;
-  __shared__ __attribute__((aligned(16))) double ls[BINS + 1];
-  __shared__ __attribute__((aligned(16))) double wave[MD];
+  // the log spectrum and the reordered mel sequence live in the FFT image: they are consumed (into registers)
+  // before the transform writes it.  With arrays of their own the kernel held 17.4 KB at fft 1024 (33.8 KB at
+  // 2048: one wave per SIMD); now 9.2 / 18.4 KB.
   __shared__ __attribute__((aligned(16))) cpx img[FftLds<N>::kElems];
+  static_assert(2 * FftLds<N>::kElems >= (BINS + 1) + MD, "log spectrum and mel sequence fit the image");
+  double* ls = reinterpret_cast<double*>(img);
+  double* wave = ls + BINS + 1;
   const int lane0 = threadIdx.x;
   FftTw<N> tw;
   tw.init(lane0);
@@ -60,18 +64,37 @@ __global__ __launch_bounds__(64) void codec_code_sp_kernel(const double* __restr
     const int lane = opaque_lane(lane0);
     const double* row = in + frame * (int64_t)BINS;
     wave_sync();
-    for (int j = lane; j < BINS; j += 64) {
-      double v = row[j] * o.pre_scale;
-      if (o.zero_value != 0.0 && v == 0.0) v = o.zero_value;
-      ls[j] = log(v);
+    {
+      // the row and the interpolation table in one trip to memory each (a rolled loop made every bin wait for its own)
+      double rv[M + 1];
+#pragma unroll
+      for (int m = 0; m <= M; ++m) rv[m] = row[imin(lane + 64 * m, BINS - 1)];
+#pragma unroll
+      for (int m = 0; m <= M; ++m) {
+        double v = rv[m] * o.pre_scale;
+        if (o.zero_value != 0.0 && v == 0.0) v = o.zero_value;
+        const double lv = log(v);
+        if (m < M || lane == 0) ls[lane + 64 * m] = lv;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     wave_sync();
     // interp1 onto the mel axis (codec.cpp:126-129) and the even/odd reordering of DCTForCodec (:77-82)
-    for (int m = lane; m < MD; m += 64) {
-      const int k = kidx[m];
-      const double y0 = ls[k - 1];
-      const double v = y0 + sfrac[m] * (ls[k] - y0);
-      wave[(m & 1) ? (MD - 1 - m) / 2 + MD / 2 : m / 2] = v;
+    {
+      int kk[M];
+      double sf[M];
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        kk[q] = kidx[lane + 64 * q];
+        sf[q] = sfrac[lane + 64 * q];
+      }
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        const int m = lane + 64 * q;
+        const double y0 = ls[kk[q] - 1];
+        const double v = y0 + sf[q] * (ls[kk[q]] - y0);
+        wave[(m & 1) ? (MD - 1 - m) / 2 + MD / 2 : m / 2] = v;
+      }
     }
     wave_sync();
     // DFT of the MD real points: the reference takes a real FFT; the one-wavefront engine starts at 512
@@ -110,8 +133,9 @@ __global__ __launch_bounds__(64) void codec_decode_sp_kernel(const IN* __restric
                                                              const cpx* __restrict__ weight, DecodeOpts o,
                                                              int64_t total_frames, double* __restrict__ sp) {
   constexpr int MD = F / 2, BINS = F / 2 + 1, N = MD, M = N / 64;
+  // the mel knots share the FFT image (the transform's results are in registers when they are written)
   __shared__ __attribute__((aligned(16))) cpx img[FftLds<N>::kElems];
-  __shared__ __attribute__((aligned(16))) double knots[MD + 2];
+  double* knots = reinterpret_cast<double*>(img);                   // [MD + 2]
   const int lane0 = threadIdx.x;
   FftTw<N> tw;
   tw.init(lane0);
@@ -145,11 +169,22 @@ __global__ __launch_bounds__(64) void codec_decode_sp_kernel(const IN* __restric
     }
     wave_sync();
     double* orow = sp + frame * (int64_t)BINS;
-    for (int b = lane; b < BINS; b += 64) {
-      const int k = kidx[b];
-      const double y0 = knots[k - 1];
-      const double e = exp((y0 + sfrac[b] * (knots[k] - y0)) * inv_md);
-      orow[b] = o.post_div != 0.0 ? e / o.post_div : e;
+    {
+      int kk[M + 1];
+      double sf[M + 1];
+#pragma unroll
+      for (int q = 0; q <= M; ++q) {                                // the table in one trip to memory
+        kk[q] = kidx[imin(lane + 64 * q, BINS - 1)];
+        sf[q] = sfrac[imin(lane + 64 * q, BINS - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q <= M; ++q) {
+        const int b = lane + 64 * q;
+        const double y0 = knots[kk[q] - 1];
+        const double e = exp((y0 + sf[q] * (knots[kk[q]] - y0)) * inv_md);
+        if (q < M || lane == 0) orow[b] = o.post_div != 0.0 ? e / o.post_div : e;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     wave_sync();
   }
