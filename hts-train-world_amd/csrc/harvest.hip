@@ -566,7 +566,19 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
                                                         const double* __restrict__ rc,
                                                         const double* __restrict__ rs, int64_t tot_b,
                                                         double* __restrict__ rc2, double* __restrict__ rs2) {
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // The 256 (frame, slot) items of a workgroup cover 256 / maxc frames; every item compares its candidate with all
+  // candidates of the two neighbouring frames, so the rows of those frames (and one frame either side) are staged
+  // in LDS once instead of being fetched by every item (2 maxc loads each, all served by L1 but one at a time).
+  extern __shared__ double rows[];                              // [(frames of the group + 2)][maxc]
+  const int64_t id0 = (int64_t)blockIdx.x * 256;
+  const int64_t fr_lo = id0 / m.maxc;
+  int64_t fr_hi = (id0 + 255) / m.maxc;
+  if (fr_hi > tot_b - 1) fr_hi = tot_b - 1;
+  const int64_t st_lo = fr_lo > 0 ? fr_lo - 1 : 0, st_hi = fr_hi + 1 < tot_b ? fr_hi + 1 : tot_b - 1;
+  const int n_stage = (int)((st_hi - st_lo + 1) * m.maxc);
+  for (int i = threadIdx.x; i < n_stage; i += 256) rows[i] = rc[st_lo * m.maxc + i];
+  __syncthreads();
+  const int64_t id = id0 + threadIdx.x;
   const int64_t fr = id / m.maxc;
   const int s = (int)(id - fr * m.maxc);
   if (fr >= tot_b) return;
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
   if (s >= nc) return;
   const int k = (int)(fr - boff[u]);
   const int nb1 = nb1_a[u];
-  double c = rc[fr * m.maxc + s], sc = rs[fr * m.maxc + s];
+  double c = rows[(fr - st_lo) * m.maxc + s], sc = rs[fr * m.maxc + s];
   if (k >= 1 && k < nb1 - 1 && c != 0) {
     // SelectBestF0 with allowed_range 1.0 on both neighbours (:652-688) only keeps the smaller relative
     // error: min over q of fl(|c - v_q| / c), capped at 1.  Correctly rounded division by c > 0 is
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
     for (int side = 0; side < 2; ++side) {
       const int nk = side == 0 ? k + 1 : k - 1;
       const bool zero_row = nk == 0 || nk == nb1 - 1;
-      const double* row = rc + (fr + (side == 0 ? 1 : -1)) * m.maxc;
+      const double* row = rows + (fr + (side == 0 ? 1 : -1) - st_lo) * m.maxc;
       for (int q0 = 0; q0 < nc; q0 += 8) {
         double v[8];
 #pragma unroll
@@ -1288,7 +1300,8 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   }
   {
     const int64_t items = W.tot_b * m.maxc;
-    hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, W.d_bframe_utt,
+    const size_t lds_rm = sizeof(double) * (size_t)((256 / m.maxc + 4) * m.maxc);
+    hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), lds_rm, st, W.d_bframe_utt,
                        W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc, W.d_rs, W.tot_b, W.d_rc2, W.d_rs2);
   }
   {
