@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void hv_band_compact_kernel(
 // thread.  Workgroups that straddle two utterances, or whose slice exceeds the LDS tile, use the
 // global lists directly.
 constexpr int kRawStage = 384;
-__global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ bframe_utt,
+__global__ __launch_bounds__(256, 8) void hv_raw_kernel(const int* __restrict__ bframe_utt,
                                                      const int64_t* __restrict__ boff,
                                                      const int* __restrict__ ylen_a, HvMeta m,
                                                      const double* __restrict__ bf, double f0_floor, double f0_ceil,
