@@ -16,6 +16,14 @@
 
 namespace wm {
 
+// The f0 a frame is analysed with.
+__host__ __device__ inline double ct_frame_f0(double f0v, int fs, int F) {
+  const double f0_floor = 3.0 * fs / (F - 3.0);              // cheaptrick.cpp:196-198
+  // f0 <= floor (cheaptrick.cpp:217); NaN too.  Above fs / 2 (and +Inf) DCCorrection indexes past its spectrum
+  // in the reference (common.cpp:56-75: upper_limit > fft_size / 2): undefined there, the default f0 here.
+  return !(f0v > f0_floor) || !(f0v <= fs / 2.0) ? kDefaultF0 : f0v;
+}
+
 // Per-utterance exclusive scan of each frame's randn consumption:
 // (2*round(1.5 fs/f0')+1) for the window (cheaptrick.cpp:126-128) then fft_size/2+1
 // for AddInfinitesimalNoise (:149-150).
@@ -27,15 +35,13 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
   const int u = blockIdx.x;
   const int64_t base = f_off[u];
   const int nf = (int)(f_off[u + 1] - base);
-  const double f0_floor = 3.0 * fs / (fft_size - 3.0);
   if (threadIdx.x == 0) carry_s = 0;
   wave_sync();
   for (int start = 0; start < nf; start += 256) {
     const int i = start + threadIdx.x;
     int c = 0;
     if (i < nf) {
-      double v = f0[base + i];
-      double cf0 = !(v > f0_floor) ? kDefaultF0 : v;     // v <= floor (cheaptrick.cpp:217); a NaN f0 also takes the default
+      const double cf0 = ct_frame_f0(f0[base + i], fs, fft_size);
       c = 2 * matlab_round(1.5 * fs / cf0) + 1 + fft_size / 2 + 1;
     }
     part[threadIdx.x] = c;
@@ -60,10 +66,6 @@ __global__ __launch_bounds__(256) void cheaptrick_offsets_kernel(const double* _
 // (f0 below (F / 8 - 2) fs / F: 1.97 kHz at 16 kHz, 5.95 kHz at 48 kHz) run with F / 8 bins of margin, i.e. within
 // the FFT image's own LDS, the others (WIDE) with the full margin.  Same code, same results.
 template <int F, bool WIDE> struct CtMargin { static constexpr int kBM = WIDE ? (((F / 3 + 2) + 1) & ~1) : F / 8; };
-__host__ __device__ inline double ct_frame_f0(double f0v, int fs, int F) {
-  const double f0_floor = 3.0 * fs / (F - 3.0);              // cheaptrick.cpp:196-198
-  return !(f0v > f0_floor) ? kDefaultF0 : f0v;               // f0 <= floor (cheaptrick.cpp:217); NaN too
-}
 struct CtUsualPred {
   const double* f0;
   int fs, F;

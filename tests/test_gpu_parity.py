@@ -376,6 +376,20 @@ def test_cheaptrick_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
     sp_close(got, want)
     got2 = pkg.capi.cheaptrick(x, fs, t, f0)
     np.testing.assert_array_equal(got2, got)
+    # beyond fs / 2 (undefined in the reference: DCCorrection runs past its spectrum) and non-finite values are
+    # analysed at the default f0 like the values at or below the floor; nothing faults, every row is finite
+    f0b = f0.copy()
+    f0b[0::6], f0b[1::6], f0b[2::6] = fs * 0.75, np.inf, np.nan
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    gotb = b.cheaptrick(dev(x), dev(t), dev(f0b)).cpu().numpy()
+    b.close()
+    assert np.isfinite(gotb).all()
+    f0z = f0b.copy()
+    f0z[0::6], f0z[1::6], f0z[2::6] = 0.0, 0.0, 0.0
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    gotz = b.cheaptrick(dev(x), dev(t), dev(f0z)).cpu().numpy()
+    b.close()
+    np.testing.assert_array_equal(gotb, gotz)
 
 
 @pytest.mark.parametrize("thr", [0.0, -1.0])
