@@ -19,6 +19,7 @@
 namespace wm {
 
 int wm_check(hipError_t e);   // maps to WM_ERR_HIP and records the message
+void set_error(const char* msg);
 
 // Device memory of batches and stage workspaces comes from a process-wide cache of freed blocks (context.cpp):
 // the drop-in C API builds a batch per call signature, and hipMalloc / hipFree (which also synchronises the
@@ -62,13 +63,41 @@ struct Context {
 // of Synthesis runs beside CheapTrick and D4C) delays a whole share by that much: the launch ends late by the
 // overlap.  With a few workgroups per slot the hardware dispatcher hands the shares out as slots become free; the
 // price is a last round that is not full (at most one share of 1 / oversub of a slot's work).
+// The occupancy query is made once per (device, kernel) -- a process may hold contexts on several GPUs -- and
+// remembered (context.cpp); `slot` is 0 for "never asked".
+int& occupancy_slot(int device, const void* kernel);
 template <class K> inline int persistent_grid(const Context& c, K kernel, int block, int64_t items) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
-    per_cu = 4;
+  int& per_cu = occupancy_slot(c.device, (const void*)kernel);
+  if (per_cu == 0) {
+    int q = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, block, 0) != hipSuccess || q < 1) q = 4;
+    per_cu = q;
+  }
   const int64_t g = (int64_t)c.num_cu * per_cu * c.oversub;
   return (int)(items < g ? items : g);
 }
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel)
+template <class K> inline void allow_dynamic_lds(const Context& c, K kernel, int bytes) {
+  int& done = occupancy_slot(c.device, (const void*)((const char*)(const void*)kernel + 1));   // its own key
+  if (done) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done = 1;
+}
+
+// Every entry point that takes a batch or a context runs on the context's device, whatever device is current on
+// the calling thread, and leaves the caller's current device as it found it.
+struct OnDevice {
+  int prev = -1;
+  explicit OnDevice(const Context& c) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != c.device && hipSetDevice(c.device) == hipSuccess) prev = cur;
+  }
+  ~OnDevice() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  OnDevice(const OnDevice&) = delete;
+  OnDevice& operator=(const OnDevice&) = delete;
+};
 
 // RAII bracket: records a start/stop event pair around the launches in its scope.
 struct TimedScope {

@@ -73,7 +73,9 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
     wm::set_error("no HIP device visible: libworld_mi355 has no CPU path");
     return WM_ERR_NO_DEVICE;
   }
-  if (device >= 0) {
+  int before = -1;
+  (void)hipGetDevice(&before);
+  if (device >= 0 && device != before) {
     int rc = wm_check(hipSetDevice(device));
     if (rc) return rc;
   }
@@ -88,12 +90,15 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
   c.stream = (hipStream_t)hip_stream;
   c.own_stream = false;
   *out = h;
+  // every entry point switches to its context's device itself (OnDevice): the caller's current device stays
+  if (before >= 0 && before != c.device) (void)hipSetDevice(before);
   return WM_OK;
 }
 
 void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (!h) return;
   Context& c = h->c;
+  OnDevice dev_(c);
   hipStreamSynchronize(c.stream);
   c.timing_clear();
   if (c.d_rng) wm::dev_free(c.d_rng);
@@ -107,6 +112,7 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
 }
 
 int WorldMi355SetStream(WorldMi355Context* h, void* hip_stream) {
+  OnDevice dev_(h->c);
   Context& c = h->c;
   int rc = wm_check(hipStreamSynchronize(c.stream));
   if (rc) return rc;
@@ -116,7 +122,10 @@ int WorldMi355SetStream(WorldMi355Context* h, void* hip_stream) {
   return WM_OK;
 }
 
-int WorldMi355Synchronize(WorldMi355Context* h) { return wm_check(hipStreamSynchronize(h->c.stream)); }
+int WorldMi355Synchronize(WorldMi355Context* h) {
+  OnDevice dev_(h->c);
+  return wm_check(hipStreamSynchronize(h->c.stream));
+}
 
 int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, int n_utt,
                           const int* x_lengths, const int* f0_lengths, const int* y_lengths,
@@ -126,6 +135,7 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
     wm::set_error("CreateBatch: bad argument");
     return WM_ERR_BAD_ARG;
   }
+  OnDevice dev_(h->c);
   WorldMi355Batch* hb = new WorldMi355Batch();
   Batch& b = hb->b;
   b.ctx = &h->c;
@@ -201,6 +211,7 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
 void WorldMi355DestroyBatch(WorldMi355Batch* hb) {
   if (!hb) return;
   Batch& b = hb->b;
+  OnDevice dev_(*b.ctx);
   hipStreamSynchronize(b.ctx->stream);
   wm::free_batch_buffers(b);
   delete hb;
@@ -215,48 +226,60 @@ const int64_t* WorldMi355BatchFrameOffsets(const WorldMi355Batch* b) { return b-
 const int64_t* WorldMi355BatchOutputOffsets(const WorldMi355Batch* b) { return b->b.y_off.data(); }
 
 int WorldMi355Dio(WorldMi355Batch* b, const double* x, double* t, double* f0) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_dio(b->b, x, t, f0);
 }
 int WorldMi355StoneMask(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
                         double* refined_f0) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_stonemask(b->b, x, t, f0, refined_f0);
 }
 int WorldMi355CheapTrick(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
                          double* sp) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_cheaptrick(b->b, x, t, f0, sp);
 }
 int WorldMi355D4C(WorldMi355Batch* b, const double* x, const double* t, const double* f0, double* ap) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_d4c(b->b, x, t, f0, ap);
 }
 int WorldMi355Synthesis(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
                         double* y) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_synthesis(b->b, f0, sp, ap, y);
 }
 int WorldMi355GetNumberOfAperiodicities(int fs) { return codec_num_aperiodicities(fs); }
 int WorldMi355CodeSpectralEnvelope(WorldMi355Batch* b, const double* sp, int number_of_dimensions, double* coded) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_code_spectral_envelope(b->b, sp, number_of_dimensions, coded);
 }
 int WorldMi355DecodeSpectralEnvelope(WorldMi355Batch* b, const double* coded, int number_of_dimensions,
                                      double* sp) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_decode_spectral_envelope(b->b, coded, number_of_dimensions, sp);
 }
 int WorldMi355CodeAperiodicity(WorldMi355Batch* b, const double* ap, double* coded) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_code_aperiodicity(b->b, ap, coded);
 }
 int WorldMi355DecodeAperiodicity(WorldMi355Batch* b, const double* coded, double* ap) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_decode_aperiodicity(b->b, coded, ap);
 }
 int WorldMi355RecipeFeatures(WorldMi355Batch* b, const double* f0, const double* sp, const double* ap,
                              int spec_dim, int ap_dim, float* lf0, float* mgc, float* bap) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_recipe_features(b->b, f0, sp, ap, spec_dim, ap_dim, lf0, mgc, bap);
 }
 int WorldMi355RecipeDecode(WorldMi355Batch* b, const float* lf0, const float* mgc, const float* bap, int spec_dim,
                            int ap_dim, double* f0, double* sp, double* ap) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_recipe_decode(b->b, lf0, mgc, bap, spec_dim, ap_dim, f0, sp, ap);
 }
 int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* streams, const int* dims,
                          const int* n_windows, const double* const* const* windows,
                          const int* const* window_sizes, float* out) {
+  OnDevice dev_(b->b.ctx[0]);
   return launch_compose_cmp(b->b, n_streams, streams, dims, n_windows, windows, window_sizes, out);
 }
 void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_samples, int bytes_per_frame,
@@ -269,10 +292,12 @@ void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_sample
   memcpy(out12 + 10, &d, 2);
 }
 int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0) {
+  OnDevice dev_(b->b.ctx[0]);
   return wm::launch_harvest(b->b, x, t, f0);
 }
 int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
                       double* ap) {
+  OnDevice dev_(hb->b.ctx[0]);
   Batch& b = hb->b;
   int rc = launch_dio(b, x, t, b.d_f0_tmp);
   rc = rc ? rc : launch_stonemask(b, x, t, b.d_f0_tmp, f0, b.p.f0_floor);
@@ -282,17 +307,21 @@ int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f
 }
 int WorldMi355AnalyzeSynthesize(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
                                 double* ap, double* y) {
+  OnDevice dev_(hb->b.ctx[0]);
   return launch_analyze_synthesize(hb->b, x, t, f0, sp, ap, y);
 }
 int WorldMi355Vibrato(WorldMi355Batch* hb, const float* lf0, const int* seg_utt_off, const int* seg_start,
                       const int* seg_end, const double* seg_pitch, float* vib, float* lf0_out, int* n_too_long) {
+  OnDevice dev_(hb->b.ctx[0]);
   return launch_vibrato(hb->b, lf0, seg_utt_off, seg_start, seg_end, seg_pitch, vib, lf0_out, n_too_long);
 }
 int WorldMi355UtteranceStatus(WorldMi355Batch* hb, const double* x, const double* f0, const double* sp,
                               const double* ap, int* status) {
+  OnDevice dev_(hb->b.ctx[0]);
   return launch_utterance_status(hb->b, x, f0, sp, ap, status);
 }
 int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
+  OnDevice dev_(h->c);
   Context& c = h->c;
   int rc = wm_check(hipStreamSynchronize(c.stream));
   c.timing_clear();
@@ -300,6 +329,7 @@ int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
   return rc;
 }
 int WorldMi355TimingQuery(WorldMi355Context* h, const char* kernel, double* total_ms, int* launches) {
+  OnDevice dev_(h->c);
   Context& c = h->c;
   int rc = wm_check(hipStreamSynchronize(c.stream));
   if (rc) return rc;

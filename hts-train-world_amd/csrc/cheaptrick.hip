@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       if (lane == 0) pw[H] = p[M];
       wave_sync();
     }
-    dc_correction_margin<H, kBM>(pw, cf0, fs, F, lane);
+    dc_correction_margin<H, kBM, WIDE ? H : kBM>(pw, cf0, fs, F, lane);
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
     linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane);
@@ -194,8 +194,8 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
   if (grid <= 0) return 0;
 #define WM_CT_CASE(FF)                                                                                   \
   case FF: {                                                                                             \
-    static const int per_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, false>, 64, (int64_t)1 << 40); \
-    static const int perw_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, true>, 64, (int64_t)1 << 40); \
+    const int per_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, false>, 64, (int64_t)1 << 40); \
+    const int perw_ = persistent_grid(*b.ctx, cheaptrick_kernel<FF, true>, 64, (int64_t)1 << 40); \
     hipLaunchKernelGGL((cheaptrick_kernel<FF, false>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,     \
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off, b.ctx->d_rng,        \
                        b.p.fs, b.p.q1, tf, (const int*)b.d_perm, (const int*)b.d_part_n, d_sp);          \

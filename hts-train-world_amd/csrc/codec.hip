@@ -345,7 +345,7 @@ static int code_sp(Batch& b, const double* d_in, int ndim, CodeOpts o, OUT* d_ou
   TimedScope ts_(b.ctx, name);
 #define WM_CODE_CASE(FF)                                                                                     \
   case FF: {                                                                                                 \
-    static const int per_ = persistent_grid(*b.ctx, codec_code_sp_kernel<FF, OUT>, 64, (int64_t)1 << 40);    \
+    const int per_ = persistent_grid(*b.ctx, codec_code_sp_kernel<FF, OUT>, 64, (int64_t)1 << 40);    \
     hipLaunchKernelGGL((codec_code_sp_kernel<FF, OUT>), dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st, \
                        d_in, T.d_code_k, T.d_code_s, T.d_code_w, ndim, o, tf, d_out);                        \
   } break;
@@ -378,7 +378,7 @@ static int decode_sp(Batch& b, const IN* d_coded, int ndim, DecodeOpts o, double
   TimedScope ts_(b.ctx, "codec_decode_sp_kernel");
 #define WM_DEC_CASE(FF)                                                                                      \
   case FF: {                                                                                                 \
-    static const int per_ = persistent_grid(*b.ctx, codec_decode_sp_kernel<FF, IN>, 64, (int64_t)1 << 40);   \
+    const int per_ = persistent_grid(*b.ctx, codec_decode_sp_kernel<FF, IN>, 64, (int64_t)1 << 40);   \
     hipLaunchKernelGGL((codec_decode_sp_kernel<FF, IN>), dim3((int)(tf < per_ ? tf : per_)), dim3(64), 0, st, \
                        d_coded, ndim, T.d_dec_k, T.d_dec_s, T.d_dec_w, o, tf, d_sp);                         \
   } break;

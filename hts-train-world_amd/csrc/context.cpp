@@ -23,11 +23,14 @@ int wm_check(hipError_t e) {
 }
 
 namespace {
+// Blocks are cached per (device, size class): a process may hold contexts on several GPUs
+// (WorldMi355CreateContext(device, ...)), and a block must only ever be handed back to the device it lives on.
 struct DevCache {
+  typedef std::pair<int, size_t> Key;                // (device, size class)
   std::mutex mu;
-  std::multimap<size_t, void*> free_blocks;          // size class -> block
-  std::unordered_map<void*, size_t> size_of;         // every live or cached block -> size class
-  size_t cached = 0;
+  std::multimap<Key, void*> free_blocks;
+  std::unordered_map<void*, Key> owner;              // every live or cached block -> its device and size class
+  size_t cached = 0;                                 // idle bytes, all devices
   size_t limit = (size_t)8 << 30;                    // cached (idle) bytes kept at most; WORLD_MI355_CACHE_MB
   DevCache() {
     if (const char* e = getenv("WORLD_MI355_CACHE_MB")) limit = (size_t)strtoull(e, nullptr, 10) << 20;
@@ -46,30 +49,63 @@ size_t size_class(size_t bytes) {
   const size_t step = p2 >> 4;                       // p2/2 < bytes <= p2: steps of p2/16
   return (bytes + step - 1) / step * step;
 }
+int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+// hipFree cached blocks (largest first) until at most keep_bytes stay cached; device < 0: of every device
+void trim_locked_out(size_t keep_bytes, int device) {
+  DevCache& c = dev_cache();
+  std::vector<std::pair<int, void*>> victims;
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    // largest first: walk the size classes from the top, across devices
+    while (c.cached > keep_bytes && !c.free_blocks.empty()) {
+      auto best = c.free_blocks.end();
+      for (auto it = c.free_blocks.begin(); it != c.free_blocks.end(); ++it)
+        if ((device < 0 || it->first.first == device) && (best == c.free_blocks.end() || it->first.second > best->first.second))
+          best = it;
+      if (best == c.free_blocks.end()) break;
+      victims.push_back(std::make_pair(best->first.first, best->second));
+      c.cached -= best->first.second;
+      c.owner.erase(best->second);
+      c.free_blocks.erase(best);
+    }
+  }
+  if (victims.empty()) return;
+  const int here = current_device();
+  int at = here;
+  for (auto& v : victims) {
+    if (v.first != at) { (void)hipSetDevice(v.first); at = v.first; }
+    (void)hipFree(v.second);
+  }
+  if (at != here) (void)hipSetDevice(here);
+}
 }  // namespace
 
 hipError_t dev_alloc_bytes(void** p, size_t bytes) {
   DevCache& c = dev_cache();
-  const size_t cls = size_class(bytes);
+  const DevCache::Key key(current_device(), size_class(bytes));
   {
     std::lock_guard<std::mutex> g(c.mu);
-    auto it = c.free_blocks.find(cls);
+    auto it = c.free_blocks.find(key);
     if (it != c.free_blocks.end()) {
       *p = it->second;
       c.free_blocks.erase(it);
-      c.cached -= cls;
+      c.cached -= key.second;
       return hipSuccess;
     }
   }
-  hipError_t e = hipMalloc(p, cls);
-  if (e != hipSuccess) {                             // out of memory with idle blocks around: give them back and retry
+  hipError_t e = hipMalloc(p, key.second);
+  if (e != hipSuccess) {                             // out of memory with idle blocks around: give this device's back and retry
     (void)hipGetLastError();
-    dev_cache_trim(0);
-    e = hipMalloc(p, cls);
+    trim_locked_out(0, key.first);
+    e = hipMalloc(p, key.second);
   }
   if (e == hipSuccess) {
     std::lock_guard<std::mutex> g(c.mu);
-    c.size_of[*p] = cls;
+    c.owner[*p] = key;
   }
   return e;
 }
@@ -80,32 +116,24 @@ void dev_free(void* p) {
   size_t over = 0;
   {
     std::lock_guard<std::mutex> g(c.mu);
-    auto it = c.size_of.find(p);
-    if (it == c.size_of.end()) {                     // not ours (should not happen): plain free
+    auto it = c.owner.find(p);
+    if (it == c.owner.end()) {                       // not ours (should not happen): plain free
       (void)hipFree(p);
       return;
     }
     c.free_blocks.emplace(it->second, p);
-    c.cached += it->second;
+    c.cached += it->second.second;
     over = c.cached > c.limit ? c.limit / 2 : (size_t)-1;
   }
   if (over != (size_t)-1) dev_cache_trim(over);
 }
 
-void dev_cache_trim(size_t keep_bytes) {
-  DevCache& c = dev_cache();
-  std::vector<void*> victims;
-  {
-    std::lock_guard<std::mutex> g(c.mu);
-    while (c.cached > keep_bytes && !c.free_blocks.empty()) {
-      auto it = std::prev(c.free_blocks.end());      // largest first
-      victims.push_back(it->second);
-      c.cached -= it->first;
-      c.size_of.erase(it->second);
-      c.free_blocks.erase(it);
-    }
-  }
-  for (void* q : victims) (void)hipFree(q);
+void dev_cache_trim(size_t keep_bytes) { trim_locked_out(keep_bytes, -1); }
+int& occupancy_slot(int device, const void* kernel) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int>* slots = new std::map<std::pair<int, const void*>, int>;
+  std::lock_guard<std::mutex> g(mu);
+  return (*slots)[std::make_pair(device, kernel)];      // std::map nodes do not move: the reference stays valid
 }
 const char* last_error() { return g_last_error.c_str(); }
 void set_error(const char* msg) { g_last_error = msg; }

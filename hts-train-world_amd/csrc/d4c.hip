@@ -512,9 +512,9 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   hipStream_t st = c.stream;
   const int64_t tf = b.total_f;
   if (tab.window_length >= FD / 4) return WM_ERR_UNSUPPORTED;    // d4cb_band_kernel: taps fill half the packed operand at most
-  static const int g1 = persistent_grid(c, d4cb_centroid_kernel<FD>, 64, (int64_t)1 << 40);
-  static const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
-  static const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);
+  const int g1 = persistent_grid(c, d4cb_centroid_kernel<FD>, 64, (int64_t)1 << 40);
+  const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
+  const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);
   const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   const size_t ws_rows = (size_t)g1;                               // one scratch row per workgroup of the centroid kernel
   if (!b.d_d4c_big) {
@@ -543,7 +543,7 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
                      b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);
   // the rare frames afterwards, over the default rows the output kernel has written for them
-  static const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
+  const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
   hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
                      b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab,
                      b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);
@@ -595,7 +595,7 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   launch_partition(st, VoicedPred{d_f0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
 #define WM_LT_CASE(FF)                                                                                     \
   case FF: {                                                                                               \
-    static const int per_ = persistent_grid(c, d4c_lovetrain_kernel<FF>, 64, (int64_t)1 << 40);            \
+    const int per_ = persistent_grid(c, d4c_lovetrain_kernel<FF>, 64, (int64_t)1 << 40);            \
     hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,  \
                        b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf,                \
                        (const int*)b.d_perm, (const int*)b.d_part_n, b.d_ap0);                             \
@@ -625,12 +625,12 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
                    b.d_part_n + 1);
 #define WM_D4C_CASE(FF, WV)                                                                               \
   case FF: {                                                                                              \
-    static const int per_ = persistent_grid(c, d4c_kernel<FF, WV, false>, 64, (int64_t)1 << 40);          \
+    const int per_ = persistent_grid(c, d4c_kernel<FF, WV, false>, 64, (int64_t)1 << 40);          \
     hipLaunchKernelGGL((d4c_kernel<FF, WV, false>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,         \
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
                        b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
                        (const int*)b.d_perm, (const int*)b.d_part_n, d_ap);                               \
-    static const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
+    const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
     hipLaunchKernelGGL((d4c_kernel<FF, 1, true>), dim3(imin(grid, per2_)), dim3(64), 0, st, d_x,          \
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
                        b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \

@@ -695,10 +695,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     TimedScope ts_(b.ctx, "dio_band_kernel");
     if (m.band_conv) {
       const cpx* Hb = (const cpx*)b.d_dio_H + (m.lc_conv ? m.lc_conv / 2 + 1 : 0);
-      static const bool attr_ = (hipFuncSetAttribute((const void*)dio_band_fft_kernel<2048>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(ConvEvCfg<2048, kDioConvC>::kLdsBytes)) == hipSuccess);
-      (void)attr_;
+      allow_dynamic_lds(*b.ctx, dio_band_fft_kernel<2048>, (int)(ConvEvCfg<2048, kDioConvC>::kLdsBytes));
       hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), (ConvEvCfg<2048, kDioConvC>::kLdsBytes), st,
                          b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
                          b.d_dio_slots);

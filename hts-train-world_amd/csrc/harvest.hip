@@ -377,181 +377,217 @@ __global__ __launch_bounds__(256) void hv_twiddle_kernel(cpx* __restrict__ tw) {
 // RefineF0Candidates (harvest.cpp:622-631) over the overlapped candidate table that
 // OverlapF0Candidates (:417-429) would build: slot s = j + ncand1 * blk reads frame k - blk
 // (blk = 1..3) or k + blk - 3 (blk = 4..6); out-of-range or unwritten entries are zero.
+//
+// RefineF0Candidates / GetRefinedF0 (harvest.cpp:434-617).  ONE LANE PER (frame, slot).  The windows are short
+// at the decimated rate (three periods at 8 kHz: 30-340 samples) and everything around the sums is per-candidate
+// scalar work (window geometry, transform size, six bins, FixF0's divisions and square roots): with a wavefront
+// -- or a 16-lane row, the form this replaces -- per candidate that work was replicated over the lanes, rows
+// without a candidate idled and every sum ended in a cross-lane reduction (3.9 G wave instructions on
+// configs[2], 120 k per frame-wave).  Here a workgroup owns kRfChunk consecutive basic frames:
+//   0. their candidate rows (and three frames either side) and per-frame descriptors go to LDS;
+//   1. the occupied (frame, slot) pairs are listed, ordered by window length (counting sort on LDS counters,
+//      longest first), so that the 64 refinements of a wavefront run for about the same number of samples;
+//   2. waves fetch groups of 64 listed pairs; a lane walks its own window sample by sample.
+// Per sample and lane: the Blackman window by rotation of (cos, sin), the differentiated window from its two
+// neighbours, and for each of the six bins the two windowed sums by Goertzel's recurrence
+//   s[n] = x[n] + 2 cos(w) s[n-1] - s[n-2],   X(w) = e^{-jw(N-1)} (s[N-1] - e^{-jw} s[N-2])
+// (two instructions per sum and sample where a rotating twiddle takes four).  The phase factor is the same for
+// the main and the differentiated spectrum of a bin, and FixF0 (:505-528) only uses |main|^2 and
+// Im(conj(main) diff): both are unchanged by it, so it is dropped.  Rounding: the recurrence amplifies by about
+// N / sin(w) <= 2e4 at the lowest f0, i.e. 1e-12 relative in the sums, 1e-9 Hz in a refined f0.
+constexpr int kRfChunk = 128;      // basic frames per workgroup
+constexpr int kRfBins = 1024;      // half window lengths told apart by the ordering; longer ones share the last bin
 
+__device__ __forceinline__ double hv_blackman(double c) {           // 0.42 + 0.5 c + 0.08 (2 c^2 - 1), :446-456
+  return fma(c, fma(0.16, c, 0.5), 0.34);
+}
 
-// RefineF0Candidates / GetRefinedF0 (harvest.cpp:434-617).  One wavefront per basic frame.  The
-// candidates of all slots are fetched side by side (lane = slot), empty slots are answered at once,
-// and the occupied ones are refined FOUR AT A TIME, one per 16-lane row: the windows are short at
-// the decimated rate (3 periods of 8 kHz: 100-340 samples), so a whole wavefront per candidate spends
-// most of its instructions on per-candidate scalar work replicated over 64 lanes (twiddle bases,
-// FixF0's divisions and square roots); a row per candidate shares that work four ways and reduces
-// over 16 lanes with four row rotations.
-__global__ __launch_bounds__(64) void hv_refine_kernel(const int* __restrict__ bframe_utt,
-                                                       const int64_t* __restrict__ boff,
-                                                       const int* __restrict__ nb1_a, HvMeta m,
-                                                       const int64_t* __restrict__ yoff,
-                                                       const int* __restrict__ ylen_a, const double* __restrict__ y,
-                                                       const double* __restrict__ offc,
-                                                       const int* __restrict__ ncand1_a, double f0_floor,
-                                                       double f0_ceil, int lmax, int64_t tot_b,
-                                                       const cpx* __restrict__ twid, double* __restrict__ rc,
-                                                       double* __restrict__ rs) {
-  extern __shared__ __attribute__((aligned(16))) double mw_all[];   // [4][lmax + 2]
-  const int lane0 = threadIdx.x;
-  for (int64_t fr = blockIdx.x; fr < tot_b; fr += gridDim.x) {
-    const int lane = opaque_lane(lane0);
-    const int row = lane >> 4, l16 = lane & 15;
-    double* mw = mw_all + row * (lmax + 2);
-    const int u = bframe_utt[fr];
-    const int k = (int)(fr - boff[u]);
-    const int nb1 = nb1_a[u];
-    const int nc1 = ncand1_a[u];
-    const double* ys = y + yoff[u];
-    const int ylen = ylen_a[u];
-    const double pos = k * 1 / 1000.0;
-    const double fs = m.afs;
-    const double inv_fs = 1.0 / fs;
-    const int ns = nc1 * kHvOverlap;
-    for (int s0 = 0; s0 < ns; s0 += 64) {
-      const int sl_ = s0 + lane;
-      double f0s = 0.0;
-      if (sl_ < ns) {
-        const int blk = sl_ / nc1, j = sl_ - blk * nc1;
-        const int src = blk == 0 ? k : (blk <= 3 ? k - blk : k + (blk - 3));
-        if (src >= 0 && src < nb1) f0s = offc[(boff[u] + src) * m.cpf + j];
-        if (!(f0s > 0.0)) {
-          rc[fr * m.maxc + sl_] = 0.0;
-          rs[fr * m.maxc + sl_] = 0.0;
-        }
+__global__ __launch_bounds__(256) void hv_refine_kernel(const int* __restrict__ bframe_utt,
+                                                        const int64_t* __restrict__ boff,
+                                                        const int* __restrict__ nb1_a, HvMeta m,
+                                                        const int64_t* __restrict__ yoff,
+                                                        const int* __restrict__ ylen_a, const double* __restrict__ y,
+                                                        const double* __restrict__ offc,
+                                                        const int* __restrict__ ncand1_a, double f0_floor,
+                                                        double f0_ceil, int64_t tot_b,
+                                                        const cpx* __restrict__ twid, double* __restrict__ rc,
+                                                        double* __restrict__ rs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rf_smem[];
+  double* rows = reinterpret_cast<double*>(rf_smem);                         // [kRfChunk + 6][cpf]
+  int* hist = reinterpret_cast<int*>(rows + (kRfChunk + 6) * m.cpf);         // [kRfBins] counts, then cursors
+  int4* meta = reinterpret_cast<int4*>(hist + kRfBins);                      // [kRfChunk] {utterance, k, nb1, nc1}
+  unsigned short* list = reinterpret_cast<unsigned short*>(meta + kRfChunk); // [kRfChunk * maxc] (frame << 8) | slot
+  __shared__ int sh_w[4], sh_next;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t fr0 = (int64_t)blockIdx.x * kRfChunk;
+  const int nfr = (int)(tot_b - fr0 < kRfChunk ? tot_b - fr0 : kRfChunk);
+  const double fs = m.afs, inv_fs = 1.0 / fs;
+
+  // ---- 0. stage ----
+  {
+    const int64_t flat0 = (fr0 - 3) * m.cpf, flat_end = tot_b * m.cpf;
+    for (int e = tid; e < (kRfChunk + 6) * m.cpf; e += 256) {
+      const int64_t g = flat0 + e;
+      rows[e] = (g >= 0 && g < flat_end) ? offc[g] : 0.0;
+    }
+    for (int fl = tid; fl < nfr; fl += 256) {
+      const int u = bframe_utt[fr0 + fl];
+      meta[fl] = make_int4(u, (int)(fr0 + fl - boff[u]), nb1_a[u], ncand1_a[u]);
+    }
+    for (int b = tid; b < kRfBins; b += 256) hist[b] = 0;
+    if (tid == 0) sh_next = 0;
+  }
+  __syncthreads();
+  // candidate of (local frame, slot): 0 when the slot is empty, -1 when it lies beyond the utterance's table
+  auto candidate = [&](int fl, int slot) -> double {
+    const int4 mt = meta[fl];
+    if (slot >= mt.w * kHvOverlap) return -1.0;
+    // slot / nc1 for slot < 256, nc1 <= 36: the quotient of the half-shifted value is at least 0.5 / nc1 from an integer
+    const int blk = (int)(((float)slot + 0.5f) * __frcp_rn((float)mt.w));
+    const int j = slot - blk * mt.w;
+    const int d = blk == 0 ? 0 : (blk <= 3 ? -blk : blk - 3);
+    const int src = mt.y + d;
+    return (src >= 0 && src < mt.z) ? rows[(fl + 3 + d) * m.cpf + j] : 0.0;
+  };
+  // ordering key, longest window first: the half window length in single precision (the order only decides which
+  // refinements share a wavefront)
+  const float hw_scale = 1.5f * (float)fs;
+  auto order_key = [&](double f0) -> int {
+    const int hw = (int)(hw_scale * __frcp_rn((float)f0) + 1.0f);
+    return kRfBins - 1 - imin(kRfBins - 1, hw);
+  };
+  // ---- 1. list the occupied pairs, longest window first: a wave per frame, a lane per slot ----
+  for (int fl = wv; fl < nfr; fl += 4) {
+    for (int slot = lane; slot < m.maxc; slot += 64) {
+      const double f0 = candidate(fl, slot);
+      if (f0 > 0.0) {
+        atomicAdd(&hist[order_key(f0)], 1);
+      } else if (f0 == 0.0) {                                  // GetRefinedF0 :593-597
+        rc[(fr0 + fl) * m.maxc + slot] = 0.0;
+        rs[(fr0 + fl) * m.maxc + slot] = 0.0;
       }
-      unsigned long long todo = __ballot(f0s > 0.0);
-      while (todo) {
-        // this row's candidate: the (row)-th set bit of todo; rows without one idle through the group
-        unsigned long long t = todo;
-        int pick = -1;
+    }
+  }
+  __syncthreads();
+  int n_items;
+  {
+    // exclusive scan of the kRfBins counters: four per thread, a wave scan, the four wave totals
+    const int4 c4 = reinterpret_cast<int4*>(hist)[tid];
+    const int mine = c4.x + c4.y + c4.z + c4.w;
+    const int incl = wave_scan_incl_i(mine);
+    if (lane == 63) sh_w[wv] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int q = 0; q < wv; ++q) base += sh_w[q];
+    n_items = sh_w[0] + sh_w[1] + sh_w[2] + sh_w[3];
+    reinterpret_cast<int4*>(hist)[tid] = make_int4(base, base + c4.x, base + c4.x + c4.y, base + c4.x + c4.y + c4.z);
+  }
+  __syncthreads();
+  for (int fl = wv; fl < nfr; fl += 4) {
+    for (int slot = lane; slot < m.maxc; slot += 64) {
+      const double f0 = candidate(fl, slot);
+      if (f0 > 0.0) list[atomicAdd(&hist[order_key(f0)], 1)] = (unsigned short)((fl << 8) | slot);
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. refine, 64 listed pairs per wave and trip ----
+  for (;;) {
+    int grp = 0;
+    if (lane == 0) grp = atomicAdd(&sh_next, 1);
+    grp = __builtin_amdgcn_readfirstlane(grp);
+    if (grp * 64 >= n_items) break;
+    const int it = grp * 64 + lane;
+    const bool live = it < n_items;
+    const int code = list[live ? it : n_items - 1];
+    const int fl = code >> 8, slot = code & 255;
+    const double f0 = candidate(fl, slot);                     // > 0 by construction
+    const int4 mt = meta[fl];
+    const double* ys = y + yoff[mt.x];
+    const int ylen = ylen_a[mt.x];
+    const double pos = mt.y * 1 / 1000.0;
+    // GetRefinedF0 :589-617
+    const int hw = (int)(1.5 * fs / f0 + 1.0);
+    const int L = 2 * hw + 1;
+    const double inv_wlen = fs / (2.0 * hw + 1.0);
+    // fft_size = 2^(2 + int(log2(L))): L is odd, so the logarithm is never within rounding of an integer
+    const int fftn = 1 << (2 + (31 - __clz(L)));
+    const double bt0 = (-hw + 0) / fs;
+    const int basic = matlab_round((pos + bt0) * fs + 0.001);   // GetBaseIndex :434-441
+    // GetMainWindow :446-456: cos(2 pi tm / wlen) at tm = (basic + i - 1) / fs - pos, advanced by a rotation per sample
+    double c, sn, cd, sd;
+    sincospi(2.0 * ((basic - 1.0) * inv_fs - pos) * inv_wlen, &sn, &c);
+    sincospi(2.0 * inv_fs * inv_wlen, &sd, &cd);
+    double coef[6], cw[6], sw[6];
+    int bin[6];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = t ? __ffsll((long long)t) - 1 : -1;
-          if (r == row) pick = p;
-          if (t) t &= t - 1;
-        }
-        todo = t;
-        const bool live = pick >= 0;
-        // the shuffle must run on every lane: a lane of an idle row may be the SOURCE of a live one, and
-        // ds_bpermute returns 0 for sources that are masked off
-        const double f0_any = __shfl(f0s, pick < 0 ? 0 : pick, 64);
-        const double f0 = live ? f0_any : 100.0;
-        const int slot = s0 + pick;
-        // GetRefinedF0 :589-617
-        const int hw = (int)(1.5 * fs / f0 + 1.0);
-        const int L = 2 * hw + 1;
-        const double wlen = (2.0 * hw + 1.0) / fs;
-        const double inv_wlen = 1.0 / wlen;
-        const int fftn = 1 << (2 + (int)(log(hw * 2.0 + 1.0) / kLog2));
-        const double inv_fftn = 1.0 / fftn;               // power of two: exact
-        const double bt0 = (-hw + 0) / fs;
-        const int basic = matlab_round((pos + bt0) * fs + 0.001);  // GetBaseIndex :434-441
-        int Lmax = L;
+    for (int h = 0; h < 6; ++h) {
+      bin[h] = matlab_round(f0 * fftn / fs * (h + 1));          // FixF0 :515
+      cpx t;
+      if (fftn <= kHvTwid) t = twid[(bin[h] & (fftn - 1)) * (kHvTwid / fftn)];
+      else t = cis_neg2pi((double)(bin[h] & (fftn - 1)) / (double)fftn);
+      cw[h] = t.x;
+      sw[h] = -t.y;
+      coef[h] = 2.0 * t.x;
+    }
+    double m1[6], m2[6], d1[6], d2[6];
 #pragma unroll
-        for (int sh = 32; sh >= 16; sh >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, sh, 64));
-        wave_sync();
-        {
-          // GetMainWindow :446-456.  cos(2 pi tm / wlen) at tm = (basic + i - 1) / fs - pos is evaluated once
-          // per lane (i = l16) and advanced by a rotation per 16 samples (at most 22 steps); cos(4 pi ..) =
-          // 2 c^2 - 1
-          double c1, s1, cd, sd;
-          sincospi(2.0 * (((basic + l16) - 1.0) * inv_fs - pos) * inv_wlen, &s1, &c1);
-          sincospi(2.0 * 16.0 * inv_fs * inv_wlen, &sd, &cd);
-          for (int i0 = 0; i0 < Lmax; i0 += 16) {
-            const int i = i0 + l16;
-            if (i < L) mw[i] = 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
-            const double nc = c1 * cd - s1 * sd;
-            s1 = s1 * cd + c1 * sd;
-            c1 = nc;
-          }
-        }
-        wave_sync();
-        const int nh = imin((int)(fs / 2.0 / f0), 6);              // :571-572
-        int bin[6];
-        cpx mainv[6], diffv[6], w[6], st[6];
+    for (int h = 0; h < 6; ++h) m1[h] = m2[h] = d1[h] = d2[h] = 0.0;
+    double w_prev = 0.0, w_cur = hv_blackman(c);
+    // a lane leaves the loop after its own window (the wave runs on for the longest one): what a refinement returns
+    // does not depend on which other refinements share its wavefront
+    for (int i0 = 0; i0 < L; i0 += 4) {
+      double xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[q] = ys[imax(0, imin(ylen - 1, basic + i0 + q - 1))];   // :481-484
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q;
+        const double nc = c * cd - sn * sd;
+        sn = sn * cd + c * sd;
+        c = nc;
+        const double w_next = i + 1 < L ? hv_blackman(c) : 0.0;
+        const double x = i < L ? xv[q] : 0.0;
+        const double am = x * w_cur;
+        const double ad = x * (0.5 * (w_prev - w_next));        // GetDiffWindow :462-468, both edges included
 #pragma unroll
         for (int h = 0; h < 6; ++h) {
-          bin[h] = matlab_round(f0 * fftn / fs * (h + 1));          // FixF0 :515
-          mainv[h] = make_double2(0.0, 0.0);
-          diffv[h] = make_double2(0.0, 0.0);
-          // exp(-2 pi i bin i / fftn) at i = l16 and its step of 16 samples: table entries (fftn is a power of
-          // two up to kHvTwid for every f0 above 24 Hz at the decimated rate; a longer transform computes them)
-          if (fftn <= kHvTwid) {
-            const int sc_ = kHvTwid / fftn;
-            w[h] = twid[((bin[h] * l16) & (fftn - 1)) * sc_];
-            st[h] = twid[((bin[h] * 16) & (fftn - 1)) * sc_];
-          } else {
-            w[h] = cis_neg2pi((double)((bin[h] * l16) & (fftn - 1)) * inv_fftn);
-            st[h] = cis_neg2pi((double)((bin[h] * 16) & (fftn - 1)) * inv_fftn);
-          }
+          const double tm = fma(coef[h], m1[h], am - m2[h]);
+          m2[h] = m1[h];
+          m1[h] = tm;
+          const double td = fma(coef[h], d1[h], ad - d2[h]);
+          d2[h] = d1[h];
+          d1[h] = td;
         }
-        // windowed DFT bins (GetSpectra / GetMainWindow / GetDiffWindow :462-568), four trips per round
-        for (int i0 = 0; i0 < Lmax; i0 += 64) {
-          double xv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            xv[q] = ys[imax(0, imin(ylen - 1, basic + imin(L - 1, i0 + 16 * q + l16) - 1))];   // :481-484
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = i0 + 16 * q + l16;
-            if (i0 + 16 * q < Lmax) {                                // uniform
-              const bool in = i < L;
-              const int ic = in ? i : L - 1;
-              const double mm = mw[ic];
-              double d;                                             // :462-468
-              if (ic == 0) d = -mw[1] / 2.0;
-              else if (ic == L - 1) d = mw[L - 2] / 2.0;
-              else d = -(mw[ic + 1] - mw[ic - 1]) / 2.0;
-              const double am = in ? xv[q] * mm : 0.0, ad = in ? xv[q] * d : 0.0;
-#pragma unroll
-              for (int h = 0; h < 6; ++h) {
-                if (h < nh) {
-                  mainv[h].x += am * w[h].x; mainv[h].y += am * w[h].y;
-                  diffv[h].x += ad * w[h].x; diffv[h].y += ad * w[h].y;
-                  w[h] = cmul(w[h], st[h]);
-                }
-              }
-            }
-          }
-        }
-        // FixF0 :505-528 per harmonic.  The row sums land in every lane of the row; lane h of the row then does
-        // harmonic h's divisions and square root (they used to be done for all six by all lanes), and three
-        // row sums over the harmonics finish the candidate.
-        double mr_h = 0.0, mi_h = 0.0, dr_h = 0.0, di_h = 0.0;
-        int bin_h = 0;
-#pragma unroll
-        for (int h = 0; h < 6; ++h) {
-          const double mr = row_sum16(mainv[h].x), mi = row_sum16(mainv[h].y);
-          const double dr = row_sum16(diffv[h].x), di = row_sum16(diffv[h].y);
-          if (l16 == h) { mr_h = mr; mi_h = mi; dr_h = dr; di_h = di; bin_h = bin[h]; }
-        }
-        double numer = 0.0, denom = 0.0, sc = 0.0;
-        if (l16 < nh) {
-          const double num = mr_h * di_h - mi_h * dr_h;             // :565-566
-          const double pwv = mr_h * mr_h + mi_h * mi_h;             // :567-568
-          const double p = bin_h <= fftn / 2 ? pwv : 0.0;
-          const double inst = p == 0.0 ? 0.0 : (double)bin_h * fs * inv_fftn + num / p * fs / 2.0 / kPi;
-          const double amp = sqrt(p);
-          numer = amp * inst;
-          denom = amp * (l16 + 1.0);
-          sc = fabs((inst / (l16 + 1.0) - f0) / f0);
-        }
-        numer = row_sum16(numer);
-        denom = row_sum16(denom);
-        sc = row_sum16(sc);
-        double rf0 = numer / (denom + kSafe);
-        double rscore = 1.0 / (sc / nh + kSafe);
-        if (rf0 < f0_floor || rf0 > f0_ceil || rscore < 2.5) { rf0 = 0.0; rscore = 0.0; }   // :610-614
-        if (live && l16 == 0) {
-          rc[fr * m.maxc + slot] = rf0;
-          rs[fr * m.maxc + slot] = rscore;
-        }
+        w_prev = w_cur;
+        w_cur = w_next;
       }
+    }
+    // FixF0 :505-528
+    const int nh = imin((int)(fs / 2.0 / f0), 6);                // :571-572
+    const double inv_fftn = 1.0 / fftn;                          // power of two: exact
+    double numer = 0.0, denom = 0.0, sc = 0.0;
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const double mr = m1[h] - cw[h] * m2[h], mi = sw[h] * m2[h];
+      const double dr = d1[h] - cw[h] * d2[h], di = sw[h] * d2[h];
+      const double num = mr * di - mi * dr;                      // :565-566
+      const double pwv = mr * mr + mi * mi;                      // :567-568
+      const double p = bin[h] <= fftn / 2 ? pwv : 0.0;
+      const double inst = p == 0.0 ? 0.0 : (double)bin[h] * fs * inv_fftn + num / p * fs / 2.0 / kPi;
+      const double amp = sqrt(p);
+      if (h < nh) {
+        numer += amp * inst;
+        denom += amp * (h + 1.0);
+        sc += fabs((inst / (h + 1.0) - f0) / f0);
+      }
+    }
+    double rf0 = numer / (denom + kSafe);
+    double rscore = 1.0 / (sc / nh + kSafe);
+    if (rf0 < f0_floor || rf0 > f0_ceil || rscore < 2.5) { rf0 = 0.0; rscore = 0.0; }   // :610-614
+    if (live) {
+      rc[(fr0 + fl) * m.maxc + slot] = rf0;
+      rs[(fr0 + fl) * m.maxc + slot] = rscore;
     }
   }
 }
@@ -1255,10 +1291,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   {
     TimedScope ts_(b.ctx, "hv_band_kernel");
     if (m.conv) {
-      static const bool attr_ = (hipFuncSetAttribute((const void*)hv_band_fft_kernel<2048>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(ConvEvCfg<2048, kHvConvC>::kLdsBytes)) == hipSuccess);
-      (void)attr_;
+      allow_dynamic_lds(*b.ctx, hv_band_fft_kernel<2048>, (int)(ConvEvCfg<2048, kHvConvC>::kLdsBytes));
       const int groups = (m.nch + kHvChGroup - 1) / kHvChGroup;
       hipLaunchKernelGGL(hv_band_fft_kernel<2048>, dim3(W.tiles_max, groups, n_utt), dim3(64),
                          (ConvEvCfg<2048, kHvConvC>::kLdsBytes), st, W.d_yoff, W.d_ylen, W.d_y, (const cpx*)W.d_H, m.nch, m.half0,
@@ -1291,11 +1324,13 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   }
   {
     TimedScope ts_(b.ctx, "hv_refine_kernel");
-    const int lmax = 2 * (int)(1.5 * m.afs / b.p.f0_floor + 1.0) + 1;
-    const size_t lds = sizeof(double) * 4 * (size_t)(lmax + 2);
-    const int grid = (int)(W.tot_b < (int64_t)c.frame_grid ? W.tot_b : (int64_t)c.frame_grid);
-    hipLaunchKernelGGL(hv_refine_kernel, dim3(grid), dim3(64), lds, st, W.d_bframe_utt, W.d_boff, W.d_nb1, m,
-                       W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, lmax, W.tot_b,
+    const size_t lds = sizeof(double) * (size_t)((kRfChunk + 6) * m.cpf) + sizeof(int) * kRfBins + sizeof(int4) * kRfChunk +
+                       sizeof(unsigned short) * (size_t)(kRfChunk * m.maxc);
+    if (m.maxc > 255) return WM_ERR_UNSUPPORTED;                  // a slot is eight bits of a listed pair
+    allow_dynamic_lds(c, hv_refine_kernel, (int)lds);
+    const int64_t grid = (W.tot_b + kRfChunk - 1) / kRfChunk;
+    hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)grid), dim3(256), lds, st, W.d_bframe_utt, W.d_boff, W.d_nb1, m,
+                       W.d_yoff, W.d_ylen, W.d_y, W.d_offc, W.d_ncand1, b.p.f0_floor, b.p.f0_ceil, W.tot_b,
                        (const cpx*)W.d_twid, W.d_rc, W.d_rs);
   }
   {

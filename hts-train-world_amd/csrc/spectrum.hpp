@@ -32,10 +32,12 @@ template <int HALF, int BM> struct SmoothCfg {
   static_assert(64 * kCh >= 64 * kBi + (3 * BM) / 2 + 3, "interpolation reads stay inside the scanned entries");
 };
 
-// DCCorrection in place on arr[0..HALF]; f0 * fft_size / fs + 1 <= BM.
-template <int HALF, int BM>
+// DCCorrection in place on arr[0..HALF]; the corrected bins are 0 .. int(f0 * fft_size / fs), which must be at most
+// COVER (by default the margin BM; CheapTrick's wide instantiation lets f0 up to fs / 2 through, i.e. HALF bins,
+// while its margin is sized by the smoothing width 2 f0 / 3).
+template <int HALF, int BM, int COVER = BM>
 __device__ __forceinline__ void dc_correction_margin(double* arr, double f0, int fs, int fft_size, int lane) {
-  constexpr int T = (BM + 1 + 63) / 64;
+  constexpr int T = (COVER + 1 + 63) / 64;
   const double inv_fft = 1.0 / fft_size;               // power of two: exact
   const int upper = 2 + (int)(f0 * fft_size / fs);
   const int nrep = upper - 1;

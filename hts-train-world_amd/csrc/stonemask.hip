@@ -234,6 +234,12 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   // half of it.  The frames with windows of at most half the maximum run with half the scratch, the rest as before.
   const int lhalf = lmax / 2;
   const double lower = f_low > kFloorF0StoneMask ? f_low : 0.0;
+  // The output is cleared before the lists are made from d_f0: the two must not be the same array (the reference's
+  // StoneMask takes them as separate arrays too, stonemask.h:27-29); refused rather than answered with zeros.
+  if (d_out == d_f0) {
+    set_error("StoneMask: refined_f0 must not alias f0");
+    return WM_ERR_BAD_ARG;
+  }
   int rc = wm_check(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)tf, c.stream));    // stonemask.cpp:186-187
   if (rc) return rc;
   TimedScope ts_(b.ctx, "stonemask_kernel");

@@ -794,7 +794,7 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
                      b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm, b.d_pulse_perm + b.pulse_rec_cap);
 #define WM_SY_CASE(FF)                                                                                          \
   case FF: {                                                                                                    \
-    static const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
+    const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
     hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
                        (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
                        (const int*)b.d_pulse_perm, c.d_scratch);                                                \

@@ -86,7 +86,8 @@ const int64_t* WorldMi355BatchOutputOffsets(const WorldMi355Batch* b);  /* host,
  *   CheapTrick cheaptrick.cpp:200-228 D4C        d4c.cpp:337-397
  *   Synthesis  synthesis.cpp:338-397 (synchronises once internally: the pulse count
  *              decides the size of the overlap-add scratch)
- *   Harvest    harvest.cpp:1223-1255 */
+ *   Harvest    harvest.cpp:1223-1255
+ * refined_f0 of StoneMask must not be the f0 array (WM_ERR_BAD_ARG): the output is cleared first. */
 int WorldMi355Dio(WorldMi355Batch* b, const double* x, double* t, double* f0);
 int WorldMi355StoneMask(WorldMi355Batch* b, const double* x, const double* t, const double* f0,
                         double* refined_f0);

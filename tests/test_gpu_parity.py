@@ -367,8 +367,10 @@ def test_cheaptrick_outside_the_usual_f0_range(gpu, pkg, oracle, fs):
     f0[0::6] = edge - 1.0
     f0[1::6] = edge + 1.0
     f0[2::6] = fs / 4.0
-    f0[3::6] = fs / 3.0                # (towards fs / 2 DCCorrection reads past the half spectrum: undefined in the reference)
+    f0[3::6] = fs / 3.0
     f0[4::6] = 0.0
+    f0[5::12] = 0.45 * fs              # above fs / 3 DCCorrection touches more bins than the smoothing mirror is wide
+    f0[11::12] = 0.4999 * fs           # the last f0 the reference defines (upper_limit = fft_size / 2 + 1, common.cpp:56-75)
     want = oracle.cheaptrick(x, fs, t, f0)
     b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
     got = b.cheaptrick(dev(x), dev(t), dev(f0)).cpu().numpy()
@@ -559,6 +561,65 @@ def test_harvest_against_oracle(gpu, oracle, fs, fp, idxs, dur):
     assert ((f0 > 0) == (fo > 0)).all()
     assert np.abs(f0 - fo).max() < 0.1          # the bar
     np.testing.assert_allclose(f0, fo, atol=F0_TOL, rtol=0)
+    b.close()
+
+
+@pytest.mark.parametrize("fs,fp,lo,hi", [(16000, 5.0, 50.0, 500.0), (16000, 5.0, 100.0, 1000.0), (48000, 1.0, 50.0, 500.0),
+                                         (22050, 2.0, 110.0, 420.0)])
+def test_harvest_option_sweep(gpu, pkg, oracle, fs, fp, lo, hi):
+    """HarvestOption.f0_floor / f0_ceil away from the defaults (harvest.cpp:1223-1262): the range sets the number of
+    filter-bank channels (harvest.cpp:1139-1148: 1 + int(log2(ceil * 1.1 / (floor * 0.9)) * 40)) and the candidate
+    capacity per frame (:334-343), which size the detection and refinement kernels; through the batched entry and
+    through the drop-in Harvest()."""
+    torch, W, ctx = gpu
+    xs = [sd.make_utterance(i, fs, duration=d) for i, d in ((21, 0.9), (22, 1.4))]
+    b = W.WorldBatch(ctx, W.default_params(fs, fp, f0_floor=lo, f0_ceil=hi), x_lengths=[len(x) for x in xs])
+    t, f0 = b.harvest(torch.from_numpy(np.concatenate(xs)).cuda())
+    b.close()
+    ro = [oracle.harvest(x, fs, fp, lo, hi) for x in xs]
+    np.testing.assert_array_equal(t.cpu().numpy(), np.concatenate([r[0] for r in ro]))
+    fo = np.concatenate([r[1] for r in ro])
+    f0 = f0.cpu().numpy()
+    assert (fo > 0).sum() > len(fo) // 10               # the case is not trivially unvoiced
+    assert ((f0 > 0) == (fo > 0)).all()
+    np.testing.assert_allclose(f0, fo, atol=F0_TOL, rtol=0)
+    t1, f1 = pkg.capi.harvest(xs[0], fs, fp, lo, hi)
+    np.testing.assert_array_equal(t1, ro[0][0])
+    np.testing.assert_allclose(f1, ro[0][1], atol=F0_TOL, rtol=0)
+
+
+def test_harvest_full_size_config2(gpu, oracle):
+    """BASELINE.json configs[2] at its full size: Harvest over 64 utterances of 2-8 s at 48 kHz with a 1 ms hop
+    (about 320 k frames).  Properties that need no oracle on everything -- run-to-run bit identity, the time axis,
+    the f0 range (harvest.cpp:1223-1255: zero or inside [floor, ceil]), batch invariance of one utterance -- plus
+    parity on the shortest utterance against the oracle."""
+    torch, W, ctx = gpu
+    fs, fp = 48000, 1.0
+    xs = sd.make_batch(64, fs, (2.0, 8.0), first=0, workers=16)
+    b = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(x) for x in xs])
+    assert b.total_frames > 250_000
+    xc = torch.from_numpy(np.concatenate(xs)).cuda()
+    t, f0 = b.harvest(xc)
+    t1, f01 = t.clone(), f0.clone()
+    t, f0 = b.harvest(xc)
+    assert torch.equal(t, t1) and torch.equal(f0, f01)
+    fo = b.frame_offsets
+    for u in (0, 31, 63):
+        n = fo[u + 1] - fo[u]
+        np.testing.assert_array_equal(t[fo[u]:fo[u + 1]].cpu().numpy(), np.arange(n) * fp / 1000.0)
+    assert bool(((f0 == 0) | ((f0 >= 71.0) & (f0 <= 800.0))).all())
+    voiced = float((f0 > 0).double().mean())
+    assert 0.2 < voiced < 0.98
+    order = np.argsort([len(x) for x in xs])
+    u = int(order[0])
+    b1 = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(xs[u])])
+    _, f0a = b1.harvest(torch.from_numpy(xs[u]).cuda())
+    b1.close()
+    assert torch.equal(f0a, f0[fo[u]:fo[u + 1]])                    # the same bits alone and inside the batch
+    _, want = oracle.harvest(xs[u], fs, fp)
+    got = f0[fo[u]:fo[u + 1]].cpu().numpy()
+    assert ((got > 0) == (want > 0)).all()
+    np.testing.assert_allclose(got, want, atol=F0_TOL, rtol=0)
     b.close()
 
 
@@ -800,6 +861,14 @@ def test_errors_are_reported_not_swallowed(gpu):
         b.code_spectral_envelope(torch.ones(T, b.bins, dtype=torch.float64, device="cuda"), 600)
     with pytest.raises(AssertionError):                    # host-side type check of the mirror
         b.analyze(x.float())
+    t, f0 = b.dio(x)
+    with pytest.raises(RuntimeError):                      # StoneMask clears its output first: in place is refused
+        import ctypes as C
+        lib = W.load_library()
+        rc = lib.WorldMi355StoneMask(b.handle, C.c_void_p(x.data_ptr()), C.c_void_p(t.data_ptr()),
+                                     C.c_void_p(f0.data_ptr()), C.c_void_p(f0.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(lib.WorldMi355LastError())
     b.close()
 
 
