@@ -650,6 +650,50 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
   rs2[fr * m.maxc + s] = sc;
 }
 
+// SearchF0Base (harvest.cpp:693-705) and FixStep1 (:710-722, allowed 0.008) for every basic frame of the batch:
+// a workgroup takes 256 consecutive frames plus the two before them (FixStep1 looks two frames back).  Entries
+// the reference leaves unwritten (f0_base == 0) are zero.  c1 = base, c2 = step 1, sm = 0 (per global frame).
+__global__ __launch_bounds__(256) void hv_base_kernel(const int* __restrict__ bframe_utt, const int64_t* __restrict__ boff,
+                                                      HvMeta m, const int* __restrict__ ncand1_a,
+                                                      const double* __restrict__ rc2, const double* __restrict__ rs2,
+                                                      int64_t tot_b, double* __restrict__ c1, double* __restrict__ c2,
+                                                      double* __restrict__ sm) {
+  __shared__ double bs_[258];
+  const int64_t fr0 = (int64_t)blockIdx.x * 256;
+  for (int e = threadIdx.x; e < 258; e += 256) {
+    const int64_t fr = fr0 - 2 + e;
+    double bv = 0.0;
+    if (fr >= 0 && fr < tot_b) {
+      const int nc = ncand1_a[bframe_utt[fr]] * kHvOverlap;
+      const double* cr = rc2 + fr * m.maxc;
+      const double* sr = rs2 + fr * m.maxc;
+      double bsc = 0.0;
+      for (int j0 = 0; j0 < nc; j0 += 8) {
+        double cv[8], sv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int j = imin(nc - 1, j0 + r); cv[r] = cr[j]; sv[r] = sr[j]; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (j0 + r < nc && sv[r] > bsc) { bv = cv[r]; bsc = sv[r]; }
+      }
+    }
+    bs_[e] = bv;
+  }
+  __syncthreads();
+  const int64_t fr = fr0 + threadIdx.x;
+  if (fr >= tot_b) return;
+  const int k = (int)(fr - boff[bframe_utt[fr]]);              // frame index inside its utterance
+  const double b0 = bs_[threadIdx.x + 2], bm1 = bs_[threadIdx.x + 1], bm2 = bs_[threadIdx.x];
+  double v = 0.0;
+  if (k >= 2 && b0 != 0.0) {
+    const double ref = bm1 * 2 - bm2;
+    v = (fabs((b0 - ref) / ref) > 0.008 && fabs((b0 - bm1)) / bm1 > 0.008) ? 0.0 : b0;
+  }
+  c1[fr] = b0;
+  c2[fr] = v;
+  sm[fr] = 0.0;
+}
+
 // ---- contour logic (sequential along time) -------------------------------------------------
 struct HvCand {                     // candidate table of one utterance after pruning
   const double* c; const double* s; int nc; int stride;
@@ -717,15 +761,16 @@ __device__ __forceinline__ double hv_search_score(double f0, const double* c, co
   return score;
 }
 
-// ---- workgroup-wide (256 threads, uniform control flow) forms of the contour helpers --------------
+// ---- workgroup-wide (kCtThreads threads, uniform control flow) forms of the contour helpers --------------
+constexpr int kCtThreads = 1024, kCtWaves = kCtThreads / 64;
 // Boundaries of a 0/1 sequence (GetBoundaryList, harvest.cpp:727-743): transitions of
 // v(i) = (i == n-1) ? 0 : voiced(i), i in [1, n), against v(i-1) (0 before the first), written in
 // order as list[p] = i - (p & 1).  Ordered compaction by ballots; returns the count to every thread.
 template <class F>
-__device__ __forceinline__ int hv_boundaries_wg(F voiced, int n, int* __restrict__ list, int* sh4) {
+__device__ __forceinline__ int hv_boundaries_wg(F voiced, int n, int* __restrict__ list, int* shw) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int cnt = 0;
-  for (int i0 = 1; i0 < n; i0 += 256) {
+  for (int i0 = 1; i0 < n; i0 += kCtThreads) {
     const int i = i0 + threadIdx.x;
     bool flag = false;
     if (i < n) {
@@ -734,15 +779,20 @@ __device__ __forceinline__ int hv_boundaries_wg(F voiced, int n, int* __restrict
       flag = v != p;
     }
     const unsigned long long bal = __ballot(flag);
-    if (lane == 0) sh4[wv] = __popcll(bal);
+    if (lane == 0) shw[wv] = __popcll(bal);
     __syncthreads();
     int base = cnt;
-    for (int q = 0; q < wv; ++q) base += sh4[q];
+    int all = 0;
+    for (int q = 0; q < kCtWaves; ++q) {
+      const int cq = shw[q];
+      if (q < wv) base += cq;
+      all += cq;
+    }
     if (flag) {
       const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
       list[pos] = i - (pos & 1);
     }
-    cnt += sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    cnt += all;
     __syncthreads();
   }
   return cnt;
@@ -847,8 +897,9 @@ __device__ __forceinline__ double hv_seq_sum_wave(double x, F value, int n, int 
 
 constexpr int kSmLag = 300;      // SmoothF0Contour lag (harvest.cpp:1085)
 constexpr int kSmPar = 32;       // sections filtered concurrently
+constexpr int kSmTail = 320;     // frames beyond a section over which the smoothing filter settles (0.875^320 = 3e-19)
 
-__global__ __launch_bounds__(256) void hv_contour_kernel(
+__global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     const int64_t* __restrict__ boff, const int* __restrict__ nb1_a, HvMeta m, const int* __restrict__ ncand1_a,
     const double* __restrict__ rc2, const double* __restrict__ rs2, int64_t tot_b, int n_utt,
     double* __restrict__ work, int* __restrict__ blist, const int64_t* __restrict__ mdoff, double* __restrict__ mdata,
@@ -874,45 +925,24 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
   int* s_of = s_hi + sec_cap;
   __shared__ int sh_n;
 
-  // SearchF0Base (:693-705) and FixStep1 (:710-722, allowed 0.008); entries the reference leaves
-  // unwritten (f0_base == 0) are zero here
-  for (int i = threadIdx.x; i < nf; i += 256) {
-    double bs = 0.0, bv = 0.0;
-    const double* cr = cd.c + (int64_t)i * cd.stride;
-    const double* sr = cd.s + (int64_t)i * cd.stride;
-    for (int j = 0; j < nc; ++j)
-      if (sr[j] > bs) { bv = cr[j]; bs = sr[j]; }
-    c1[i] = bv;
-    smooth[i] = 0.0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nf; i += 256) {
-    double v = 0.0;
-    if (i >= 2 && c1[i] != 0.0) {
-      const double ref = c1[i - 1] * 2 - c1[i - 2];
-      v = (fabs((c1[i] - ref) / ref) > 0.008 && fabs((c1[i] - c1[i - 1])) / c1[i - 1] > 0.008) ? 0.0 : c1[i];
-    }
-    c2[i] = v;
-  }
-  __syncthreads();
-
-  // ---- from here on all 256 threads run with uniform control flow; bulk loops are thread-parallel,
+  // SearchF0Base and FixStep1 have run for the whole batch (hv_base_kernel): c1 = base, c2 = step 1, smooth = 0
+  // ---- from here on all threads run with uniform control flow; bulk loops are thread-parallel,
   // decisions are recomputed by every thread from values in memory, single writers are thread 0 ----
-  __shared__ int sh4[4];
+  __shared__ int sh4[kCtWaves];
   __shared__ int sh_key[2048], sh_ord[2048];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   // FixStep2 (:748-762, minimum 6): c2 -> c1
-  for (int i = tid; i < nf; i += 256) c1[i] = c2[i];
+  for (int i = tid; i < nf; i += kCtThreads) c1[i] = c2[i];
   int nb = hv_boundaries_wg([&](int i) { return c2[i] > 0; }, nf, bl, sh4);
-  for (int i = tid; i < nb / 2; i += 256) {
+  for (int i = tid; i < nb / 2; i += kCtThreads) {
     const int lo = bl[i * 2], hi = bl[i * 2 + 1];
     if (hi - lo >= 6) continue;
     for (int j = lo; j <= hi; ++j) c1[j] = 0.0;
   }
   __syncthreads();
   // FixStep3 (:968-995, allowed 0.18): c1 -> c2
-  for (int i = tid; i < nf; i += 256) c2[i] = c1[i];
+  for (int i = tid; i < nf; i += kCtThreads) c2[i] = c1[i];
   nb = hv_boundaries_wg([&](int i) { return c1[i] > 0; }, nf, bl, sh4);
   const int nsec = nb / 2;
   if (tid == 0) {                                                  // GetMultiChannelF0 :767-778 (banded rows)
@@ -926,11 +956,11 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
   __syncthreads();
   for (int i = 0; i < nsec; ++i) {
     const int lo = s_lo[i], hi = s_hi[i], of = s_of[i], v0 = bl[i * 2], v1 = bl[i * 2 + 1];
-    for (int j = lo + tid; j <= hi; j += 256) md[of + (j - lo)] = (j >= v0 && j <= v1) ? c1[j] : 0.0;
+    for (int j = lo + tid; j <= hi; j += kCtThreads) md[of + (j - lo)] = (j >= v0 && j <= v1) ? c1[j] : 0.0;
   }
   __syncthreads();
   // Extend :861-878 (in place): a section only touches its own row, so sections go to the four waves
-  for (int i = wv; i < nsec; i += 4) {
+  for (int i = wv; i < nsec; i += kCtWaves) {
     HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
     const int o1 = bl[i * 2 + 1], o0 = bl[i * 2];
     const int e1 = hv_extend_f0_wave(o1, imin(nf - 2, o1 + 100), 1, cd, 0.18, md, sc, lane);
@@ -969,7 +999,7 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
     const bool in_lds = nchn <= 2048;
     int* order = in_lds ? sh_ord : bl2;                            // MakeSortedOrder :883-896
     if (in_lds) {
-      for (int i = tid; i < nchn; i += 256) sh_key[i] = bl[i * 2];
+      for (int i = tid; i < nchn; i += kCtThreads) sh_key[i] = bl[i * 2];
       __syncthreads();
     }
     if (tid == 0) {
@@ -985,7 +1015,7 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
     __syncthreads();
     {
       HvSec s0; s0.lo = s_lo[0]; s0.hi = s_hi[0]; s0.off = s_of[0];
-      for (int i = tid; i < nf; i += 256) c2[i] = hv_get(md, s0, i);
+      for (int i = tid; i < nf; i += kCtThreads) c2[i] = hv_get(md, s0, i);
     }
     // boundary_list[0], [1] of the reference double as the running start / end of the merged contour
     int run_st = bl[0], run_ed = bl[1];
@@ -995,14 +1025,14 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
       HvSec so; so.lo = s_lo[o]; so.hi = s_hi[o]; so.off = s_of[o];
       const int st2 = o == 0 ? run_st : bl[o * 2], ed2 = o == 0 ? run_ed : bl[o * 2 + 1];
       if (st2 - run_ed > 0) {
-        for (int j = st2 + tid; j <= ed2; j += 256) c2[j] = hv_get(md, so, j);
+        for (int j = st2 + tid; j <= ed2; j += kCtThreads) c2[j] = hv_get(md, so, j);
         run_st = st2;
         run_ed = ed2;
       } else {                                                     // MergeF0Sub :912-932
         const int st1 = run_st, ed1 = run_ed;
         if (!(st1 <= st2 && ed1 >= ed2)) {
           // per-frame scores in parallel (c1 / best are free here), then the two sums in frame order
-          for (int k = st2 + tid; k <= ed1; k += 256) {
+          for (int k = st2 + tid; k <= ed1; k += kCtThreads) {
             const double* cr = cd.c + (int64_t)k * cd.stride;
             const double* sr = cd.s + (int64_t)k * cd.stride;
             c1[k] = hv_search_score_row(c2[k], cr, sr, nc);
@@ -1012,8 +1042,8 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
           const double sc1 = hv_seq_sum_wave(0.0, [&](int q) { return c1[st2 + q]; }, ed1 - st2 + 1, lane);
           const double sc2 = hv_seq_sum_wave(0.0, [&](int q) { return best[st2 + q]; }, ed1 - st2 + 1, lane);
           __syncthreads();
-          if (sc1 > sc2) { for (int k = ed1 + tid; k <= ed2; k += 256) c2[k] = hv_get(md, so, k); }
-          else { for (int k = st2 + tid; k <= ed2; k += 256) c2[k] = hv_get(md, so, k); }
+          if (sc1 > sc2) { for (int k = ed1 + tid; k <= ed2; k += kCtThreads) c2[k] = hv_get(md, so, k); }
+          else { for (int k = st2 + tid; k <= ed2; k += kCtThreads) c2[k] = hv_get(md, so, k); }
           run_ed = ed2;
         }
       }
@@ -1021,9 +1051,9 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
     }
   }
   // FixStep4 (:1000-1022, threshold 9): c2 -> best
-  for (int i = tid; i < nf; i += 256) best[i] = c2[i];
+  for (int i = tid; i < nf; i += kCtThreads) best[i] = c2[i];
   nb = hv_boundaries_wg([&](int i) { return c2[i] > 0; }, nf, bl, sh4);
-  for (int i = tid; i < nb / 2 - 1; i += 256) {
+  for (int i = tid; i < nb / 2 - 1; i += kCtThreads) {
     const int e0 = bl[i * 2 + 1], s1 = bl[(i + 1) * 2];
     const int distance = s1 - e0 - 1;
     if (distance >= 9) continue;
@@ -1041,59 +1071,62 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
     if (tid == 0) sh_n = cnt / 2;
   }
   __syncthreads();
-  // FilteringF0 (:1049-1074) per section, kSmPar sections at a time, one thread each
+  // FilteringF0 (:1049-1074) per section, kSmPar sections at a time, one thread each.  The reference runs both
+  // passes of the zero-lag filter over the whole padded contour; outside [st, ed] the input is constant (x[st]
+  // before, x[ed] after, :1054-1055) for at least the 300 frames of padding, and the filter's poles have radius
+  // 0.875 (0.875^300 = 4e-18): at st the forward pass is in its steady state for the constant x[st], and the
+  // backward pass, which only has to deliver [st, ed], is in its steady state kSmTail frames beyond ed.  Both
+  // passes therefore run over [st, ed + kSmTail] from those states -- a few hundred steps per section instead of
+  // two times the utterance.
   {
     const int nsec = sh_n;
     const int nn = nf + 2 * kSmLag;
     const double fb0 = 0.0078202080334971724, fb1 = 0.015640416066994345;
     const double fa0 = 1.7347257688092754, fa1 = -0.76600660094326412;
+    const double dc = 1.0 - fa0 - fa1;                                // w = x / dc for a constant input x
     double* sm = smbuf + smoff[u];
     for (int base = 0; base < nsec; base += kSmPar) {
       const int sidx = base + threadIdx.x;
       if (threadIdx.x < kSmPar && sidx < nsec) {
 #pragma clang fp contract(off)
         const int st = bl[sidx * 2], ed = bl[sidx * 2 + 1];          // padded coordinates
-        double* tmp = sm + (int64_t)threadIdx.x * nn;
-        const double xs = best[st - kSmLag], xe = best[ed - kSmLag];
+        const int last = imin(nn - 1, ed + kSmTail);
+        double* tmp = sm + (int64_t)threadIdx.x * nn;                 // forward output at padded position st + q
+        const double xe = best[ed - kSmLag];
         // Both passes are strictly sequential recurrences; what can be taken off the chain is the
         // memory traffic: inputs are fetched 16 steps at a time (independent loads, one round trip per
         // block instead of one per step) and results are stored without waiting.
         constexpr int kBlk = 16;
-        double w0 = 0.0, w1 = 0.0;
-        for (int i0 = 0; i0 < nn; i0 += kBlk) {
+        double w0 = best[st - kSmLag] / dc, w1 = w0;
+        for (int i0 = st; i0 <= last; i0 += kBlk) {
           double xin[kBlk];
 #pragma unroll
-          for (int r = 0; r < kBlk; ++r) {
-            const int i = i0 + r;
-            const int jc = imin(nf - 1, imax(0, imin(ed, imax(st, i)) - kSmLag));
-            xin[r] = best[jc];
-          }
+          for (int r = 0; r < kBlk; ++r) xin[r] = best[imin(ed, i0 + r) - kSmLag];
 #pragma unroll
           for (int r = 0; r < kBlk; ++r) {
             const int i = i0 + r;
-            if (i < nn) {
-              const double xi = i < st ? xs : (i > ed ? xe : xin[r]);
+            if (i <= last) {
+              const double xi = i > ed ? xe : xin[r];
               const double wt = xi + fa0 * w0 + fa1 * w1;
-              tmp[nn - i - 1] = fb0 * wt + fb1 * w0 + fb0 * w1;
+              tmp[i - st] = fb0 * wt + fb1 * w0 + fb0 * w1;
               w1 = w0; w0 = wt;
             }
           }
         }
         __threadfence_block();                                    // the second pass reads what the first wrote
-        w0 = w1 = 0.0;
-        for (int i0 = 0; i0 < nn; i0 += kBlk) {
+        w0 = w1 = tmp[last - st] / dc;
+        for (int i0 = last; i0 >= st; i0 -= kBlk) {
           double tin[kBlk];
 #pragma unroll
-          for (int r = 0; r < kBlk; ++r) tin[r] = tmp[imin(nn - 1, i0 + r)];
+          for (int r = 0; r < kBlk; ++r) tin[r] = tmp[imax(st, i0 - r) - st];
 #pragma unroll
           for (int r = 0; r < kBlk; ++r) {
-            const int i = i0 + r;
-            if (i < nn) {
+            const int i = i0 - r;
+            if (i >= st) {
               const double wt = tin[r] + fa0 * w0 + fa1 * w1;
               const double o = fb0 * wt + fb1 * w0 + fb0 * w1;
               w1 = w0; w0 = wt;
-              const int j = nn - i - 1;
-              if (j >= st && j <= ed) smooth[j - kSmLag] = o;
+              if (i <= ed) smooth[i - kSmLag] = o;
             }
           }
         }
@@ -1105,7 +1138,7 @@ __global__ __launch_bounds__(256) void hv_contour_kernel(
   // final resampling to the requested frame period (:1230-1251)
   const int64_t fo = f_off[u];
   const int nout = (int)(f_off[u + 1] - fo);
-  for (int i = threadIdx.x; i < nout; i += 256) {
+  for (int i = threadIdx.x; i < nout; i += kCtThreads) {
     const double t = i * frame_period / 1000.0;
     t_out[fo + i] = t;
     f0_out[fo + i] = frame_period == 1.0 ? smooth[i] : smooth[imin(nf - 1, matlab_round(t * 1000.0))];
@@ -1341,7 +1374,9 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   }
   {
     TimedScope ts_(b.ctx, "hv_contour_kernel");
-    hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(256), 0, st, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc2,
+    hipLaunchKernelGGL(hv_base_kernel, dim3((unsigned)((W.tot_b + 255) / 256)), dim3(256), 0, st, W.d_bframe_utt, W.d_boff, m,
+                       W.d_ncand1, W.d_rc2, W.d_rs2, W.tot_b, W.d_work, W.d_work + W.tot_b, W.d_work + 3 * W.tot_b);
+    hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(kCtThreads), 0, st, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc2,
                        W.d_rs2, W.tot_b, n_utt, W.d_work, W.d_bl, W.d_mdoff, W.d_md, W.d_sec, W.d_smoff, W.d_sm,
                        b.d_f_off, b.p.frame_period, d_t, d_f0);
   }
