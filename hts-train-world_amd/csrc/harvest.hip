@@ -9,7 +9,7 @@
 //   hv_mean_kernel           mean removal over y_length                       harvest.cpp:81-86
 //   hv_band_kernel           152 cos-modulated Nuttall band-pass FIRs + four zero-crossing event
 //                            lists per channel (zcfilter.hpp)                 :99-238
-//   hv_raw_kernel            per (frame, channel) interp1 of the four tracks  :240-293, 334-343
+//   hv_raw_kernel            interp1 of the four tracks per channel, runs of frames walked  :240-293, 334-343
 //   hv_detect_kernel         runs of >= 10 voiced channels -> candidates      :348-412
 //   hv_refine_kernel         instantaneous-frequency refinement of every (frame, overlapped
 //                            candidate): direct DFT at <= 6 bins instead of two FFTs  :417-631
@@ -61,6 +61,7 @@ struct HarvestWs {
   int64_t *d_yoff = nullptr, *d_toff = nullptr, *d_evoff = nullptr, *d_boff = nullptr, *d_mdoff = nullptr,
           *d_smoff = nullptr;
   int* d_bframe_utt = nullptr;                 // [tot_b]
+  int* d_run_utt = nullptr; int* d_run_first = nullptr; int64_t n_runs = 0;   // runs of kRawRun frames (hv_raw_kernel)
   double* d_bf = nullptr; int* d_half = nullptr; int* d_tapoff = nullptr; double* d_taps = nullptr;
   double* d_y = nullptr; double* d_tmp = nullptr;
   double* d_events = nullptr; int* d_evcnt = nullptr;
@@ -205,91 +206,128 @@ __global__ __launch_bounds__(256) void hv_band_compact_kernel(
 }
 
 // raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
-// GetF0CandidateContour(+Sub) (harvest.cpp:240-293).  A workgroup is 256 consecutive basic frames of
-// one channel: their query times span 256 ms, so the events they can touch are a short slice of each
-// of the four lists.  The slice is located once (two uniform searches per list), staged in LDS, and
-// every thread searches there -- same comparisons, same results, without 44 dependent global loads per
-// thread.  Workgroups that straddle two utterances, or whose slice exceeds the LDS tile, use the
-// global lists directly.
-constexpr int kRawStage = 384;
-__global__ __launch_bounds__(256, 8) void hv_raw_kernel(const int* __restrict__ bframe_utt,
-                                                     const int64_t* __restrict__ boff,
-                                                     const int* __restrict__ ylen_a, HvMeta m,
-                                                     const double* __restrict__ bf, double f0_floor, double f0_ceil,
-                                                     const int64_t* __restrict__ evoff,
-                                                     const double* __restrict__ events,
-                                                     const int* __restrict__ evcnt, int64_t tot_b,
+// GetF0CandidateContour(+Sub) (harvest.cpp:240-293): per channel the four zero-crossing tracks are interpolated
+// (interp1, matlabfunctions.cpp:136-182) at every basic frame time and averaged.  The frame times of an utterance
+// are increasing and so are a track's knots (locations[j] = (e[j] + e[j+1]) / 2 / fs), so the knot interval of a
+// frame is found by WALKING, not searching: a thread owns kRawRun consecutive frames of one channel, finds the
+// interval of its first frame once (one binary search per track) and then steps forward -- a knot interval lasts
+// 1 to 15 frames; entering the next one costs its right knot and value (two divisions; the edges it needs were
+// requested two intervals earlier), a frame costs a comparison and the interpolation.  The predicate that moves to the next interval is the literal
+// "locations[k] <= t" of the reference's histc, so the intervals are the reference's.  The form this replaces
+// searched per frame (four binary searches and twenty divisions per frame and channel, 1 040 instructions).
+// Lanes of a wavefront are consecutive channels of the same run, so the stores are rows of raw[frame][channel].
+constexpr int kRawRun = 128;
+
+struct RawTrack {                 // one zero-crossing track of a channel, positioned on a knot interval
+  const double* e;                // fine edges, n + 1 of them
+  int n;                          // knots (locations) 0 .. n-1
+  int lo;                         // number of knots at or before the current time (histc's count)
+  int k;                          // lo clamped to [1, n-1]: the interval [knot k-1, knot k]
+  double w[5];                    // e[k-1 .. k+3] (indices clamped to n): the two edges past the interval are fetched
+                                  // when the interval is entered and used one and two intervals later
+  double x0, x1, y0, y1;          // knots k-1, k and the values there (dio.cpp:384-387 via harvest.cpp:188-200)
+  double h, dy, next;             // x1 - x0, y1 - y0; the knot that ends the stay (knot lo), +inf beyond the last
+};
+__device__ __forceinline__ void raw_next_knot(RawTrack& tr) {
+  tr.next = tr.lo == 0 ? tr.x0 : (tr.lo < tr.n ? tr.x1 : HUGE_VAL);      // knot lo is x1 in the interior, x0 before knot 0
+}
+__device__ __forceinline__ void raw_init(RawTrack& tr, double fs) {
+  const int k = tr.lo < 1 ? 1 : (tr.lo > tr.n - 1 ? tr.n - 1 : tr.lo);
+  tr.k = k;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) tr.w[j] = tr.e[imin(tr.n, k - 1 + j)];
+  tr.x0 = (tr.w[0] + tr.w[1]) / 2.0 / fs;
+  tr.x1 = (tr.w[1] + tr.w[2]) / 2.0 / fs;
+  tr.y0 = fs / (tr.w[1] - tr.w[0]);
+  tr.y1 = fs / (tr.w[2] - tr.w[1]);
+  tr.h = tr.x1 - tr.x0;
+  tr.dy = tr.y1 - tr.y0;
+  raw_next_knot(tr);
+}
+// one more knot lies at or before the current time
+__device__ __forceinline__ void raw_advance(RawTrack& tr, double fs) {
+  ++tr.lo;
+  const int k = tr.lo > tr.n - 1 ? tr.n - 1 : tr.lo;           // lo >= 1 here
+  if (k != tr.k) {                                              // the next interval: its left knot is the old right one
+    tr.k = k;
+    tr.w[0] = tr.w[1]; tr.w[1] = tr.w[2]; tr.w[2] = tr.w[3]; tr.w[3] = tr.w[4];
+    tr.w[4] = tr.e[imin(tr.n, k + 3)];
+    tr.x0 = tr.x1;
+    tr.y0 = tr.y1;
+    tr.x1 = (tr.w[1] + tr.w[2]) / 2.0 / fs;
+    tr.y1 = fs / (tr.w[2] - tr.w[1]);
+    tr.h = tr.x1 - tr.x0;
+    tr.dy = tr.y1 - tr.y0;
+  }
+  raw_next_knot(tr);
+}
+
+// quad_perm DPP: the value of lane (4 * (lane / 4) + Q) of the same quad
+template <int Q>
+__device__ __forceinline__ double quad_lane(double v) {
+  return dpp_get<Q | (Q << 2) | (Q << 4) | (Q << 6), 0xf, 0xf>(v);
+}
+
+// A thread walks ONE track: the four tracks of a channel sit in the four lanes of a quad (forty registers of state
+// per lane instead of 130, eight waves per SIMD to cover the trips to memory of a step that advances), and the
+// average is taken across the quad in the reference's order of summation.
+__global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ run_utt, const int* __restrict__ run_first,
+                                                     int64_t n_items, const int64_t* __restrict__ boff,
+                                                     const int* __restrict__ nb1_a, const int* __restrict__ ylen_a,
+                                                     HvMeta m, const double* __restrict__ bf, double f0_floor,
+                                                     double f0_ceil, const int64_t* __restrict__ evoff,
+                                                     const double* __restrict__ events, const int* __restrict__ evcnt,
                                                      double* __restrict__ raw) {
-  __shared__ double le[4][kRawStage];
-  const int ch = blockIdx.y;
-  const int64_t fr0 = (int64_t)blockIdx.x * 256;
-  const int64_t fr = fr0 + threadIdx.x;
-  const int64_t frl = fr0 + 255 < tot_b ? fr0 + 255 : tot_b - 1;
-  const int u0 = bframe_utt[fr0], ul = bframe_utt[frl];
-  bool staged = u0 == ul;
-  int A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, base[4] = {0, 0, 0, 0}, nint[4] = {0, 0, 0, 0};
-  bool ok = true;
-  const int uu = fr < tot_b ? bframe_utt[fr] : u0;
-  const int cap = ylen_a[uu] / 2 + 2;
-  const int* cnt = evcnt + ((int64_t)uu * m.nch + ch) * 4;
-  const double* ev = events + evoff[uu] + (int64_t)ch * 4 * cap;
-#pragma unroll
-  for (int ty = 0; ty < 4; ++ty) {
-    nint[ty] = cnt[ty] < 2 ? 0 : cnt[ty] - 1;
-    ok = ok && nint[ty] > 2;                                   // CheckEvent(n - 2), :263-266
+  // item = ((run, channel), track), track fastest; threads past the end shadow the last item and store nothing
+  const int64_t tid_all = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool real = tid_all < n_items * 4;
+  const int64_t item = (real ? tid_all : n_items * 4 - 1) >> 2;
+  const int ty = threadIdx.x & 3;
+  const int run = (int)(item / m.nch), ch = (int)(item - (int64_t)run * m.nch);
+  const int u = run_utt[run], k0 = run_first[run];
+  const int k1 = imin(nb1_a[u], k0 + kRawRun);
+  const int cap = ylen_a[u] / 2 + 2;
+  const int c = evcnt[((int64_t)u * m.nch + ch) * 4 + ty];
+  const double fs = m.afs;
+  double* out = raw + (boff[u] + k0) * m.nch + ch;
+  RawTrack tr;
+  tr.e = events + evoff[u] + ((int64_t)ch * 4 + ty) * cap;
+  tr.n = c < 2 ? 0 : c - 1;
+  // CheckEvent(n - 2) on all four tracks (:263-266): the quad's lanes agree on the outcome
+  const bool mine_ok = tr.n > 2;
+  const double okf = mine_ok ? 1.0 : 0.0;
+  const bool ok = quad_lane<0>(okf) + quad_lane<1>(okf) + quad_lane<2>(okf) + quad_lane<3>(okf) == 4.0;
+  const bool writer = real && ty == 0;
+  if (!ok) {                                                     // quad-uniform
+    if (writer)
+      for (int k = k0; k < k1; ++k) out[(int64_t)(k - k0) * m.nch] = 0.0;
+    return;
   }
-  __shared__ int sAB[8];
-  if (staged && ok) {                                           // uniform: one utterance, same lists
-    // eight searches per workgroup (four lists, first and last query time), 32 lanes each (zc_upper_group32:
-    // three dependent loads per search; one lane per search walked fifteen, the kernel's whole latency)
-    {
-      const int sr = threadIdx.x >> 5, ty = sr >> 1;
-      const int64_t fq = (sr & 1) ? frl : fr0;
-      int nty = nint[0];
+  tr.lo = zc_upper(tr.e, tr.n, fs, k0 * 1 / 1000.0);             // basic frame period 1 ms (:1174-1175)
+  raw_init(tr, fs);
+  const double b = bf[ch];
+  const double b_hi = b * 1.1, b_lo = b * 0.9;
+  // Eight frames per trip, their values stored together: a store counts in vmcnt like a load and completes in issue
+  // order with it, so a store per frame made every wait for a prefetched edge also a wait for the store before it
+  // (2.3 us per frame; the kernel waited 69 % of its cycles).
+  constexpr int kGrp = 8;
+  for (int kb = k0; kb < k1; kb += kGrp) {
+    double cv[kGrp];
 #pragma unroll
-      for (int q = 1; q < 4; ++q) nty = ty == q ? nint[q] : nty;
-      const int r = zc_upper_group32(ev + (int64_t)ty * cap, nty, m.afs, (int)(fq - boff[u0]) * 1 / 1000.0,
-                                     threadIdx.x & 31, (threadIdx.x & 32) != 0);
-      if ((threadIdx.x & 31) == 0) sAB[sr] = r;
+    for (int j = 0; j < kGrp; ++j) {
+      const double t = (kb + j) * 1 / 1000.0;
+      while (tr.next <= t) raw_advance(tr, fs);                   // histc: knots at or before t
+      const double sfrac = (t - tr.x0) / tr.h;
+      const double v = tr.y0 + sfrac * tr.dy;
+      const double c4 = (quad_lane<0>(v) + quad_lane<1>(v) + quad_lane<2>(v) + quad_lane<3>(v)) / 4.0;
+      cv[j] = (c4 > b_hi || c4 < b_lo || c4 > f0_ceil || c4 < f0_floor) ? 0.0 : c4;   // :243-252
+    }
+    if (writer) {
+#pragma unroll
+      for (int j = 0; j < kGrp; ++j)
+        if (kb + j < k1) out[(int64_t)(kb + j - k0) * m.nch] = cv[j];
     }
   }
-  __syncthreads();
-  if (staged && ok) {
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-      A[ty] = sAB[2 * ty];
-      B[ty] = sAB[2 * ty + 1];
-      base[ty] = imax(0, imin(A[ty], nint[ty] - 1) - 1);
-      const int top = imin(nint[ty], imax(B[ty], 1) + 1);      // last index needed (k + 1 <= n)
-      if (top - base[ty] + 1 > kRawStage) staged = false;
-    }
-  }
-  staged = staged && ok;
-  if (staged) {
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
-      const double* e = ev + (int64_t)ty * cap;
-      const int top = imin(nint[ty], imax(B[ty], 1) + 1);
-      for (int i = base[ty] + threadIdx.x; i <= top; i += 256) le[ty][i - base[ty]] = e[i];
-    }
-  }
-  __syncthreads();
-  if (fr >= tot_b) return;
-  double c = 0.0;
-  if (ok) {
-    const double t = (int)(fr - boff[uu]) * 1 / 1000.0;        // basic frame period 1 ms (:1174-1175)
-    double v[4];
-    bool exact = false;
-    const double hmax = zc_hmax(m.afs, t, exact);
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty)
-      v[ty] = staged ? zc_track_staged(le[ty], base[ty], A[ty], B[ty], nint[ty], m.afs, t, hmax, exact)
-                     : zc_track(ev + (int64_t)ty * cap, nint[ty], m.afs, t);
-    c = (v[0] + v[1] + v[2] + v[3]) / 4.0;
-    const double b = bf[ch];
-    if (c > b * 1.1 || c < b * 0.9 || c > f0_ceil || c < f0_floor) c = 0.0;   // :243-252
-  }
-  raw[fr * m.nch + ch] = c;
 }
 
 // DetectOfficialF0Candidates (harvest.cpp:348-412): one thread per frame
@@ -1226,6 +1264,14 @@ static int hv_setup(Batch& b) {
   up((void**)&W->d_mdoff, W->mdoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
   up((void**)&W->d_smoff, W->smoff.data(), sizeof(int64_t) * ((size_t)n_utt + 1));
   up((void**)&W->d_bframe_utt, bfu.data(), sizeof(int) * bfu.size());
+  {
+    std::vector<int> ru, rf;
+    for (int u = 0; u < n_utt; ++u)
+      for (int k = 0; k < W->nb1[(size_t)u]; k += kRawRun) { ru.push_back(u); rf.push_back(k); }
+    W->n_runs = (int64_t)ru.size();
+    up((void**)&W->d_run_utt, ru.data(), sizeof(int) * ru.size());
+    up((void**)&W->d_run_first, rf.data(), sizeof(int) * rf.size());
+  }
   up((void**)&W->d_bf, bf.data(), sizeof(double) * bf.size());
   up((void**)&W->d_half, half.data(), sizeof(int) * half.size());
   up((void**)&W->d_tapoff, tapoff.data(), sizeof(int) * tapoff.size());
@@ -1341,11 +1387,12 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     hipLaunchKernelGGL(hv_band_compact_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
                        m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
   }
-  const int gx = (int)((W.tot_b + 255) / 256);
   {
     TimedScope ts_(b.ctx, "hv_raw_kernel");
-    hipLaunchKernelGGL(hv_raw_kernel, dim3(gx, m.nch), dim3(256), 0, st, W.d_bframe_utt, W.d_boff, W.d_ylen, m,
-                       W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.d_evoff, W.d_events, W.d_evcnt, W.tot_b, W.d_raw);
+    const int64_t items = W.n_runs * m.nch;                      // four threads (the four tracks) each
+    hipLaunchKernelGGL(hv_raw_kernel, dim3((unsigned)((items * 4 + 255) / 256)), dim3(256), 0, st, W.d_run_utt, W.d_run_first,
+                       items, W.d_boff, W.d_nb1, W.d_ylen, m, W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.d_evoff, W.d_events,
+                       W.d_evcnt, W.d_raw);
   }
   (void)hipMemsetAsync(W.d_ncand1, 0, sizeof(int) * (size_t)n_utt, st);
   if (m.nch > 192) return WM_ERR_UNSUPPORTED;                    // hv_detect_kernel: channel mask of 3 words

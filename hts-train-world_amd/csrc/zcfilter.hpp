@@ -275,7 +275,6 @@ __device__ __forceinline__ double zc_track(const double* __restrict__ e, int n, 
 }
 
 
-// ---- the same lookup for a block of queries with nearby times -------------------------------------
 // upper_bound index alone (the first part of zc_track), literal comparisons
 __device__ __forceinline__ int zc_upper(const double* __restrict__ e, int n, double fs, double t) {
   int lo = 0, hi = n;
@@ -286,49 +285,4 @@ __device__ __forceinline__ int zc_upper(const double* __restrict__ e, int n, dou
   }
   return lo;
 }
-// The same upper bound found by 32 lanes together (`l` = lane of the group, `upper_half` = whether the group is
-// the upper half of its wavefront; every lane of the wavefront must call): each round probes 32 evenly spaced
-// positions of the remaining range in ONE trip to memory and keeps the gap between the last passing and the first
-// failing probe, so a list of 30 000 events takes three dependent loads instead of fifteen.  The predicate and
-// therefore the result are those of zc_upper.
-__device__ __forceinline__ int zc_upper_group32(const double* __restrict__ e, int n, double fs, double t, int l,
-                                                bool upper_half) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int step = (hi - lo + 31) >> 5;
-    const int idx = lo + l * step;
-    bool pass = false;
-    if (idx < hi) pass = (e[idx] + e[idx + 1]) / 2.0 / fs <= t;
-    const unsigned long long vote = __ballot(pass);
-    const int c = __popc((unsigned)(upper_half ? vote >> 32 : vote));   // passing probes: a prefix (monotone)
-    if (c == 0) {
-      hi = lo;
-    } else {
-      const int first_fail = lo + c * step;
-      lo = lo + (c - 1) * step + 1;
-      hi = first_fail < hi ? first_fail : hi;
-    }
-  }
-  return lo;
-}
-// zc_track for a query whose upper_bound is known to lie in [A, B]; le[] holds e[base .. ] (LDS).
-// hmax / exact from zc_hmax(fs, t): the probes compare half-sums, no division (same decisions).
-__device__ __forceinline__ double zc_track_staged(const double* le, int base, int A, int B, int n, double fs,
-                                                  double t, double hmax, bool exact) {
-  int lo = A, hi = B;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const double half = (le[mid - base] + le[mid + 1 - base]) / 2.0;
-    const bool le_t = exact ? half <= hmax : half / fs <= t;
-    if (le_t) lo = mid + 1; else hi = mid;
-  }
-  const int k = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
-  const double e0 = le[k - 1 - base], e1 = le[k - base], e2 = le[k + 1 - base];
-  const double x0 = (e0 + e1) / 2.0 / fs, x1 = (e1 + e2) / 2.0 / fs;
-  const double y0 = fs / (e1 - e0), y1 = fs / (e2 - e1);
-  const double h = x1 - x0;
-  const double sfrac = (t - x0) / h;
-  return y0 + sfrac * (y1 - y0);
-}
-
 }  // namespace wm
