@@ -5,15 +5,19 @@ One "step" = one pass of the hot path over one batch of synthetic 16 kHz utteran
 already resident in HBM: Dio -> StoneMask -> CheapTrick -> D4C (analysis) then Synthesis from the
 features just produced, every utterance of the batch, fp64 as the reference computes.  Workload at
 N=1 is BASELINE.json configs[1]: 256 synthetic utterances of 2-8 s.  With --gpus N every rank owns
-its own 256 utterances (weak scaling, no data-path collective); `--gather` adds the RCCL gather-v
-of the float32 feature files to rank 0 inside the step.
+its own 256 utterances (weak scaling, no data-path collective); at N > 1 the line also carries
+`with_gather`: the same step followed by the RCCL gather-v of the float32 feature files to rank 0.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- dominant kernel (d4c_kernel): algorithmic bytes per launch / HIP-event duration
-                  measured on the launch stream, against the 8 TB/s HBM peak; the FP64 figures that
-                  actually bound the path are reported beside it.
-  cpu_baseline -- the reference WORLD (oracle/_ref, kind "reference") or this repo's C restatement
-                  (kind "port") timed single-threaded on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0 (contract in the task description) with these extra objects:
+  roofline       -- dominant kernel (d4c_kernel): algorithmic bytes per launch / HIP-event duration
+                    measured on the launch stream, against the 8 TB/s HBM peak; the FP64 figures that
+                    actually bound the path are reported beside it.
+  cpu_baseline   -- the reference WORLD (oracle/_ref, kind "reference") or this repo's C restatement
+                    (kind "port") timed single-threaded on a bounded sample of the same workload.
+  side_workloads -- (N = 1, default run) compact lines of the other BASELINE.json configurations, measured in the
+                    same process after the headline: configs[2] Harvest, configs[4] Synthesis only, configs[3]
+                    the corpus sweep; each with its own roofline / cpu_baseline / parity.  `--workload X` runs
+                    one of them alone and prints its full line.
 """
 from __future__ import annotations
 
@@ -39,13 +43,16 @@ def byte_model(fs, fp_ms, fft_size):
     """Algorithmic HBM bytes per frame, fp64 C-API layout:
       analysis  : hop samples*8 + t 8 + f0 8 + sp bins*8 + ap bins*8   (8864 at 16 kHz / 5 ms / fft 1024)
       synthesis : f0 8 + sp + ap + hop samples*8                       (8856)
-      d4c_kernel: its hop new samples + t + f0 + ap0 in, one ap row out (4768)"""
+      d4c_kernel: its hop new samples + t + f0 + ap0 in, one ap row out (4768)
+      pulse     : synth_pulse_kernel: f0 + one sp row + one ap row in per frame (its responses are intermediates,
+                  y is the overlap-add kernel's)                       (8216)"""
     hop = fs * fp_ms / 1000.0
     bins = fft_size // 2 + 1
     analysis = hop * 8 + 16 + 2 * bins * 8
     synthesis = 8 + 2 * bins * 8 + hop * 8
     d4c = hop * 8 + 24 + bins * 8
-    return {"analysis": analysis, "synthesis": synthesis, "round_trip": analysis + synthesis, "d4c": d4c}
+    return {"analysis": analysis, "synthesis": synthesis, "round_trip": analysis + synthesis, "d4c": d4c,
+            "pulse": 8 + 2 * bins * 8}
 
 
 def d4c_flops_per_voiced_frame(fs):
@@ -56,23 +63,43 @@ def d4c_flops_per_voiced_frame(fs):
     return (5 + bands) * 2.5 * fd * np.log2(fd)
 
 
-# HBM-side bytes of the dominant kernel come from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# runs, tools/pmc_hbm.sh) stored in profiles/pmc_traffic.json together with a hash of the kernel's sources: when the
-# sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
-D4C_SOURCES = ("d4c.hip", "d4c_big.hpp", "peel.hpp", "fft.hpp", "frame.hpp", "spectrum.hpp", "common.hpp", "window.hpp",
-               "partition.hpp", "wavesync.hpp")
+# HBM-side bytes of a workload's dominant kernel come from PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+# runs, tools/profile_round.sh) stored in profiles/pmc_traffic.json together with a hash of the kernel's sources: when
+# the sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
+# The counter readings are corrected by the factors measured with tools/micro/hbmcal.hip on this chip
+# (profiles/hbm_counter_calibration.json; MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half the bytes read).
+COMMON_SOURCES = ("fft.hpp", "common.hpp", "wavesync.hpp", "partition.hpp")
+KERNEL_SOURCES = {
+    "analysis_synthesis": ("d4c.hip", "d4c_big.hpp", "peel.hpp", "frame.hpp", "spectrum.hpp", "window.hpp") + COMMON_SOURCES,
+    "harvest": ("harvest.hip", "fftconv.hpp", "zcfilter.hpp", "decimate.hpp") + COMMON_SOURCES,
+    "synthesis": ("synthesis.hip", "frame.hpp", "spectrum.hpp", "window.hpp") + COMMON_SOURCES,
+}
+KERNEL_SOURCES["sweep"] = KERNEL_SOURCES["analysis_synthesis"]
 
 
-def kernel_source_hash():
+def kernel_source_hash(workload="analysis_synthesis"):
     import hashlib
     h = hashlib.sha256()
-    for n in D4C_SOURCES:
+    for n in KERNEL_SOURCES[workload]:
         with open(os.path.join(ROOT, "hts-train-world_amd", "csrc", n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def measured_traffic(fs):
+def counter_calibration():
+    """(fetch factor, write factor, note) from profiles/hbm_counter_calibration.json; (1, 1, why) without it."""
+    path = os.path.join(ROOT, "profiles", "hbm_counter_calibration.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+        return (float(c["fetch_factor_8B_per_lane"]), float(c["write_factor_8B_per_lane"]),
+                "counters x (%.2f read, %.2f write): profiles/hbm_counter_calibration.json (tools/micro/hbmcal.hip, 8 B per lane)"
+                % (c["fetch_factor_8B_per_lane"], c["write_factor_8B_per_lane"]))
+    except (OSError, ValueError, KeyError):
+        return 1.0, 1.0, "uncalibrated counters (profiles/hbm_counter_calibration.json missing)"
+
+
+def measured_traffic(fs, workload="analysis_synthesis"):
     """(bytes per frame, note) from profiles/pmc_traffic.json, or (None, reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -80,15 +107,17 @@ def measured_traffic(fs):
             recs = json.load(f)
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json missing"
-    sha = kernel_source_hash()
-    mine = [r for r in recs if r.get("fs") == fs]
+    key = "analysis_synthesis" if workload == "sweep" else workload
+    sha = kernel_source_hash(key)
+    mine = [r for r in recs if r.get("fs") == fs and r.get("workload", "analysis_synthesis") == key]
     if not mine:
-        return None, "no PMC passes recorded for fs %d in profiles/pmc_traffic.json" % fs
+        return None, "no PMC passes recorded for %s at fs %d in profiles/pmc_traffic.json" % (key, fs)
+    ff, wf, cal = counter_calibration()
     for r in mine:
         if r.get("source_sha") == sha:
-            per = (r["fetch_kb"] + r["write_kb"]) * 1024.0 / r["frames"]
-            return per, "PMC FETCH_SIZE + WRITE_SIZE of %s, separate passes (%s), %d frames" % (
-                r["kernel"], r.get("files", "profiles/"), r["frames"])
+            per = (r["fetch_kb"] * ff + r["write_kb"] * wf) * 1024.0 / r["frames"]
+            return per, "PMC FETCH_SIZE + WRITE_SIZE of %s, separate passes (%s), %d frames; %s" % (
+                r["kernel"], r.get("files", "profiles/"), r["frames"], cal)
     return None, "kernel sources changed since the PMC passes in profiles/pmc_traffic.json (now %s)" % sha
 
 
@@ -108,8 +137,10 @@ def parse():
     ap.add_argument("--fs", type=int, default=16000, choices=(16000, 48000),
                     help="analysis_synthesis only: 16000 is BASELINE.json's metric; 48000 (fft 2048, D4C fft 4096) is the "
                          "setting the reference's author committed (config.status: SAMPFREQ=48000)")
-    ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the step")
+    ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the timed step itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="analysis_synthesis at one GPU: skip the side_workloads (configs[2], [4], [3]) after the headline")
     ap.add_argument("--separate-calls", action="store_true",
                     help="WorldMi355Analyze then WorldMi355Synthesis instead of WorldMi355AnalyzeSynthesize")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -119,23 +150,28 @@ def parse():
     ap.add_argument("--workers", type=int, default=0, help="processes for synthetic data generation (0 = auto)")
     ap.add_argument("--workload", choices=["analysis_synthesis", "sweep", "harvest", "synthesis", "codec"],
                     default="analysis_synthesis",
-                    help="analysis_synthesis = configs[1] (the headline metric); sweep = configs[3]: a fixed corpus of ~1000 "
-                         "utterances sharded over the ranks (LPT), analysed, gathered to rank 0 as float32 and written to files "
-                         "by rank 0 (strong scaling); harvest = configs[2] (48 kHz, 1 ms, 64 utterances); synthesis = configs[4] "
-                         "(Synthesis only from precomputed features); codec = the recipe's coded lf0/mgc/bap from resident "
-                         "features plus the decoders (SURVEY.md 8(f))")
-    ap.add_argument("--coded", action="store_true", help="sweep: write the recipe's coded lf0/mgc/bap (50 + 25 dims) instead of raw f0/sp/ap")
+                    help="analysis_synthesis = configs[1] (the headline metric, followed at one GPU by the side workloads); "
+                         "sweep = configs[3]: a fixed corpus of ~1000 utterances sharded over the ranks (LPT), analysed, "
+                         "gathered to rank 0 as float32 and written to files by rank 0 (strong scaling); harvest = configs[2] "
+                         "(48 kHz, 1 ms, 64 utterances); synthesis = configs[4] (Synthesis only from precomputed features); "
+                         "codec = the recipe's coded lf0/mgc/bap from resident features plus the decoders (SURVEY.md 8(f))")
+    ap.add_argument("--raw", action="store_true",
+                    help="sweep: write raw float32 f0/sp/ap (4.1 KB per frame) instead of what the recipe's own call writes "
+                         "(data/Makefile.in:214: coded lf0 / mgc[50] / bap[25], 304 B per frame)")
+    ap.add_argument("--coded", action="store_true", help="sweep: the default since round 3 (kept for older command lines)")
     ap.add_argument("--rounds", type=int, default=4,
-                    help="sweep: batches per rank; rank 0 copies and writes one round while the next is analysed")
+                    help="sweep: batches per rank; one round is gathered, copied and written while the next is analysed")
     ap.add_argument("--writers", choices=("rank0", "all"), default="rank0",
                     help="sweep: rank0 = configs[3] as stated (gather-v, rank 0 writes everything); all = no gather, every "
                          "rank writes its own shard's files (shows what the rank-0 funnel costs)")
+    ap.add_argument("--io-threads", type=int, default=0, help="sweep: file-writing threads (0 = one per host core, 4..32)")
     ap.add_argument("--plan-only", action="store_true",
                     help="print this rank's share of the workload as JSON and exit without touching the GPU")
     ap.add_argument("--out-dir", default=None, help="sweep: where rank 0 writes the feature files (default: a fresh temp dir, removed afterwards)")
     args = ap.parse_args()
     if args.utts <= 0:
         args.utts = {"sweep": 1000, "harvest": 64, "synthesis": 1024}.get(args.workload, 256)
+    args.coded = not args.raw
     return args
 
 
@@ -166,6 +202,51 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
+class Env:
+    """What every workload needs: torch, the package, rank layout, barrier and reductions over ranks."""
+
+    def __init__(self, args, torch, dist, pkg, rank, world, shared_gpu):
+        self.args, self.torch, self.dist, self.pkg = args, torch, dist, pkg
+        self.W, self.sd, self.sh = pkg.world, pkg.synth_data, pkg.sharding
+        self.rank, self.world, self.shared_gpu = rank, world, shared_gpu
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, elapsed, frames):
+        """(max elapsed over ranks, total frames over ranks)."""
+        if self.world == 1:
+            return elapsed, float(frames)
+        torch, dist = self.torch, self.dist
+        tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64,
+                          device="cuda" if self.args.backend == "nccl" else "cpu")
+        tmax, tsum = tt.clone(), tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+
+    def rehearsal_note(self):
+        if self.shared_gpu or (self.world > 1 and self.args.backend == "gloo"):
+            return "rehearsal: %d ranks over gloo on %d GPU(s)" % (self.world, self.torch.cuda.device_count())
+        return None
+
+
+def timed_steps(env, step, steps, warmup, prewarm, ramp_step=None):
+    """The contract's timing: untimed warm-up, then exactly `steps` steps between barrier + synchronize on both sides.
+    Returns (elapsed seconds on this rank, clock_ramp object or None)."""
+    ramp = clock_ramp(ramp_step or step, env.barrier, prewarm, steps) if prewarm > 0 else None
+    for _ in range(warmup):
+        step()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    env.barrier()
+    return time.perf_counter() - t0, ramp
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -177,7 +258,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     pkg = importlib.import_module("hts-train-world_amd")
-    W, sd, sh = pkg.world, pkg.synth_data, pkg.sharding
+    sd, sh = pkg.synth_data, pkg.sharding
 
     # ---- synthetic workload (not timed).  Generated BEFORE the GPU is touched: the generator forks a
     # worker pool, and a process that has initialised HIP / RCCL should not be forked ----
@@ -186,7 +267,10 @@ def main():
     workers = args.workers if args.workers > 0 else max(1, min(16, ncpu // max(1, world)))
     if args.workers <= 0 and any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")):
         workers = 1      # under rocprofv3 the preloaded tool has already initialised the GPU: do not fork
+    side = (args.workload == "analysis_synthesis" and world == 1 and not args.no_side and args.fs == 16000
+            and workers > 1)
     plan = None
+    side_data = {}
     if args.workload == "sweep":
         # a FIXED corpus whatever the number of ranks (strong scaling): every rank derives the same partition from
         # the lengths alone and generates only its own utterances
@@ -205,6 +289,11 @@ def main():
                               "utterances": list(range(rank * utts, (rank + 1) * utts))}), flush=True)
             return
         xs = sd.make_batch(utts, fs, tuple(args.dur), first=rank * utts, workers=workers)
+        if side:
+            # configs[2]: 64 utterances at 48 kHz; configs[3]: the corpus of 1000 (its first `utts` are the headline's)
+            side_data["harvest"] = sd.make_batch(64, 48000, (2.0, 8.0), workers=workers)
+            side_data["corpus"] = xs + sd.make_batch(1000 - utts, fs, (2.0, 8.0), first=utts, workers=workers) \
+                if utts < 1000 else xs[:1000]
     # the CPU path on all host cores of this process' share, also before the GPU is touched
     cpu_all = None
     if (world == 1 and workers > 1 and not args.no_cpu_baseline and args.workload == "analysis_synthesis"):
@@ -221,15 +310,36 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+    env = Env(args, torch, dist, pkg, rank, world, shared_gpu)
+    ctx = pkg.world.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
 
     if args.workload == "sweep":
-        return sweep_workload(args, torch, dist, pkg, rank, world, xs, plan, fs, fp, shared_gpu)
-    if args.workload != "analysis_synthesis":
-        return side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts)
+        by_id = dict(zip(plan[1], xs))
+        line = sweep_bench(env, ctx, plan[0], by_id, fs, fp, args.steps, args.warmup, cpu=not args.no_cpu_baseline)
+    elif args.workload == "harvest":
+        line = harvest_bench(env, ctx, xs, fs, fp, args.steps, args.warmup, args.prewarm, cpu=not args.no_cpu_baseline)
+    elif args.workload == "synthesis":
+        line = synthesis_bench(env, ctx, xs, None, fs, fp, args.steps, args.warmup, args.prewarm,
+                               cpu=not args.no_cpu_baseline)
+    elif args.workload == "codec":
+        line = codec_bench(env, ctx, xs, fs, fp, args.steps, args.warmup, args.prewarm, cpu=not args.no_cpu_baseline)
+    else:
+        line = headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data if side else None)
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[1]: the headline
+# ------------------------------------------------------------------------------------------------------------------
+def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
+    args, torch, W, sh = env.args, env.torch, env.W, env.sh
+    rank, world = env.rank, env.world
     lens = [len(x) for x in xs]
     x = torch.from_numpy(np.concatenate(xs)).cuda()
-    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
     batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=lens)
     frames = int(batch.total_frames)
     outs = (torch.empty(frames, dtype=torch.float64, device="cuda"), torch.empty(frames, dtype=torch.float64, device="cuda"),
@@ -237,6 +347,10 @@ def main():
             torch.empty(frames, batch.bins, dtype=torch.float64, device="cuda"))
     y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
     frame_counts = np.diff(batch.frame_offsets).tolist()
+    all_counts = None
+    if world > 1:                                   # every rank's frame counts, once: the gather's layout
+        all_counts = [None] * world
+        env.dist.all_gather_object(all_counts, [int(c) for c in frame_counts])
     bm = byte_model(fs, fp, batch.fft_size)
 
     def compute():
@@ -248,37 +362,56 @@ def main():
             t, f0, sp, ap, _ = batch.analyze_synthesize(x, out=outs, y=y)
         return f0, sp, ap
 
+    def gather(f0, sp, ap):
+        # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
+        feats = [f0.float(), sp.float(), ap.float()]
+        if args.backend == "gloo":
+            feats = [v.cpu() for v in feats]
+        sh.gather_features(feats, frame_counts, dst=0, all_counts=all_counts)
+
     def step():
         f0, sp, ap = compute()
         if args.gather and world > 1:
-            # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
-            feats = [f0.float(), sp.float(), ap.float()]
-            if args.backend == "gloo":
-                feats = [v.cpu() for v in feats]
-            sh.gather_features(feats, frame_counts, dst=0)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            gather(f0, sp, ap)
 
     # the ramp runs the rank-local part only: its length is set by each rank's clock, so it must not hold a collective
-    ramp = clock_ramp(compute, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
+    ctx.timing_enable(False)
+    ramp = clock_ramp(compute, env.barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
     for _ in range(args.warmup):
         step()
-    barrier()
+    env.barrier()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: ctx.timing_query(k) for k in ANALYSIS_KERNELS + SYNTHESIS_KERNELS}
     ctx.timing_enable(False)
-    elapsed_max, total_frames = reduce_over_ranks(torch, dist, world, args.backend, elapsed, frames)
-    hi = host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world)
-    hic = host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=(50, 25))
+    elapsed_max, total_frames = env.reduce(elapsed, frames)
+    with_gather = None
+    if world > 1 and not args.gather:
+        # the same step followed by the one exchange the path has: the gather-v of the float32 feature slabs to
+        # rank 0 (RCCL grouped send/recv over xGMI), under the same timing contract
+        def step_g():
+            gather(*compute())
+        step_g()
+        env.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_g()
+        env.barrier()
+        eg, _ = env.reduce(time.perf_counter() - t0, frames)
+        per_rank = 4 * frames * (1 + 2 * batch.bins)
+        with_gather = {"value": round(total_frames * args.steps / eg, 1), "unit": "frames/s",
+                       "ms_per_step": round(eg / args.steps * 1e3, 3),
+                       "gathered_bytes_per_step": per_rank * (world - 1),
+                       "note": "analysis + synthesis, then float32 f0/sp/ap of every rank gathered to rank 0 (%s)"
+                               % ("RCCL send/recv" if args.backend == "nccl" else "gloo rehearsal")}
+    hi = host_inclusive(env, ctx, xs, fs, fp)
+    hic = host_inclusive(env, ctx, xs, fs, fp, coded=(50, 25))
 
+    line = None
     if rank == 0:
         value = total_frames * args.steps / elapsed_max
         voiced = int((outs[1] > 0).sum().item())
@@ -309,25 +442,63 @@ def main():
         }
         if ramp:
             line["clock_ramp"] = ramp
-        if shared_gpu or (world > 1 and args.backend == "gloo"):
-            line["config"]["note"] = "rehearsal: %d ranks over gloo on %d GPU(s)" % (world, torch.cuda.device_count())
+        if env.rehearsal_note():
+            line["config"]["note"] = env.rehearsal_note()
+        if with_gather:
+            line["with_gather"] = with_gather
         line["host_inclusive"] = hi
         line["host_inclusive_coded"] = hic
         if cpu_all:
             line["cpu_baseline_all_cores"] = cpu_all
         if parity:
             line["parity"] = parity
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # ---- the other BASELINE.json configurations, compact, in the same run (one GPU) ----
+    if side_data is not None and rank == 0:
+        feats = (outs[1].clone(), outs[2].clone(), outs[3].clone(), np.diff(batch.frame_offsets).tolist(),
+                 np.diff(batch.out_offsets).tolist())
+        del outs, y, x
+        batch.close()
+        torch.cuda.empty_cache()
+        cpu = not args.no_cpu_baseline
+        sides = {}
+        sides["harvest"] = compact(harvest_bench(env, ctx, side_data["harvest"], 48000, 1.0, 5, 2, 2.0, cpu=cpu))
+        sides["synthesis"] = compact(synthesis_bench(env, ctx, xs, feats, fs, fp, 5, 2, 2.0, cpu=cpu))
+        del feats
+        torch.cuda.empty_cache()
+        corpus = side_data["corpus"]
+        counts = [len(v) for v in corpus]
+        sides["sweep"] = compact(sweep_bench(env, ctx, counts, dict(enumerate(corpus)), fs, fp, 3, 1, cpu=cpu))
+        line["side_workloads"] = sides
+    else:
+        batch.close()
+    return line
 
 
-def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=None):
+def compact(line):
+    """A side workload's line reduced to what the headline line carries of it."""
+    if line is None:
+        return None
+    roof = line.get("roofline") or {}
+    keep_roof = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_note",
+                                          "launch_ms", "units_per_launch", "bytes_per_unit", "fp64", "kernel_ms_per_step")
+                 if k in roof}
+    out = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+           "steps": line["steps"], "scaling": line["scaling"], "dtype": line["dtype"],
+           "config": {"workload": line["config"]["workload"], "frames": line["config"].get("frames_per_gpu",
+                                                                                           line["config"].get("frames"))},
+           "roofline": keep_roof, "cpu_baseline": line.get("cpu_baseline"), "parity": line.get("parity")}
+    for k in ("phases_ms_per_step", "predicted", "value_compute_only"):
+        if k in line:
+            out[k] = line[k]
+    return out
+
+
+def host_inclusive(env, ctx, xs, fs, fp, coded=None):
     """The same step fed from and drained to pinned HOST memory in the on-disk types (int16 samples up; float32
     f0 / sp / ap and int16 resynthesised samples down), double-buffered on copy streams beside the kernels
     (hts-train-world_amd/pipeline.py).  Reported beside `value`, never as it (the metric
     "including H2D of waveforms and D2H of features")."""
+    args, torch, pkg = env.args, env.torch, env.pkg
     pl = pkg.pipeline
     pipe = pl.HostPipeline(ctx, pkg.world.default_params(fs, fp), [len(x) for x in xs], synthesis=True, coded=coded)
     x16 = pl.to_int16(np.concatenate(xs))
@@ -336,9 +507,7 @@ def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=None):
     steps = max(2, args.steps)
     for _ in range(2):
         pipe.result(pipe.submit())
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    env.barrier()
     t0 = time.perf_counter()
     prev = None
     pipe.feed()
@@ -355,7 +524,7 @@ def host_inclusive(args, torch, dist, pkg, ctx, xs, fs, fp, world, coded=None):
     frames = int(pipe.batch.total_frames)
     up, down = pipe.bytes_per_step()
     pipe.close()
-    dt_max, total = reduce_over_ranks(torch, dist, world, args.backend, dt, frames)
+    dt_max, total = env.reduce(dt, frames)
     return {"value": round(total * steps / dt_max, 1), "unit": "frames/s", "ms_per_step": round(dt_max / steps * 1e3, 3),
             "overlapped": True, "steps": steps,
             "layout": "pinned host int16 waveforms up (%d B/frame), float32 %s + int16 resynthesis down (%d B/frame); "
@@ -392,63 +561,62 @@ ANALYSIS_KERNELS = ("dio_lowcut_kernel", "dio_band_kernel", "dio_candidate_kerne
                     "cheaptrick_kernel", "d4c_lovetrain_kernel", "d4c_kernel")
 SYNTHESIS_KERNELS = ("synth_inc_kernel", "synth_timebase_kernel", "synth_search_kernel", "synth_pulse_kernel",
                      "synth_ola_kernel")
+HARVEST_KERNELS = ("hv_decimate", "hv_band_kernel", "hv_band_fft_kernel", "hv_raw_kernel", "hv_detect_kernel",
+                   "hv_refine_kernel", "hv_remove_kernel", "hv_contour_kernel")
 
 
-def reduce_over_ranks(torch, dist, world, backend, elapsed, frames):
-    """(max elapsed over ranks, total frames over ranks)."""
-    if world == 1:
-        return elapsed, float(frames)
-    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    tmax, tsum = tt.clone(), tt.clone()
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    return float(tmax[0]), float(tsum[1])
-
-
-def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps):
-    """The `roofline` object for the dominant kernel (d4c_kernel): algorithmic bytes per launch over the HIP-event
-    duration of its launches on the launch stream, against the HBM peak; FP64 figures (what binds it) beside it."""
-    d4c_ms, d4c_n = kernel_ms["d4c_kernel"]
-    d4c_avg_s = d4c_ms / max(1, d4c_n) * 1e-3
-    # a step may launch the kernel several times (the sweep analyses its shard in batches): per-launch units
-    per_step = max(1, round(d4c_n / max(1, steps)))
-    frames = frames / per_step
-    voiced = voiced / per_step
-    per_frame, note = measured_traffic(fs)
-    flops = d4c_flops_per_voiced_frame(fs)
-    ok = d4c_avg_s > 0
-    fd = 2 ** (1 + int(math.log2(4.0 * fs / 47.0 + 1.0)))          # fft_size_d4c (d4c.cpp:341-343)
-    name = "d4c_kernel" if fd <= 2048 else "d4c_kernel scope = d4cb_centroid + d4cb_spectrum + d4cb_band + d4cb_output (fft %d)" % fd
-    return {
-        "bound": "hbm", "kernel": name,
-        "achieved": round(frames * bm["d4c"] / d4c_avg_s / 1e9, 3) if ok else None,
+def kernel_roofline(workload, kernel, note, kernel_ms, steps, units, bytes_per_unit, fs, flops_per_launch=None):
+    """The `roofline` object of a workload's dominant kernel: algorithmic bytes per launch over the HIP-event duration
+    of its launches (recorded on the launch stream), against the HBM peak; FP64 figures beside it."""
+    ms, n = kernel_ms[kernel]
+    avg_s = ms / max(1, n) * 1e-3
+    per_step = max(1, round(n / max(1, steps)))        # a step may launch the kernel several times (batches)
+    units = units / per_step
+    per_unit, tnote = measured_traffic(fs, workload)
+    ok = avg_s > 0
+    roof = {
+        "bound": "hbm", "kernel": kernel,
+        "achieved": round(units * bytes_per_unit / avg_s / 1e9, 3) if ok else None,
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(frames * bm["d4c"] / d4c_avg_s / 1e9 / HBM_PEAK_GBS, 6) if ok else None,
-        "traffic": round(frames * per_frame) if per_frame is not None else None,
-        "launches_per_step": per_step,
-        "traffic_note": note,
-        "launch_ms": round(d4c_avg_s * 1e3, 4), "units_per_launch": round(frames),
-        "bytes_per_unit": bm["d4c"],
-        "note": "FP64-FFT/LDS bound, not HBM bound (SURVEY.md 8d); fp64 figures beside it",
-        "fp64": {"achieved_tflops": round(voiced * flops / d4c_avg_s / 1e12, 3) if ok else None,
-                 "peak_tflops": FP64_PEAK_TFLOPS,
-                 "frac": round(voiced * flops / d4c_avg_s / 1e12 / FP64_PEAK_TFLOPS, 5) if ok else None},
+        "frac": round(units * bytes_per_unit / avg_s / 1e9 / HBM_PEAK_GBS, 6) if ok else None,
+        "traffic": round(units * per_unit) if per_unit is not None else None,
+        "launches_per_step": per_step, "traffic_note": tnote,
+        "launch_ms": round(avg_s * 1e3, 4), "units_per_launch": round(units), "bytes_per_unit": bytes_per_unit,
+        "note": note,
         "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in kernel_ms.items()},
     }
+    if flops_per_launch is not None:
+        fl = flops_per_launch / per_step
+        roof["fp64"] = {"achieved_tflops": round(fl / avg_s / 1e12, 3) if ok else None, "peak_tflops": FP64_PEAK_TFLOPS,
+                        "frac": round(fl / avg_s / 1e12 / FP64_PEAK_TFLOPS, 5) if ok else None}
+    return roof
 
 
-def sweep_workload(args, torch, dist, pkg, rank, world, xs, plan, fs, fp, shared_gpu):
+def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps, workload="analysis_synthesis"):
+    fd = 2 ** (1 + int(math.log2(4.0 * fs / 47.0 + 1.0)))          # fft_size_d4c (d4c.cpp:341-343)
+    name = "d4c_kernel" if fd <= 2048 else "d4c_kernel scope = d4cb_centroid + d4cb_spectrum + d4cb_band + d4cb_output (fft %d)" % fd
+    roof = kernel_roofline(workload, "d4c_kernel", "FP64-FFT/LDS bound, not HBM bound (SURVEY.md 8d); fp64 figures beside it",
+                           kernel_ms, steps, frames, bm["d4c"], fs, flops_per_launch=voiced * d4c_flops_per_voiced_frame(fs))
+    roof["kernel"] = name
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configs[3]: the corpus sweep
+# ------------------------------------------------------------------------------------------------------------------
+def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     """configs[3]: the data/ feature-extraction sweep over a fixed corpus (data/Makefile.in:125-242), sharded over the
     ranks; one step = every rank analyses its shard, the float32 feature slabs are gathered to rank 0, rank 0 writes
-    every utterance's files.  Waveforms are resident in HBM when the timed region starts."""
+    every utterance's files (what the recipe's call writes: coded lf0 / mgc / bap; --raw for f0 / sp / ap).  Waveforms
+    are resident in HBM when the timed region starts.  by_id: this rank's utterances by corpus index."""
     import shutil
     import tempfile
+    args, torch, dist, pkg = env.args, env.torch, env.dist, env.pkg
+    rank, world = env.rank, env.world
     W, sweep = pkg.world, pkg.sweep
-    counts, mine = plan
-    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
     sw = sweep.ShardedSweep(ctx, fs, fp, counts, rank, world, spec_dim=50 if args.coded else 0, ap_dim=25,
                             backend=args.backend, rounds=args.rounds, writers=args.writers)
-    by_id = dict(zip(mine, xs))
+    mine = sw.shards[rank]
     sw.load(lambda i: by_id[i])
     out_dir = None
     sink = None
@@ -461,80 +629,91 @@ def sweep_workload(args, torch, dist, pkg, rank, world, xs, plan, fs, fp, shared
     if out_dir:
         names = ("lf0", "mgc", "bap") if args.coded else ("f0", "sp", "ap")
         sink = sweep.dir_sink(out_dir, names)
+    io_threads = args.io_threads or None
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        sw.run(sink)
-    barrier()
+    for _ in range(warmup):
+        sw.run(sink, io_threads)
+    env.barrier()
     ctx.timing_enable(True)
-    phases = {"compute": 0.0, "gather": 0.0, "to_host": 0.0, "write": 0.0}
+    phases = {"compute": 0.0, "gather": 0.0, "to_host": 0.0, "write": 0.0, "wall": 0.0}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ph = sw.run(sink)
+    for _ in range(steps):
+        ph = sw.run(sink, io_threads)
         for k in phases:
-            phases[k] += ph[k]
-    barrier()
+            phases[k] += ph.get(k, 0.0)
+    env.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = {k: ctx.timing_query(k) for k in ANALYSIS_KERNELS}
     ctx.timing_enable(False)
-    elapsed_max, _ = reduce_over_ranks(torch, dist, world, args.backend, elapsed, sw.my_frames)
+    elapsed_max, _ = env.reduce(elapsed, sw.my_frames)
     # slowest rank's compute, the busiest rank's share of frames (LPT balance)
-    comp_max, _ = reduce_over_ranks(torch, dist, world, args.backend, phases["compute"], 0)
-    most, _ = reduce_over_ranks(torch, dist, world, args.backend, float(sw.my_frames), 0)
+    comp_max, _ = env.reduce(phases["compute"], 0)
+    most, _ = env.reduce(float(sw.my_frames), 0)
+    line = None
     if rank == 0:
         total = sw.total_frames
-        value = total * args.steps / elapsed_max
+        value = total * steps / elapsed_max
         F = pkg.capi.cheaptrick_fft_size(fs)
         bm = byte_model(fs, fp, F)
         frames0 = sum(int(b.total_frames) for b, _ in sw.loaded)
         voiced = 0
         for b, xx in sw.loaded:
             voiced += int((b.analyze(xx)[1] > 0).sum().item())
-        roof = d4c_roofline(kernel_ms, frames0, voiced, fs, bm, args.steps) if frames0 else None
+        roof = d4c_roofline(kernel_ms, frames0, voiced, fs, bm, steps, workload="sweep") if frames0 else None
         per_frame_out = 4 * ((1 + 50 + 25) if args.coded else (1 + 2 * (F // 2 + 1)))
-        k = float(args.steps)
+        k = float(steps)
+        ms = lambda v: round(v / k * 1e3, 3)
+        # What eight ranks would take, from this run's phases: compute divides by the ranks; the gather, the copy to the
+        # host and the file writes stay with rank 0 (its xGMI links carry 7/8 of the bytes the copy engine then moves
+        # down).  A pass is a pipeline over the rounds: the longest stage bounds it, one round of the others is exposed.
+        R = max(1, sw.rounds)
+        c8 = comp_max / k / 8.0
+        host_side = (phases["to_host"] + phases["gather"]) / k
+        wr = phases["write"] / k
+        pred8 = max(c8, host_side, wr) + (c8 + host_side + wr - max(c8, host_side, wr)) / R
         line = {
             "metric": "WORLD analysis sweep frames/sec @16kHz, 5ms hop (corpus -> float32 feature files on rank 0)",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[3]: fixed corpus of %d synthetic 16 kHz utterances (%g-%g s, %d frames), LPT-sharded "
                                    "over %d rank(s); Dio+StoneMask+CheapTrick+D4C in fp64, %s float32 gathered to rank 0 "
-                                   "(grouped send/recv), written by rank 0 as one file per utterance and feature"
+                                   "(grouped send/recv), written by rank 0 as one file per utterance and feature; rounds "
+                                   "pipelined: analysis | gather + copy to host | file writes"
                                    % (len(counts), args.dur[0], args.dur[1], total, world,
-                                      "coded lf0/mgc(50)/bap(25)" if args.coded else "raw f0/sp/ap"),
+                                      "coded lf0/mgc(50)/bap(25) (the recipe's call, data/Makefile.in:214)" if args.coded
+                                      else "raw f0/sp/ap"),
                        "fs": fs, "frame_period_ms": fp, "utterances": len(counts), "frames": total,
                        "frames_on_busiest_rank": int(most), "output_bytes_per_frame": per_frame_out,
                        "rounds": sw.rounds, "writers": args.writers,
                        "parallelism": "utterance-sharded x%d, %s" % (world, "gather-v to rank 0 over " + args.backend
                                                                       if args.writers == "rank0" else "every rank writes its shard")},
-            "phases_ms_per_step": {"compute_slowest_rank": round(comp_max / k * 1e3, 3),
-                                   "gather_rank0": round(phases["gather"] / k * 1e3, 3),
-                                   "to_host_rank0": round(phases["to_host"] / k * 1e3, 3),
-                                   "file_write_rank0": round(phases["write"] / k * 1e3, 3)},
+            "phases_ms_per_step": {"compute_slowest_rank": ms(comp_max), "gather_rank0": ms(phases["gather"]),
+                                   "to_host_rank0": ms(phases["to_host"]), "file_write_rank0": ms(phases["write"]),
+                                   "pass_wall_rank0": ms(phases["wall"]),
+                                   "note": "busy times per stage (HIP events per stream; writes: first submit to last "
+                                           "completion); they overlap inside pass_wall"},
+            "predicted": {"ranks": 8, "ms_per_step": round(pred8 * 1e3, 3),
+                          "speedup_over_this_run": round(elapsed_max / steps / pred8, 2) if world == 1 and pred8 > 0 else None,
+                          "model": "max(compute/8, gather + to_host, write) + (the other two stages) / rounds, from "
+                                   "this run's phases; rank 0 keeps the host side"},
             "value_compute_only": round(total * k / comp_max, 1) if comp_max > 0 else None,
             "roofline": roof, "cpu_baseline": None,
         }
-        if shared_gpu or (world > 1 and args.backend == "gloo"):
-            line["config"]["note"] = "rehearsal: %d ranks over gloo on %d GPU(s)" % (world, torch.cuda.device_count())
-        if world == 1 and not args.no_cpu_baseline:
+        if env.rehearsal_note():
+            line["config"]["note"] = env.rehearsal_note()
+        if world == 1 and cpu:
             line["cpu_baseline"], line["parity"] = sweep_cpu_baseline(by_id, mine, fs, fp, out_dir, args)
-        print(json.dumps(line), flush=True)
         if not args.out_dir:
             shutil.rmtree(out_dir, ignore_errors=True)
     sw.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 def sweep_cpu_baseline(by_id, mine, fs, fp, out_dir, args):
-    """The reference's `analysis` arithmetic (Dio+StoneMask+CheapTrick+D4C, float32 outputs) single-threaded on a
-    bounded sample of the corpus, and the files rank 0 wrote for those utterances checked against it."""
+    """The reference's `analysis` arithmetic (Dio+StoneMask+CheapTrick+D4C, float32 outputs; with the coder when the
+    files are coded) single-threaded on a bounded sample of the corpus, and the files rank 0 wrote for those
+    utterances checked against it."""
     from oracle.bindings import Oracle, Reference
     lib = Reference() if Reference.available() else Oracle()
     F = lib.cheaptrick_fft_size(fs)
@@ -546,10 +725,29 @@ def sweep_cpu_baseline(by_id, mine, fs, fp, out_dir, args):
         f0 = lib.stonemask(x, fs, t, f0)
         sp = lib.cheaptrick(x, fs, t, f0, -0.15, F)
         ap = lib.d4c(x, fs, t, f0, F, 0.0)
+        if args.coded:                                             # analysis.cpp:292-366
+            sp4 = sp * 1e4
+            sp4[sp4 == 0.0] = 0.0001
+            mgc = lib.code_spectral_envelope(sp4, fs, F, 50)
+            mgc[:, 0] += 12.0
+            bap = lib.code_spectral_envelope(ap * 1e4, fs, F, 25)
+            bap[:, 0] -= 9.210340
+            bap[(bap[:, 0] > 0) & (bap[:, 0] < 1e-4), 0] = 0.0
         tcpu += time.perf_counter() - a
         frames += len(f0)
         n += 1
-        if not args.coded:
+        if args.coded:
+            g_lf0 = np.fromfile(os.path.join(out_dir, "utt%05d.lf0" % i), dtype=np.float32)
+            g_mgc = np.fromfile(os.path.join(out_dir, "utt%05d.mgc" % i), dtype=np.float32).reshape(-1, 50)
+            g_bap = np.fromfile(os.path.join(out_dir, "utt%05d.bap" % i), dtype=np.float32).reshape(-1, 25)
+            v = f0 > 0                                               # lf0 = 0 where unvoiced (analysis.cpp:216-224)
+            assert np.array_equal(v, g_lf0 != 0), "voiced / unvoiced frames of utterance %d differ" % i
+            if v.any():
+                df0 = max(df0, float(np.abs(np.exp(g_lf0[v].astype(np.float64)) - f0[v]).max()))
+            se_sp += float(((g_mgc.astype(np.float64) - mgc.astype(np.float32)) ** 2).sum())
+            se_ap += float(((g_bap.astype(np.float64) - bap.astype(np.float32)) ** 2).sum())
+            cnt += mgc.size
+        else:
             g_f0 = np.fromfile(os.path.join(out_dir, "utt%05d.f0" % i), dtype=np.float32)
             g_sp = np.fromfile(os.path.join(out_dir, "utt%05d.sp" % i), dtype=np.float32).reshape(-1, F // 2 + 1)
             g_ap = np.fromfile(os.path.join(out_dir, "utt%05d.ap" % i), dtype=np.float32).reshape(-1, F // 2 + 1)
@@ -557,15 +755,15 @@ def sweep_cpu_baseline(by_id, mine, fs, fp, out_dir, args):
             se_sp += float(((g_sp.astype(np.float64) - sp.astype(np.float32)) ** 2).sum())
             se_ap += float(((g_ap.astype(np.float64) - ap.astype(np.float32)) ** 2).sum())
             cnt += sp.size
-        if tcpu > 25.0:
+        if tcpu > 12.0:
             break
     cpu = {"value": round(frames / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
-           "sample": "%d utterances of the corpus (%d frames), Dio+StoneMask+CheapTrick+D4C, single thread, %.1f s "
-                     "(file writing not included)" % (n, frames, tcpu)}
-    parity = None
-    if cnt:
-        parity = {"vs": lib.kind, "utterances": n, "files": "float32 as written by rank 0",
-                  "max_abs_dF0_hz": df0, "sp_rmse": (se_sp / cnt) ** 0.5, "ap_rmse": (se_ap / cnt) ** 0.5}
+           "sample": "%d utterances of the corpus (%d frames), Dio+StoneMask+CheapTrick+D4C%s, single thread, %.1f s "
+                     "(file writing not included)" % (n, frames, " + the CLI's coding" if args.coded else "", tcpu)}
+    parity = {"vs": lib.kind, "utterances": n,
+              "files": "float32 %s as written by rank 0" % ("lf0/mgc/bap" if args.coded else "f0/sp/ap"),
+              "max_abs_dF0_hz": df0, ("mgc_rmse" if args.coded else "sp_rmse"): (se_sp / max(1, cnt)) ** 0.5,
+              ("bap_rmse" if args.coded else "ap_rmse"): (se_ap / max(1, cnt)) ** 0.5}
     return cpu, parity
 
 
@@ -578,104 +776,221 @@ def workload_spec(args):
     return 16000, 5.0, args.utts
 
 
-def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
-    """configs[2] (Harvest), configs[4] (Synthesis only) and the feature codec: same contract, separate metric names."""
+# ------------------------------------------------------------------------------------------------------------------
+# configs[2] (Harvest), configs[4] (Synthesis only), the feature codec
+# ------------------------------------------------------------------------------------------------------------------
+def side_line(env, metric, cfg, value, steps, warmup, elapsed, frames, roof, ramp):
+    line = {"metric": "WORLD %s frames/sec" % metric, "value": round(value, 1), "unit": "frames/s", "n_gpus": env.world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": dict(cfg, frames_per_gpu=frames), "roofline": roof, "cpu_baseline": None}
+    if ramp:
+        line["clock_ramp"] = ramp
+    if env.rehearsal_note():
+        line["config"]["note"] = env.rehearsal_note()
+    return line
+
+
+def harvest_bench(env, ctx, xs, fs, fp, steps, warmup, prewarm, cpu=True):
+    """configs[2]: Harvest at 48 kHz with a 1 ms hop over 64 utterances of 2-8 s."""
+    torch, W = env.torch, env.W
     x = torch.from_numpy(np.concatenate(xs)).cuda()
-    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
     batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(v) for v in xs])
     frames = int(batch.total_frames)
-    if args.workload == "harvest":
-        names = ("hv_decimate", "hv_band_kernel", "hv_raw_kernel", "hv_refine_kernel", "hv_contour_kernel")
-        step = lambda: batch.harvest(x)
-    elif args.workload == "codec":
-        # SURVEY.md 8(f) ranks 1-2: the recipe's coded features from resident sp/ap, and the decoders back
-        t, f0, sp, ap = batch.analyze(x)
-        names = ("codec_code_sp_kernel", "codec_decode_sp_kernel", "codec_code_ap_kernel", "codec_decode_ap_kernel")
-
-        def step():
-            lf0, mgc, bap = batch.recipe_features(f0, sp, ap, 50, 25)
-            csp = batch.code_spectral_envelope(sp, 50)
-            cap = batch.code_aperiodicity(ap)
-            batch.decode_spectral_envelope(csp)
-            batch.decode_aperiodicity(cap)
-    else:
-        t, f0, sp, ap = batch.analyze(x)
-        y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
-        names = ("synth_inc_kernel", "synth_timebase_kernel", "synth_search_kernel", "synth_pulse_kernel", "synth_ola_kernel")
-        step = lambda: batch.synthesize(f0, sp, ap, out=y)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ramp = clock_ramp(step, barrier, args.prewarm, args.steps) if args.prewarm > 0 else None
-    for _ in range(args.warmup):
+    step = lambda: batch.harvest(x)
+    ctx.timing_enable(False)
+    ramp = clock_ramp(step, env.barrier, prewarm, steps) if prewarm > 0 else None
+    for _ in range(warmup):
         step()
-    barrier()
+    env.barrier()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
-    kms = {k: ctx.timing_query(k)[0] / args.steps for k in names}
-    if args.workload == "codec":
-        # the synth CLI's way back (WorldMi355RecipeDecode), outside the timed step: reported beside it
-        lf0, mgc, bap = batch.recipe_features(f0, sp, ap, 50, 25)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            batch.recipe_decode(lf0, mgc, bap)
-        torch.cuda.synchronize()
-        kms["recipe_decode_call_ms (not in value)"] = (time.perf_counter() - t1) * 1e3 / args.steps
-        kms["codec_bap_decode_kernel (not in value)"] = ctx.timing_query("codec_bap_decode_kernel")[0] / args.steps
-    tt = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
-        tmax, tsum = tt.clone(), tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, total = float(tmax[0]), float(tsum[1])
-    else:
-        total = float(frames)
-    if rank == 0:
-        value = total * args.steps / elapsed
-        bpf = 400 if args.workload == "harvest" else 8856          # SURVEY.md section 8d
-        if args.workload == "codec":
-            # per frame: recipe packing reads sp+ap (2 x 4104 B), coders read them again, decoders write them
-            bpf = 4 * 4104 + 2 * 4104
-        mname = {"harvest": "Harvest @48kHz, 1ms hop", "codec": "feature codec (recipe packing + code + decode) @16kHz",
-                 "synthesis": "Synthesis-only @16kHz, 5ms hop"}[args.workload]
-        line = {"metric": "WORLD %s frames/sec" % mname,
-                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "configs[%d]: %d synthetic utterances (%g-%g s) per GPU, fs %d, hop %g ms"
-                                       % ({"harvest": 2, "codec": 1}.get(args.workload, 4), utts, args.dur[0], args.dur[1], fs, fp),
-                           "frames_per_gpu": frames},
-                "roofline": {"bound": "hbm", "achieved": round(value / world * bpf / 1e9, 3), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(value / world * bpf / 1e9 / HBM_PEAK_GBS, 7),
-                             "traffic": None, "bytes_per_unit": bpf, "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}},
-                "cpu_baseline": None}
-        if ramp:
-            line["clock_ramp"] = ramp
-        if world == 1 and not args.no_cpu_baseline and args.workload == "harvest":
+    kms = {k: ctx.timing_query(k) for k in HARVEST_KERNELS}
+    ctx.timing_enable(False)
+    elapsed, total = env.reduce(elapsed, frames)
+    line = None
+    if env.rank == 0:
+        value = total * steps / elapsed
+        # The dominant kernel is the filter bank (hv_band_fft_kernel): per basic frame (1 ms = 8 samples of the 8 kHz
+        # decimated signal) it must read those 8 samples (64 B; the event lists it writes are intermediates), and per
+        # block of `step` samples it runs one forward and one inverse real transform of 2048 points per channel.
+        r = max(1, min(12, int(fs / 8000.0 + 0.5)))
+        nch = 1 + int(math.log2(800.0 * 1.1 / (71.0 * 0.9)) * 40)                 # harvest.cpp:1151-1153
+        dec_per_frame = fs / r * fp / 1000.0
+        flops = frames * dec_per_frame / 1790.0 * (nch + 1) * 2.5 * 2048 * 11      # blocks x (channels + 1) real FFT-2048
+        roof = kernel_roofline("harvest", "hv_band_fft_kernel",
+                               "FP64-FFT bound: %d channels x one inverse real FFT-2048 per block; fp64 figures beside it; "
+                               "the whole path moves 400 B/frame (SURVEY.md 8d)" % nch,
+                               kms, steps, frames, dec_per_frame * 8, fs, flops_per_launch=flops)
+        roof["pipeline"] = {"bytes_per_frame": 400, "achieved_gbs": round(value / env.world * 400 / 1e9, 3),
+                            "frac_hbm": round(value / env.world * 400 / 1e9 / HBM_PEAK_GBS, 7),
+                            "achieved_fp64_tflops": round(value / env.world * 0.39e6 / 1e12, 3),
+                            "frac_fp64": round(value / env.world * 0.39e6 / 1e12 / FP64_PEAK_TFLOPS, 4),
+                            "note": "0.39 MFLOP/frame is the reference's FFT count (SURVEY.md 8d); the kernels here "
+                                    "execute fewer (block convolution, Goertzel sums at six bins)"}
+        line = side_line(env, "Harvest @48kHz, 1ms hop",
+                         {"workload": "configs[2]: %d synthetic utterances (%g-%g s) per GPU, fs %d, hop %g ms, Harvest "
+                                      "(71-800 Hz), f0 resident in HBM" % (len(xs), env.args.dur[0], env.args.dur[1], fs, fp)},
+                         value, steps, warmup, elapsed, frames, roof, ramp)
+        if env.world == 1 and cpu:
             from oracle.bindings import Oracle, Reference
             lib = Reference() if Reference.available() else Oracle()
             got = batch.harvest(x)[1].cpu().numpy()
-            nfr, tcpu, df0 = 0, 0.0, 0.0
+            nfr, tcpu, df0, n = 0, 0.0, 0.0, 0
             for u in range(min(len(xs), 6)):
                 a = time.perf_counter()
                 tc, fc = lib.harvest(xs[u], fs, fp)
                 tcpu += time.perf_counter() - a
                 nfr += len(fc)
+                n += 1
                 df0 = max(df0, float(np.abs(got[batch.frame_offsets[u]:batch.frame_offsets[u + 1]] - fc).max()))
-                if tcpu > 30:
+                if tcpu > 10:
                     break
             line["cpu_baseline"] = {"value": round(nfr / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
-                                    "sample": "first utterances of the same batch (%d frames), %.1f s" % (nfr, tcpu)}
-            line["parity"] = {"vs": lib.kind, "max_abs_dF0_hz": df0}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "codec":
+                                    "sample": "first %d utterances of the same batch (%d frames), Harvest, single thread, "
+                                              "%.1f s" % (n, nfr, tcpu)}
+            line["parity"] = {"vs": lib.kind, "utterances": n, "max_abs_dF0_hz": df0}
+    batch.close()
+    return line
+
+
+def synthesis_bench(env, ctx, xs, feats, fs, fp, steps, warmup, prewarm, cpu=True):
+    """configs[4]: Synthesis only from precomputed f0 / sp / ap, 1024 feature sets per GPU.  `feats` (f0, sp, ap,
+    frame counts, output lengths of 256 analysed utterances) makes the 1024 sets from those 256 four times over (the
+    compact side run of the default invocation); without it the sets are the analyses of `xs`."""
+    torch, W = env.torch, env.W
+    if feats is None:
+        ba = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(v) for v in xs])
+        t, f0, sp, ap = ba.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
+        T, Y = np.diff(ba.frame_offsets).tolist(), np.diff(ba.out_offsets).tolist()
+        ba.close()
+        how = "%d synthetic utterances (%g-%g s) analysed beforehand" % (len(xs), env.args.dur[0], env.args.dur[1])
+        src = xs
+    else:
+        f0a, spa, apa, Ta, Ya = feats
+        rep = max(1, 1024 // len(Ta))
+        f0, sp, ap = f0a.repeat(rep), spa.repeat(rep, 1), apa.repeat(rep, 1)
+        T, Y = Ta * rep, Ya * rep
+        how = "%d feature sets = the headline's %d analysed utterances %d times over" % (len(T), len(Ta), rep)
+        src = xs
+    batch = W.WorldBatch(ctx, W.default_params(fs, fp), f0_lengths=T, y_lengths=Y)
+    frames = int(batch.total_frames)
+    y = torch.empty(int(batch.total_out), dtype=torch.float64, device="cuda")
+    step = lambda: batch.synthesize(f0, sp, ap, out=y)
+    ctx.timing_enable(False)
+    ramp = clock_ramp(step, env.barrier, prewarm, steps) if prewarm > 0 else None
+    for _ in range(warmup):
+        step()
+    env.barrier()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    kms = {k: ctx.timing_query(k) for k in SYNTHESIS_KERNELS}
+    ctx.timing_enable(False)
+    elapsed, total = env.reduce(elapsed, frames)
+    line = None
+    if env.rank == 0:
+        value = total * steps / elapsed
+        bm = byte_model(fs, fp, batch.fft_size)
+        F = batch.fft_size
+        # per pulse: minimum-phase response (3 real + 1 complex transform of F points on F/2-point engines) plus the
+        # aperiodic part; counted as 7 (voiced) / 4 (unvoiced) real FFTs of F points, about 5.8 per frame (SURVEY.md 8d)
+        flops = frames * 5.8 * 2.5 * F * math.log2(F)
+        roof = kernel_roofline("synthesis", "synth_pulse_kernel",
+                               "FP64-FFT bound (7 / 4 transforms per voiced / unvoiced pulse); the kernel must read f0 and one "
+                               "sp and ap row per frame, its per-pulse responses are intermediates",
+                               kms, steps, frames, bm["pulse"], fs, flops_per_launch=flops)
+        roof["pipeline"] = {"bytes_per_frame": bm["synthesis"],
+                            "achieved_gbs": round(value / env.world * bm["synthesis"] / 1e9, 3),
+                            "frac_hbm": round(value / env.world * bm["synthesis"] / 1e9 / HBM_PEAK_GBS, 6)}
+        line = side_line(env, "Synthesis-only @16kHz, 5ms hop",
+                         {"workload": "configs[4]: %s, Synthesis only (fft %d), fp64, y resident in HBM" % (how, F)},
+                         value, steps, warmup, elapsed, frames, roof, ramp)
+        if env.world == 1 and cpu:
+            from oracle.bindings import Oracle, Reference
+            lib = Reference() if Reference.available() else Oracle()
+            fo, yo = batch.frame_offsets, batch.out_offsets
+            yh = y.cpu().numpy()
+            nfr, tcpu, dy, n = 0, 0.0, 0.0, 0
+            for u in range(min(batch.n_utt, 24)):
+                g = slice(fo[u], fo[u + 1])
+                a_f0, a_sp, a_ap = f0[g].cpu().numpy(), sp[g].cpu().numpy(), ap[g].cpu().numpy()
+                a = time.perf_counter()
+                yy = lib.synthesis(a_f0, a_sp, a_ap, F, fp, fs, int(yo[u + 1] - yo[u]))
+                tcpu += time.perf_counter() - a
+                nfr += fo[u + 1] - fo[u]
+                n += 1
+                dy = max(dy, float(np.abs(yh[yo[u]:yo[u + 1]] - yy).max()))
+                if tcpu > 8:
+                    break
+            line["cpu_baseline"] = {"value": round(nfr / tcpu, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
+                                    "sample": "the first %d feature sets of the same batch (%d frames), Synthesis, single "
+                                              "thread, %.1f s" % (n, nfr, tcpu)}
+            line["parity"] = {"vs": lib.kind, "utterances": n, "max_abs_dy": dy}
+    batch.close()
+    return line
+
+
+def codec_bench(env, ctx, xs, fs, fp, steps, warmup, prewarm, cpu=True):
+    """the recipe's coded features from resident sp/ap, and the decoders back."""
+    torch, W = env.torch, env.W
+    x = torch.from_numpy(np.concatenate(xs)).cuda()
+    batch = W.WorldBatch(ctx, W.default_params(fs, fp), x_lengths=[len(v) for v in xs])
+    frames = int(batch.total_frames)
+    t, f0, sp, ap = batch.analyze(x)
+    names = ("codec_code_sp_kernel", "codec_decode_sp_kernel", "codec_code_ap_kernel", "codec_decode_ap_kernel")
+
+    def step():
+        batch.recipe_features(f0, sp, ap, 50, 25)
+        csp = batch.code_spectral_envelope(sp, 50)
+        cap = batch.code_aperiodicity(ap)
+        batch.decode_spectral_envelope(csp)
+        batch.decode_aperiodicity(cap)
+
+    ctx.timing_enable(False)
+    ramp = clock_ramp(step, env.barrier, prewarm, steps) if prewarm > 0 else None
+    for _ in range(warmup):
+        step()
+    env.barrier()
+    ctx.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    kms = {k: ctx.timing_query(k)[0] / steps for k in names}
+    # the synth CLI's way back (WorldMi355RecipeDecode), outside the timed step: reported beside it
+    lf0, mgc, bap = batch.recipe_features(f0, sp, ap, 50, 25)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        batch.recipe_decode(lf0, mgc, bap)
+    torch.cuda.synchronize()
+    kms["recipe_decode_call_ms (not in value)"] = (time.perf_counter() - t1) * 1e3 / steps
+    kms["codec_bap_decode_kernel (not in value)"] = ctx.timing_query("codec_bap_decode_kernel")[0] / steps
+    ctx.timing_enable(False)
+    elapsed, total = env.reduce(elapsed, frames)
+    line = None
+    if env.rank == 0:
+        value = total * steps / elapsed
+        # per frame: recipe packing reads sp+ap (2 x 4104 B), coders read them again, decoders write them
+        bpf = 4 * 4104 + 2 * 4104
+        roof = {"bound": "hbm", "achieved": round(value / env.world * bpf / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(value / env.world * bpf / 1e9 / HBM_PEAK_GBS, 7), "traffic": None, "bytes_per_unit": bpf,
+                "kernel_ms_per_step": {k: round(v, 4) for k, v in kms.items()}}
+        line = side_line(env, "feature codec (recipe packing + code + decode) @16kHz",
+                         {"workload": "configs[1] features: %d synthetic utterances (%g-%g s) per GPU, recipe packing + "
+                                      "CodeSpectralEnvelope + CodeAperiodicity + both decoders"
+                                      % (len(xs), env.args.dur[0], env.args.dur[1])},
+                         value, steps, warmup, elapsed, frames, roof, ramp)
+        if env.world == 1 and cpu:
             from oracle.bindings import Oracle, Reference
             lib = Reference() if Reference.available() else Oracle()
             F = batch.fft_size
@@ -697,10 +1012,8 @@ def side_workload(args, torch, dist, W, sd, rank, world, xs, fs, fp, utts):
                                     "sample": "the same step on the first %d utterances (%d frames), %.1f s"
                                               % (n_u, fo[n_u], tcpu)}
             line["parity"] = {"vs": lib.kind, "max_abs_d_coded_sp": float(np.abs(got - csp).max())}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    batch.close()
+    return line
 
 
 _CPU_XS = None
@@ -778,7 +1091,7 @@ def cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, n_cpu):
         se_ap += float(((t_ap[g] - ap) ** 2).sum())
         cnt += sp.size
         dy = max(dy, float(np.abs(t_y[yo[u]:yo[u + 1]] - yy).max()))
-        if time.perf_counter() - t0 > 40.0:
+        if time.perf_counter() - t0 > 25.0:
             n_cpu = u + 1
             break
     cpu = {"value": round(frames / cpu_time, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,

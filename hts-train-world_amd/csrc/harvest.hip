@@ -1372,6 +1372,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     if (m.conv) {
       allow_dynamic_lds(*b.ctx, hv_band_fft_kernel<2048>, (int)(ConvEvCfg<2048, kHvConvC>::kLdsBytes));
       const int groups = (m.nch + kHvChGroup - 1) / kHvChGroup;
+      TimedScope tf_(b.ctx, "hv_band_fft_kernel");
       hipLaunchKernelGGL(hv_band_fft_kernel<2048>, dim3(W.tiles_max, groups, n_utt), dim3(64),
                          (ConvEvCfg<2048, kHvConvC>::kLdsBytes), st, W.d_yoff, W.d_ylen, W.d_y, (const cpx*)W.d_H, m.nch, m.half0,
                          m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots);
@@ -1414,6 +1415,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                        (const cpx*)W.d_twid, W.d_rc, W.d_rs);
   }
   {
+    TimedScope ts_(b.ctx, "hv_remove_kernel");
     const int64_t items = W.tot_b * m.maxc;
     const size_t lds_rm = sizeof(double) * (size_t)((256 / m.maxc + 4) * m.maxc);
     hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), lds_rm, st, W.d_bframe_utt,

@@ -84,6 +84,7 @@ def load_library():
     L.WorldMi355RecipeFeatures.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.WorldMi355RecipeDecode.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.WorldMi355ComposeCmp.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.WorldMi355WriteFiles.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int]
     L.WorldMi355HtkHeader.restype = None
     L.WorldMi355HtkHeader.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.WorldMi355TimingEnable.argtypes = [vp, C.c_int]
@@ -354,6 +355,23 @@ class WorldBatch:
         if self.handle:
             load_library().WorldMi355DestroyBatch(self.handle)
             self.handle = None
+
+
+def write_files(items, threads=16):
+    """items: [(path, numpy array)] -- every array written raw to its path by native threads in ONE library call
+    (WorldMi355WriteFiles: the interpreter lock is released for its duration).  The arrays must be C-contiguous and
+    stay alive until the call returns (they do: it is synchronous).  Host only."""
+    n = len(items)
+    if n == 0:
+        return
+    paths = (C.c_char_p * n)(*[os.fsencode(str(p)) for p, _ in items])
+    ptrs = (C.c_void_p * n)()
+    sizes = (C.c_size_t * n)()
+    for k, (_, a) in enumerate(items):
+        assert a.flags["C_CONTIGUOUS"], "write_files: contiguous arrays only"
+        ptrs[k] = a.ctypes.data
+        sizes[k] = a.nbytes
+    _check(load_library().WorldMi355WriteFiles(n, paths, ptrs, sizes, int(threads)), "WriteFiles")
 
 
 def htk_header(n_frames, sampling_rate, frame_shift_samples, bytes_per_frame, htk_type=9):

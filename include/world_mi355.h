@@ -24,6 +24,7 @@
 #ifndef WORLD_MI355_H_
 #define WORLD_MI355_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -36,6 +37,7 @@ extern "C" {
 #define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048,4096}; D4C's own size outside {1024,2048,4096} */
 #define WM_ERR_NO_DEVICE 4        /* no HIP device: the product path never falls back to CPU */
 #define WM_ERR_UNSUPPORTED 5
+#define WM_ERR_IO 6                /* a file could not be written (WorldMi355WriteFiles); see WorldMi355LastError() */
 
 typedef struct WorldMi355Context WorldMi355Context;
 typedef struct WorldMi355Batch WorldMi355Batch;
@@ -158,6 +160,13 @@ int WorldMi355ComposeCmp(WorldMi355Batch* b, int n_streams, const float* const* 
 /* The 12-byte HTK header of addhtkheader.pl:60-75 (host only, native byte order). */
 void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_samples, int bytes_per_frame,
                          int htk_type, unsigned char out12[12]);
+
+/* The fwrite loops at the end of the reference's `analysis` CLI (test/analysis.cpp:360-390), for a whole batch at
+ * once: file i = paths[i] receives bytes[i] bytes from data[i] (HOST memory: the pinned slabs a sweep copies the
+ * float32 features into), created or truncated.  n_threads plain threads work the list off; returns when every
+ * file is written and closed.  Host only: no context, no HIP call.  WM_ERR_IO names the first file that failed. */
+int WorldMi355WriteFiles(int n_files, const char* const* paths, const void* const* data, const size_t* bytes,
+                         int n_threads);
 
 
 /* ---- Vibrato feature (data/scripts/Extract.py:115-227, invoked at data/Makefile.in:215), SURVEY.md 8(f) rank 4 ----

@@ -30,7 +30,7 @@ def test_headers_declare_the_world_api():
                  "GetFFTSizeForCheapTrick", "GetF0FloorForCheapTrick", "D4C", "InitializeD4COption", "Synthesis",
                  "GetNumberOfAperiodicities", "CodeAperiodicity", "DecodeAperiodicity", "CodeSpectralEnvelope",
                  "DecodeSpectralEnvelope", "WorldMi355CodeSpectralEnvelope", "WorldMi355RecipeFeatures", "WorldMi355RecipeDecode",
-                 "WorldMi355ComposeCmp", "WorldMi355HtkHeader",
+                 "WorldMi355ComposeCmp", "WorldMi355HtkHeader", "WorldMi355WriteFiles",
                  "WorldMi355Analyze", "WorldMi355AnalyzeSynthesize", "WorldMi355Synthesis", "WorldMi355CreateBatch"):
         assert want in names, want
 

@@ -37,3 +37,29 @@ def test_lpt_shards_balance_and_cover():
     loads = [sum(costs[i] for i in s) for s in shards]
     assert max(loads) - min(loads) <= max(costs)
     assert sh.lpt_shards([5, 3], 4) == [[0], [1], [], []]
+
+
+def test_native_file_writer(tmp_path):
+    """WorldMi355WriteFiles (host only): a list of arrays to a list of files with plain threads -- the fwrite loops at
+    the end of the reference's analysis CLI (test/analysis.cpp:360-390) for a whole batch; errors name the file."""
+    import pytest
+    W = importlib.import_module("hts-train-world_amd.world")
+    rng = np.random.default_rng(5)
+    slab = rng.standard_normal((500, 7)).astype(np.float32)
+    items, want = [], {}
+    off = 0
+    for k in range(40):                                    # row slices of one slab, ragged, one empty
+        n = 0 if k == 11 else int(rng.integers(1, 25))
+        a = slab[off:off + n]
+        off += n
+        p = tmp_path / ("u%03d.sp" % k)
+        items.append((p, a))
+        want[p] = a.tobytes()
+    (tmp_path / "u005.sp").write_bytes(b"x" * 10000)       # an older, longer file is truncated
+    W.write_files(items, threads=6)
+    for p, b in want.items():
+        assert p.read_bytes() == b
+    with pytest.raises(RuntimeError, match="no_such_dir"):
+        W.write_files([(tmp_path / "no_such_dir" / "a.f0", slab[:3])], threads=2)
+    with pytest.raises(AssertionError):
+        W.write_files([(tmp_path / "t.f0", slab[:, 0])])   # a column of a slab is not contiguous

@@ -109,7 +109,7 @@ def _worker(rank, world, port, counts, limit, q):
             assert f0.shape == (sw.frames[i],) and np.all(f0 == i)
             assert np.array_equal(sp[:, 0], np.arange(sw.frames[i])) and sp.shape[1] == 3
             assert np.all(ap == owner[i])
-        assert set(ph) == {"compute", "gather", "to_host", "write"}
+        assert set(ph) == {"compute", "gather", "to_host", "write", "wall"}
         q.put("ok")
     dist.destroy_process_group()
 
@@ -134,7 +134,7 @@ def test_two_rank_sweep_layout(limit):
 def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
     """The sharded sweep (2 ranks, LPT shards, gather-v to rank 0, rank 0 writes) against the single-rank sweep:
     every file of every utterance bit for bit.  Both ranks share the one GPU of the box, hence gloo."""
-    extra = ["--coded"] if coded else []
+    extra = [] if coded else ["--raw"]          # coded lf0 / mgc / bap is what the recipe writes, and the default
     common = ["--workload", "sweep", "--utts", 14, "--dur", 0.4, 1.6, "--steps", 1, "--warmup", 0, "--no-cpu-baseline",
               "--workers", 1]
     one = _bench(*common, *extra, "--out-dir", tmp_path / "one")
@@ -148,14 +148,35 @@ def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
     for n in names:
         a, b = open(tmp_path / "one" / n, "rb").read(), open(tmp_path / "two" / n, "rb").read()
         assert a == b and len(a) > 0, n
-    # and the content is the analysis of that utterance: spot check one against the per-utterance API
+    # and the content is the reference's analysis of that utterance: the files of one utterance against the ORACLE
+    # (float32 as the CLI writes them, test/analysis.cpp:292-390)
+    from oracle.bindings import Oracle
+    o = Oracle()
     i = 3
     x = sd.make_utterance(i, 16000, (0.4, 1.6))
-    t, f0 = pkg.capi.dio(x, 16000)
-    f0 = pkg.capi.stonemask(x, 16000, t, f0)
+    t, f0 = o.dio(x, 16000)
+    f0 = o.stonemask(x, 16000, t, f0)
+    F = o.cheaptrick_fft_size(16000)
+    sp = o.cheaptrick(x, 16000, t, f0, -0.15, F)
+    ap = o.d4c(x, 16000, t, f0, F, 0.0)
+    rd = lambda ext, cols=None: (np.fromfile(tmp_path / "two" / ("utt%05d.%s" % (i, ext)), dtype=np.float32)
+                                 .reshape((-1, cols) if cols else (-1,)))
     if not coded:
-        got = np.fromfile(tmp_path / "two" / ("utt%05d.f0" % i), dtype=np.float32)
-        np.testing.assert_array_equal(got, f0.astype(np.float32))
+        np.testing.assert_allclose(rd("f0"), f0.astype(np.float32), rtol=1e-6, atol=0)
+        np.testing.assert_allclose(rd("sp", F // 2 + 1), sp.astype(np.float32), rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(rd("ap", F // 2 + 1), ap.astype(np.float32), rtol=0, atol=1e-6)
+    else:
+        sp4 = sp * 1e4
+        sp4[sp4 == 0.0] = 0.0001
+        mgc = o.code_spectral_envelope(sp4, 16000, F, 50)
+        mgc[:, 0] += 12.0
+        bap = o.code_spectral_envelope(ap * 1e4, 16000, F, 25)
+        bap[:, 0] -= 9.210340
+        bap[(bap[:, 0] > 0) & (bap[:, 0] < 1e-4), 0] = 0.0
+        lf0 = np.where(f0 > 0, np.log(np.where(f0 > 0, f0, 1.0)), 0.0)         # analysis.cpp:216-224
+        np.testing.assert_allclose(rd("lf0"), lf0.astype(np.float32), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rd("mgc", 50), mgc.astype(np.float32), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(rd("bap", 25), bap.astype(np.float32), rtol=0, atol=2e-5)
 
 
 @pytest.mark.gpu

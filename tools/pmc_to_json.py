@@ -2,7 +2,10 @@
 into one record of profiles/pmc_traffic.json: HBM-side KB of the dominant kernel, the frames it processed, and a hash
 of the kernel's sources (bench.py prints `roofline.traffic` only while that hash still matches).
 
-    python tools/pmc_to_json.py FETCH_DIR WRITE_DIR FRAMES FS TAG
+    python tools/pmc_to_json.py FETCH_DIR WRITE_DIR FRAMES FS TAG [WORKLOAD]
+
+WORKLOAD: analysis_synthesis (default; d4c_kernel), harvest (hv_band_fft_kernel), synthesis (synth_pulse_kernel).
+The readings are stored as reported; bench.py applies the factors of profiles/hbm_counter_calibration.json.
 """
 import csv
 import glob
@@ -27,12 +30,17 @@ def counts_as_launch(name):
     return "d4cb_spectrum_kernel" not in name and "d4cb_band_kernel" not in name
 
 
-def total(dirname, counter):
+MATCH = {"analysis_synthesis": is_usual_d4c,
+         "harvest": lambda n: "hv_band_fft_kernel" in n,
+         "synthesis": lambda n: "synth_pulse_kernel" in n}
+
+
+def total(dirname, counter, match=is_usual_d4c):
     kb, launches, name = 0.0, 0, None
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Counter_Name") == counter and is_usual_d4c(row.get("Kernel_Name", "")):
+                if row.get("Counter_Name") == counter and match(row.get("Kernel_Name", "")):
                     kb += float(row["Counter_Value"])
                     if counts_as_launch(row["Kernel_Name"]):
                         launches += 1
@@ -42,21 +50,23 @@ def total(dirname, counter):
 
 def main():
     fdir, wdir, frames, fs, tag = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    fkb, fl, name = total(fdir, "FETCH_SIZE")
-    wkb, wl, _ = total(wdir, "WRITE_SIZE")
+    workload = sys.argv[6] if len(sys.argv) > 6 else "analysis_synthesis"
+    fkb, fl, name = total(fdir, "FETCH_SIZE", MATCH[workload])
+    wkb, wl, _ = total(wdir, "WRITE_SIZE", MATCH[workload])
     assert fl and fl == wl, (fl, wl)
     kname = (name or "d4c_kernel").split("(")[0]
     if "d4cb_" in kname:
         kname = "d4cb_centroid_kernel + d4cb_spectrum_kernel + d4cb_band_kernel (the D4C scope at fft 4096)"
-    rec = {"kernel": kname, "fs": fs, "frames": frames, "launches": fl,
-           "fetch_kb": fkb / fl, "write_kb": wkb / wl, "source_sha": bench.kernel_source_hash(), "tag": tag,
+    rec = {"workload": workload, "kernel": kname, "fs": fs, "frames": frames, "launches": fl,
+           "fetch_kb": fkb / fl, "write_kb": wkb / wl, "source_sha": bench.kernel_source_hash(workload), "tag": tag,
            "files": "profiles/%s_pmc_fetch.csv, profiles/%s_pmc_write.csv" % (tag, tag),
-           "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); 8-byte-per-lane accesses, not the 16-byte streaming "
-                        "pattern the guide's x2 read correction was calibrated on"}
+           "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); bench.py multiplies by the factors measured in "
+                        "profiles/hbm_counter_calibration.json (reads x 2.0, writes x 1.0 on gfx950)"}
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     recs = []
     if os.path.exists(path):
-        recs = [r for r in json.load(open(path)) if r.get("fs") != fs]
+        recs = [r for r in json.load(open(path))
+                if not (r.get("fs") == fs and r.get("workload", "analysis_synthesis") == workload)]
     recs.append(rec)
     json.dump(recs, open(path, "w"), indent=1)
     print(json.dumps(rec))
