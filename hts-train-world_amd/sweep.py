@@ -70,6 +70,8 @@ class ShardedSweep:
         self.params = W.default_params(self.fs, self.fp)
         self.loaded = []                 # [(WorldBatch, x on device)] for this rank's batches
         self._pinned = {}                # rank 0's host staging of the gathered slabs
+        self._items = {}                 # (round, sink) -> the native writer's list for that round
+        self._write_busy = 0.0
         self.total_frames = sum(self.frames)
         self.my_frames = sum(self.frames[i] for i in self.shards[rank])
 
@@ -119,11 +121,18 @@ class ShardedSweep:
             return self._run_pipelined(sink, io_threads)
         return self._run_serial(sink, io_threads)
 
-    def _submit(self, pool, sink, host, groups, pending, io_threads=16):
+    def _submit(self, pool, sink, host, groups, pending, io_threads=16, key=None):
+        """Hand one round's utterances to the writers.  With a DirSink the round is ONE job: the list of (path, row
+        slice) pairs -- built once per (round, sink) and kept, the pinned slabs are the same every pass -- goes to
+        the native writer; any other sink is called per utterance from the pool."""
+        native = hasattr(sink, "paths")
+        cached = self._items.get(key) if (native and key is not None) else None
+        if cached is not None and cached[0] == tuple(h.data_ptr() for h in host):
+            pending.append(pool.submit(self._timed_write, cached[1], io_threads))
+            return
         arrs = [h.numpy() for h in host]
         off = 0
         items = []
-        native = hasattr(sink, "paths")
         for g in groups:                              # rank order, then batch order: the gather's layout
             for i in g:
                 e = off + self.frames[i]
@@ -133,7 +142,14 @@ class ShardedSweep:
                     pending.append(pool.submit(sink, i, arrs[0][off:e], arrs[1][off:e], arrs[2][off:e]))
                 off = e
         if items:
-            pending.append(pool.submit(W.write_files, items, io_threads))
+            if key is not None:
+                self._items[key] = (tuple(h.data_ptr() for h in host), items)
+            pending.append(pool.submit(self._timed_write, items, io_threads))
+
+    def _timed_write(self, items, io_threads):
+        t0 = time.perf_counter()
+        W.write_files(items, io_threads)
+        self._write_busy += time.perf_counter() - t0
 
     def _run_pipelined(self, sink, io_threads):
         import torch
@@ -148,6 +164,7 @@ class ShardedSweep:
         hosts, round_groups, keep = [], [], []
         pending = []
         t_first_submit = [None]
+        self._write_busy = 0.0
         t0 = time.perf_counter()
         with ThreadPoolExecutor(io_threads) as pool:
             def drain(k):
@@ -156,7 +173,7 @@ class ShardedSweep:
                 if sink is not None and hosts[k] is not None:
                     if t_first_submit[0] is None:
                         t_first_submit[0] = time.perf_counter()
-                    self._submit(pool, sink, hosts[k], round_groups[k], pending, io_threads)
+                    self._submit(pool, sink, hosts[k], round_groups[k], pending, io_threads, key=(k, id(sink)))
 
             for k in range(self.rounds):
                 c0, c1, x0, x1, x2 = ev(), ev(), ev(), ev(), ev()
@@ -211,7 +228,9 @@ class ShardedSweep:
             ph["gather"] += x0.elapsed_time(x1) * 1e-3
             ph["to_host"] += x1.elapsed_time(x2) * 1e-3
         if t_first_submit[0] is not None:
-            ph["write"] = t_end - t_first_submit[0]
+            # time inside the native writer when the sink is a DirSink (jobs of different rounds may overlap), else the
+            # span from the first submit to the last completion
+            ph["write"] = self._write_busy if self._write_busy > 0 else t_end - t_first_submit[0]
         ph["wall"] = t_end - t0
         if self.world > 1 and dist.is_initialized():
             dist.barrier()
@@ -298,16 +317,19 @@ def file_sink(paths):
 
 
 class DirSink:
-    """sink for ShardedSweep.run(): utterance i goes to out_dir/utt%05d.{f0,sp,ap} (or the names given).  Callable
-    like any sink; run() recognises `paths` and hands a whole round to the native writer instead (one library call,
-    plain threads: WorldMi355WriteFiles), which is what keeps 3 000 files per pass off the interpreter lock."""
+    """sink for ShardedSweep.run(): utterance i goes to out_dir/<name>/utt%05d.<name> for the three names given --
+    one directory per feature, as the recipe lays its files out (data/Makefile.in:214: lf0/$base.lf0, mgc/$base.mgc,
+    bap/$base.bap; creating files in ONE directory serialises on that directory's lock).  Callable like any sink;
+    run() recognises `paths` and hands a whole round to the native writer instead (one library call, plain threads:
+    WorldMi355WriteFiles), which is what keeps 3 000 files per pass off the interpreter lock."""
 
     def __init__(self, out_dir, names=("f0", "sp", "ap")):
-        os.makedirs(out_dir, exist_ok=True)
         self.out_dir, self.names = out_dir, tuple(names)
+        for n in self.names:
+            os.makedirs(os.path.join(out_dir, n), exist_ok=True)
 
     def paths(self, i):
-        return [os.path.join(self.out_dir, "utt%05d.%s" % (i, n)) for n in self.names]
+        return [os.path.join(self.out_dir, n, "utt%05d.%s" % (i, n)) for n in self.names]
 
     def __call__(self, i, f0, sp, ap):
         for path, arr in zip(self.paths(i), (f0, sp, ap)):

@@ -143,8 +143,11 @@ def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
     assert one[0]["n_gpus"] == 1 and two[0]["n_gpus"] == 2 and two[0]["scaling"] == "strong"
     assert two[0]["config"]["frames"] == one[0]["config"]["frames"]
     assert two[0]["config"]["frames_on_busiest_rank"] < one[0]["config"]["frames"] * 0.6
-    names = sorted(os.listdir(tmp_path / "one"))
-    assert names == sorted(os.listdir(tmp_path / "two")) and len(names) == 14 * 3
+    # one directory per feature, as the recipe lays them out (data/Makefile.in:214)
+    listing = lambda d: sorted(os.path.join(sub, n) for sub in os.listdir(d) for n in os.listdir(d / sub))
+    names = listing(tmp_path / "one")
+    assert names == listing(tmp_path / "two") and len(names) == 14 * 3
+    assert sorted(os.listdir(tmp_path / "one")) == sorted(["lf0", "mgc", "bap"] if coded else ["f0", "sp", "ap"])
     for n in names:
         a, b = open(tmp_path / "one" / n, "rb").read(), open(tmp_path / "two" / n, "rb").read()
         assert a == b and len(a) > 0, n
@@ -159,7 +162,7 @@ def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
     F = o.cheaptrick_fft_size(16000)
     sp = o.cheaptrick(x, 16000, t, f0, -0.15, F)
     ap = o.d4c(x, 16000, t, f0, F, 0.0)
-    rd = lambda ext, cols=None: (np.fromfile(tmp_path / "two" / ("utt%05d.%s" % (i, ext)), dtype=np.float32)
+    rd = lambda ext, cols=None: (np.fromfile(tmp_path / "two" / ext / ("utt%05d.%s" % (i, ext)), dtype=np.float32)
                                  .reshape((-1, cols) if cols else (-1,)))
     if not coded:
         np.testing.assert_allclose(rd("f0"), f0.astype(np.float32), rtol=1e-6, atol=0)
