@@ -515,30 +515,40 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   const int g1 = persistent_grid(c, d4cb_centroid_kernel<FD>, 64, (int64_t)1 << 40);
   const int g2 = persistent_grid(c, d4cb_spectrum_kernel<FD>, 64, (int64_t)1 << 40);
   const int g3 = persistent_grid(c, d4cb_band_kernel<FD>, 64, (int64_t)1 << 40);
-  const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
-  const size_t ws_rows = (size_t)g1;                               // one scratch row per workgroup of the centroid kernel
+  // The per-frame arrays between the kernels (C: the centroid by quarter, GD: the group delay; 33 KB per frame) hold
+  // kD4cBigChunk listed frames at most and are reused chunk after chunk: the workspace is bounded whatever the batch
+  // (1.5 M frames at 48 kHz used to ask for 74 GB).  The count of listed frames lives on the device, so the chunk
+  // launches cover the whole frame range and the kernels clip to what is listed.
+  constexpr int64_t kD4cBigChunk = 128 * 1024;
+  const int64_t chunk = tf < kD4cBigChunk ? (tf > 0 ? tf : 1) : kD4cBigChunk;
+  const size_t ws_rows = (size_t)g1;                               // scratch rows per workgroup of the centroid kernel
   if (!b.d_d4c_big) {
-    const size_t per = (size_t)4 * G::kQ + 2 * (size_t)G::kRow + 8;
-    int rc = wm_check(dev_alloc(&b.d_d4c_big, sizeof(double) * (per * (size_t)(tf > 0 ? tf : 1) +
+    const size_t per = (size_t)4 * G::kQ + (size_t)G::kRow;
+    int rc = wm_check(dev_alloc(&b.d_d4c_big, sizeof(double) * (per * (size_t)chunk + 8 * (size_t)(tf > 0 ? tf : 1) +
                                                                         ws_rows * D4cBigWs<FD>::kDoubles)));
     if (rc) return rc;
   }
   double* C = b.d_d4c_big;
-  double* SC = C + (size_t)tf * 4 * G::kQ;
-  double* GD = SC + (size_t)tf * G::kRow;
-  double* COARSE = GD + (size_t)tf * G::kRow;
+  double* GD = C + (size_t)chunk * 4 * G::kQ;
+  double* COARSE = GD + (size_t)chunk * G::kRow;
   double* WS = COARSE + (size_t)tf * 8;
   const int fs = b.p.fs;
   const int* perm = (const int*)b.d_perm;
   const int* nl = (const int*)b.d_part_n;
-  hipLaunchKernelGGL(d4cb_centroid_kernel<FD>, dim3(imin(cap, g1)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, WS, C);
-  hipLaunchKernelGGL(d4cb_spectrum_kernel<FD>, dim3(imin(cap, g2)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (const double*)C, SC, GD);
-  const int64_t tasks = tf * tab.nap;
-  const int cap3 = (int)(tasks < (int64_t)c.frame_grid * 4 ? tasks : (int64_t)c.frame_grid * 4);
-  hipLaunchKernelGGL(d4cb_band_kernel<FD>, dim3(imax(1, imin(cap3, g3))), dim3(64), 0, st, d_f0, fs, tab, perm, nl,
-                     (const double*)GD, COARSE);
+  for (int64_t begin = 0; begin < tf; begin += chunk) {
+    const int64_t left = tf - begin < chunk ? tf - begin : chunk;
+    const int capc = (int)(left < (int64_t)c.frame_grid ? left : (int64_t)c.frame_grid);
+    hipLaunchKernelGGL(d4cb_centroid_kernel<FD>, dim3(imin(capc, g1)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (int)begin, (int)chunk, WS, C);
+    hipLaunchKernelGGL(d4cb_spectrum_kernel<FD>, dim3(imin(capc, g2)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (int)begin, (int)chunk,
+                       (const double*)C, GD);
+    const int64_t tasks = left * tab.nap;
+    const int cap3 = (int)(tasks < (int64_t)c.frame_grid * 4 ? tasks : (int64_t)c.frame_grid * 4);
+    hipLaunchKernelGGL(d4cb_band_kernel<FD>, dim3(imax(1, imin(cap3, g3))), dim3(64), 0, st, d_f0, fs, tab, perm, nl,
+                       (int)begin, (int)chunk, (const double*)GD, COARSE);
+  }
+  const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   const int64_t blocks = (tf + 3) / 4;
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
                      b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);

@@ -140,15 +140,21 @@ __device__ __forceinline__ void d4cb_quarter0_input(const double (&x)[FD / 64], 
   }
 }
 
-// Scratch row of a workgroup of the centroid kernel (doubles): the frame.
-template <int FD> struct D4cBigWs { static constexpr int kFrame = 0, kDoubles = FD; };
+// Scratch of a workgroup of the centroid kernel (doubles): the frames of the two sides.
+template <int FD> struct D4cBigWs { static constexpr int kDoubles = 2 * FD; };
+
+// The listed frames [begin, begin + chunk) of a launch: the per-frame arrays C / GD have `chunk` rows, indexed by
+// the position in that range.
+__device__ __forceinline__ int d4cb_chunk_count(const int* __restrict__ n_listed, int begin, int chunk) {
+  return imax(0, imin(chunk, *n_listed - begin));
+}
 
 template <int FD>
 __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, double* scratch, double* __restrict__ C) {
+    const int* __restrict__ n_listed, int begin, int chunk, double* scratch, double* __restrict__ C) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kQ = D4cBig<FD>::kQ;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<NS>::kElems];
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -156,102 +162,139 @@ __global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
   FftTw<NS> tw;
   tw.init(lane0);
   double* ws = scratch + (int64_t)blockIdx.x * D4cBigWs<FD>::kDoubles;
-  double* xs = ws + D4cBigWs<FD>::kFrame;
-  const int n_run = *n_listed;
+  const int n_run = d4cb_chunk_count(n_listed, begin, chunk);
   FramePipe pipe;
-  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  pipe.init(perm + begin, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
   WM_FOR_EACH_PIPED(sc, pipe, n_run) {
     const int fs = opaque_uniform(fs_arg);
     const double cf0 = uniform_d(sc.f0 > kFloorF0D4C ? sc.f0 : kFloorF0D4C);
     const double pos = uniform_d(sc.tpos);
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
-    double* Cf = C + sc.frame * (int64_t)(4 * kQ);
+    double* Cf = C + sc.pos * (int64_t)(4 * kQ);
+    // ---- the frames of both sides (d4c.cpp:125-142: pos -/+ 0.25 / f0), built in registers and parked in the
+    //      workgroup's scratch rows: every sub-transform re-reads them from there (every lane what it stored itself)
+    //      instead of 128 registers living through the transforms ----
+    const FrameGeom fg0 = frame_geom(fs, cf0, uniform_d(pos - 0.25 / cf0), 4.0);
+    const int L = fg0.L;                                          // the same on both sides
+    const double s = (double)(1 << (31 - __clz(fg0.hw | 1)));
+    double scale[2];
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
       const int lane = opaque_lane(lane0);
-      tw.fence();
       const double cpos = uniform_d(side == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0);
       const FrameGeom fg = frame_geom(fs, cf0, cpos, 4.0);
-      // the frame is built in registers; the first sub-transform takes it from there, the other three re-read it
-      // from the workgroup's scratch row (every lane what it stored itself) instead of holding 128 registers
-      // across the transforms before them
-      cpx v[MS];
+      double xr[4 * MS];
       double pwr;
-      const double s = (double)(1 << (31 - __clz(fg.hw | 1)));
-      {
-        double xr[4 * MS];
-        frame_strided<kBlackman, 4 * MS, false>(sc.xu, sc.xlen, fg, rtab, sc.roff + side * Lw, lane, xr, pwr);
+      frame_strided<kBlackman, 4 * MS, false>(sc.xu, sc.xlen, fg, rtab, sc.roff + side * Lw, lane, xr, pwr);
+      double* xs = ws + side * FD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (g * NS < fg.L) {                                    // wave-uniform
+      for (int g = 0; g < 4; ++g)
+        if (g * NS < fg.L) {                                      // wave-uniform
 #pragma unroll
-            for (int m = 0; m < MS; ++m) xs[lane + 64 * (m + MS * g)] = xr[m + MS * g];
-          }
-        d4cb_quarter0_input<FD>(xr, fg.L, s, lane, v);
-      }
-      const double scale = uniform_d(1.0 / (2.0 * s * pwr));
-      const cpx wl = cis_neg2pi((double)lane / (double)FD);       // W_FD^lane
-      // C[q][lane + 64 m] (+)= val * scale.  The second side adds to what the first one stored: those values are
-      // fetched (prev) BEFORE the transform whose results they meet, not one by one when they are needed -- a
-      // dependent load per value was 33 round trips to memory per frame.
-      double prev[MS / 2];
-      auto fetch = [&](int q, double (&pv)[MS / 2]) {
-#pragma unroll
-        for (int m = 0; m < MS / 2; ++m) pv[m] = side == 0 ? 0.0 : Cf[q * kQ + lane + 64 * m];
-      };
-      auto put = [&](int q, int m, double val, double before) { Cf[q * kQ + lane + 64 * m] = before + val * scale; };
-      // ---- q = 0: pairs with itself, j <-> (NS - j) mod NS ----
-      fetch(0, prev);
-      double prev_mid = 0.0;
-      if (side != 0 && lane == 0) prev_mid = Cf[NS / 2];
-      fft_forward<NS>(v, img, tw, lane);
-      store_upper<NS>(v, img, lane);
-#pragma unroll
-      for (int m = 0; m < MS / 2; ++m) {
-        const int j = lane + 64 * m;
-        cpx pt = img[(NS - j) & (NS - 1)];
-        if (m == 0) {
-          pt.x = lane == 0 ? v[0].x : pt.x;
-          pt.y = lane == 0 ? v[0].y : pt.y;
+          for (int m = 0; m < MS; ++m) xs[lane + 64 * (m + MS * g)] = xr[m + MS * g];
         }
-        put(0, m, v[m].x * pt.y + v[m].y * pt.x, prev[m]);
+      // normalisation to unit energy (d4c.cpp:96-100) and the 1 / (2 s) of the identity in d4c.hip, on the products
+      const double sv = uniform_d(1.0 / (2.0 * s * pwr));
+      if (side == 0) scale[0] = sv; else scale[1] = sv;
+    }
+    // ---- C[q][j] = sum over the sides of the centroid at bin 4 j + q, accumulated in registers and stored once
+    //      (the first version added the second side to what the first had stored: a read-modify-write of 16 KB per
+    //      frame through HBM) ----
+    // q = 0: pairs with itself, j <-> (NS - j) mod NS
+    {
+      double acc[MS / 2], mid = 0.0;
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) acc[m] = 0.0;
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {
+        const int lane = opaque_lane(lane0);
+        tw.fence();
+        const double sv = side == 0 ? scale[0] : scale[1];
+        cpx v[MS];
+        d4cb_quarter_input<FD, 0>(ws + side * FD, L, s, make_double2(1.0, 0.0), lane, v);
+        fft_forward<NS>(v, img, tw, lane);
+        store_upper<NS>(v, img, lane);
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) {
+          const int j = lane + 64 * m;
+          cpx pt = img[(NS - j) & (NS - 1)];
+          if (m == 0) {
+            pt.x = lane == 0 ? v[0].x : pt.x;
+            pt.y = lane == 0 ? v[0].y : pt.y;
+          }
+          acc[m] += (v[m].x * pt.y + v[m].y * pt.x) * sv;
+        }
+        mid += 2.0 * v[MS / 2].x * v[MS / 2].y * sv;               // lane 0: j = NS / 2 pairs with itself
+        wave_sync();
       }
-      if (lane == 0) put(0, MS / 2, 2.0 * v[MS / 2].x * v[MS / 2].y, prev_mid);   // j = NS / 2 pairs with itself
-      // ---- q = 2: pairs with itself, j <-> NS - 1 - j ----
-      d4cb_quarter_input<FD, 2>(xs, fg.L, s, wl, lane, v);
-      fetch(2, prev);
-      fft_forward<NS>(v, img, tw, lane);
-      store_upper<NS>(v, img, lane);
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) Cf[0 * kQ + lane0 + 64 * m] = acc[m];
+      if (lane0 == 0) Cf[NS / 2] = mid;
+    }
+    // q = 2: pairs with itself, j <-> NS - 1 - j
+    {
+      double acc[MS / 2];
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) acc[m] = 0.0;
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {
+        const int lane = opaque_lane(lane0);
+        tw.fence();
+        const double sv = side == 0 ? scale[0] : scale[1];
+        const cpx wl = cis_neg2pi((double)lane / (double)FD);     // W_FD^lane
+        cpx v[MS];
+        d4cb_quarter_input<FD, 2>(ws + side * FD, L, s, wl, lane, v);
+        fft_forward<NS>(v, img, tw, lane);
+        store_upper<NS>(v, img, lane);
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) {
+          const cpx pt = img[NS - 1 - (lane + 64 * m)];
+          acc[m] += (v[m].x * pt.y + v[m].y * pt.x) * sv;
+        }
+        wave_sync();
+      }
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) Cf[2 * kQ + lane0 + 64 * m] = acc[m];
+    }
+    // q = 1 and q = 3: bins 4 j + 1 pair E1[j] with E3[NS - 1 - j], bins 4 j + 3 pair E3[j] with E1[NS - 1 - j];
+    // E1 waits in registers while E3 is transformed
+    {
+      double acc1[MS / 2], acc3[MS / 2];
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) acc1[m] = acc3[m] = 0.0;
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {
+        const int lane = opaque_lane(lane0);
+        tw.fence();
+        const double sv = side == 0 ? scale[0] : scale[1];
+        const cpx wl = cis_neg2pi((double)lane / (double)FD);
+        cpx v[MS];
+        d4cb_quarter_input<FD, 1>(ws + side * FD, L, s, wl, lane, v);
+        fft_forward<NS>(v, img, tw, lane);
+        cpx v1[MS];
+#pragma unroll
+        for (int m = 0; m < MS; ++m) v1[m] = v[m];
+        d4cb_quarter_input<FD, 3>(ws + side * FD, L, s, wl, lane, v);
+        fft_forward<NS>(v, img, tw, lane);
+        store_upper<NS>(v, img, lane);
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) {
+          const cpx pt = img[NS - 1 - (lane + 64 * m)];           // E3[NS - 1 - j]
+          acc1[m] += (v1[m].x * pt.y + v1[m].y * pt.x) * sv;
+        }
+        store_upper<NS>(v1, img, lane);
+#pragma unroll
+        for (int m = 0; m < MS / 2; ++m) {
+          const cpx pt = img[NS - 1 - (lane + 64 * m)];           // E1[NS - 1 - j]
+          acc3[m] += (v[m].x * pt.y + v[m].y * pt.x) * sv;
+        }
+        wave_sync();
+      }
 #pragma unroll
       for (int m = 0; m < MS / 2; ++m) {
-        const cpx pt = img[NS - 1 - (lane + 64 * m)];
-        put(2, m, v[m].x * pt.y + v[m].y * pt.x, prev[m]);
+        Cf[1 * kQ + lane0 + 64 * m] = acc1[m];
+        Cf[3 * kQ + lane0 + 64 * m] = acc3[m];
       }
-      // ---- q = 1 and q = 3: bins 4 j + 1 pair E1[j] with E3[NS - 1 - j], bins 4 j + 3 pair E3[j] with E1[NS - 1 - j];
-      //      E1 waits in registers while E3 is transformed ----
-      d4cb_quarter_input<FD, 1>(xs, fg.L, s, wl, lane, v);
-      fft_forward<NS>(v, img, tw, lane);
-      cpx v1[MS];
-#pragma unroll
-      for (int m = 0; m < MS; ++m) v1[m] = v[m];
-      d4cb_quarter_input<FD, 3>(xs, fg.L, s, wl, lane, v);
-      fetch(1, prev);
-      fft_forward<NS>(v, img, tw, lane);
-      double prev3[MS / 2];
-      fetch(3, prev3);
-      store_upper<NS>(v, img, lane);
-#pragma unroll
-      for (int m = 0; m < MS / 2; ++m) {
-        const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E3[NS - 1 - j]
-        put(1, m, v1[m].x * pt.y + v1[m].y * pt.x, prev[m]);
-      }
-      store_upper<NS>(v1, img, lane);
-#pragma unroll
-      for (int m = 0; m < MS / 2; ++m) {
-        const cpx pt = img[NS - 1 - (lane + 64 * m)];             // E1[NS - 1 - j]
-        put(3, m, v[m].x * pt.y + v[m].y * pt.x, prev3[m]);
-      }
-      wave_sync();
     }
   }
 }
@@ -317,8 +360,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
-    const int* __restrict__ n_listed, const double* __restrict__ C, double* __restrict__ SC,
-    double* __restrict__ GD) {
+    const int* __restrict__ n_listed, int begin, int chunk, const double* __restrict__ C, double* __restrict__ GD) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, H = D4cBig<FD>::H, kQ = D4cBig<FD>::kQ;
   constexpr int kRow = D4cBig<FD>::kRow;
   constexpr int kBM = FD / 16;
@@ -332,46 +374,22 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
   const int lane0 = threadIdx.x;
   FftTw<NS> tw;
   tw.init(lane0);
-  const int n_run = *n_listed;
+  const int n_run = d4cb_chunk_count(n_listed, begin, chunk);
   FramePipe pipe;
-  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  pipe.init(perm + begin, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
   WM_FOR_EACH_PIPED(sc, pipe, n_run) {
     const int lane = opaque_lane(lane0);
     const int fs = opaque_uniform(fs_arg);
     tw.fence();
     const double cf0 = uniform_d(sc.f0 > kFloorF0D4C ? sc.f0 : kFloorF0D4C);
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
-    const double* Cf = C + sc.frame * (int64_t)(4 * kQ);
-    double* SCf = SC + sc.frame * (int64_t)kRow;
-    double* GDf = GD + sc.frame * (int64_t)kRow;
-    // ---- static centroid: gather the four quarters, DCCorrection (d4c.cpp:139), keep it in HBM ----
+    const double* Cf = C + sc.pos * (int64_t)(4 * kQ);
+    double* GDf = GD + sc.pos * (int64_t)kRow;
     wave_sync();
-    {
-      double cq[4][MS / 2];                                      // all 32 loads in flight, then the LDS stores
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int m = 0; m < MS / 2; ++m) cq[q][m] = Cf[q * kQ + lane + 64 * m];
-      const double mid = Cf[NS / 2];
-      cpx* arr2 = reinterpret_cast<cpx*>(arr);                   // bins 4 j .. 4 j + 3 as two 16-byte stores
-#pragma unroll
-      for (int m = 0; m < MS / 2; ++m) {
-        arr2[2 * (lane + 64 * m)] = make_double2(cq[0][m], cq[1][m]);
-        arr2[2 * (lane + 64 * m) + 1] = make_double2(cq[2][m], cq[3][m]);
-      }
-      if (lane == 0) arr[H] = mid;                               // q = 0, j = NS / 2: bin FD / 2
-    }
-    wave_sync();
-    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
-#pragma unroll
-    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven LDS reads in flight
-#pragma unroll
-      for (int t = t0; t < t0 + 11 && t < T; ++t)
-        if (lane + 64 * t <= H) SCf[lane + 64 * t] = arr[lane + 64 * t];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    wave_sync();
-    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
+    // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164), kept in registers (bin lane + 64 t): the static centroid
+    //      passes through LDS next, and what used to be parked in HBM in between (the corrected centroid, the first
+    //      smoothing of the group delay: four times 16 KB per frame) stays on the chip ----
+    double ps[T];
     {
       cpx va[MS], vb[MS];
       const FrameGeom fg = frame_geom(fs, cf0, uniform_d(sc.tpos), 4.0);
@@ -391,37 +409,40 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
     }
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
     linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
-    asm volatile("" ::: "memory");                               // the centroid is fetched here, not before the smoothing
 #pragma unroll
-    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven quotients at a time
-      double scv[11];
+    for (int t = 0; t < T; ++t) ps[t] = arr[imin(lane + 64 * t, H)];
+    wave_sync();
+    // ---- static centroid: gather the four quarters, DCCorrection (d4c.cpp:139) ----
+    {
+      double cq[4][MS / 2];                                      // all 32 loads in flight, then the LDS stores
 #pragma unroll
-      for (int t = 0; t < 11; ++t) scv[t] = t0 + t < T ? SCf[imin(lane + 64 * (t0 + t), H)] : 0.0;
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int t = 0; t < 11; ++t)
-        if (t0 + t < T && lane + 64 * (t0 + t) <= H) arr[lane + 64 * (t0 + t)] = scv[t] / arr[lane + 64 * (t0 + t)];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < MS / 2; ++m) cq[q][m] = Cf[q * kQ + lane + 64 * m];
+      const double mid = Cf[NS / 2];
+      cpx* arr2 = reinterpret_cast<cpx*>(arr);                   // bins 4 j .. 4 j + 3 as two 16-byte stores
+#pragma unroll
+      for (int m = 0; m < MS / 2; ++m) {
+        arr2[2 * (lane + 64 * m)] = make_double2(cq[0][m], cq[1][m]);
+        arr2[2 * (lane + 64 * m) + 1] = make_double2(cq[2][m], cq[3][m]);
+      }
+      if (lane == 0) arr[H] = mid;                               // q = 0, j = NS / 2: bin FD / 2
     }
+    wave_sync();
+    dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (lane + 64 * t <= H) arr[lane + 64 * t] = arr[lane + 64 * t] / ps[t];
     wave_sync();
     linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
 #pragma unroll
-    for (int t0 = 0; t0 < T; t0 += 11) {                         // eleven LDS reads in flight
-#pragma unroll
-      for (int t = t0; t < t0 + 11 && t < T; ++t)
-        if (lane + 64 * t <= H) GDf[lane + 64 * t] = arr[lane + 64 * t];
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int t = 0; t < T; ++t) ps[t] = arr[imin(lane + 64 * t, H)];      // the first smoothing, in the same registers
     wave_sync();
     linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    {
-      double g1[T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) g1[t] = GDf[imin(lane + 64 * t, H)];
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-        if (lane + 64 * t <= H) GDf[lane + 64 * t] = g1[t] - arr[lane + 64 * t];
-    }
+    for (int t = 0; t < T; ++t)
+      if (lane + 64 * t <= H) GDf[lane + 64 * t] = ps[t] - arr[lane + 64 * t];
     wave_sync();
   }
 }
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
 template <int FD>
 __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restrict__ f0, int fs, D4CTables tab,
                                                           const int* __restrict__ perm,
-                                                          const int* __restrict__ n_listed,
+                                                          const int* __restrict__ n_listed, int begin, int chunk,
                                                           const double* __restrict__ GD,
                                                           double* __restrict__ COARSE) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, kRow = D4cBig<FD>::kRow;
@@ -442,7 +463,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
   const int lane0 = threadIdx.x;
   FftTw<NS> tw;
   tw.init(lane0);
-  const int64_t n_task = (int64_t)*n_listed * tab.nap;
+  const int64_t n_task = (int64_t)d4cb_chunk_count(n_listed, begin, chunk) * tab.nap;
   const int wl = tab.window_length, hwl = wl / 2;
   const int bnd = matlab_round(FD * 8.0 / wl);
   for (int64_t task = blockIdx.x; task < n_task; task += gridDim.x) {
@@ -450,10 +471,10 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
     tw.fence();
     const int64_t li = task / tab.nap;
     const int band = (int)(task - li * tab.nap);
-    const int frame = __builtin_amdgcn_readfirstlane(perm[li]);
+    const int frame = __builtin_amdgcn_readfirstlane(perm[begin + li]);
     const double f0v = f0[frame];
     const double cf0 = uniform_d(f0v > kFloorF0D4C ? f0v : kFloorF0D4C);
-    const double* gd = GD + frame * (int64_t)kRow;
+    const double* gd = GD + li * (int64_t)kRow;                  // rows by position in the chunk
     const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
     // the window has at most FD / 4 - 1 taps (launch_d4c_big checks): the upper half of the packed operand is zero.
     // All loads are issued together with clamped indices (a branch per pair would make every pair a trip to memory).

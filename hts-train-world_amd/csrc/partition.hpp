@@ -114,6 +114,7 @@ __device__ __forceinline__ int64_t listed_at(const int* __restrict__ perm, int64
 // Every value is consumed one iteration after its request; the sample loads of a frame are the only round trip
 // left on its critical path.
 struct FrameScalars {
+  int64_t pos;          // position in the list
   int64_t frame;        // -1 beyond the end of the list
   double f0, tpos;
   const double* xu;     // the utterance's samples
@@ -166,6 +167,7 @@ struct FramePipe {
   // the scalars of the frame of round `base`, and one step of every stage
   __device__ __forceinline__ FrameScalars next() {
     FrameScalars c;
+    c.pos = xcd_dealt(base, count);
     c.frame = fr1; c.f0 = f0_1; c.tpos = tp_1; c.xu = x + xo_1; c.xlen = xl_1; c.roff = ro_1;
     const int64_t e3 = entry3();        // arrived: requested one step ago
     // new stage 3 first: its destination is then not behind this step's other requests
