@@ -503,10 +503,10 @@ struct D4cRunRarePred {
 #include "d4c_big.hpp"
 namespace wm {
 
-// fft_size_d4c = 4096: the four-kernel form of d4c_big.hpp for the usual frames
+// fft_size_d4c = 4096 / 8192: the four-kernel form of d4c_big.hpp for the usual frames
+template <int FD>
 static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const double* d_f0, D4CTables tab,
                           double* d_ap) {
-  constexpr int FD = 4096;
   typedef D4cBig<FD> G;
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
@@ -552,11 +552,15 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   const int64_t blocks = (tf + 3) / 4;
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
                      b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);
-  // the rare frames afterwards, over the default rows the output kernel has written for them
-  const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
-  hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                     b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab,
-                     b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);
+  // the rare frames afterwards, over the default rows the output kernel has written for them.  At 8192 there is no
+  // one-kernel form (its transform would be 4096 complex points on one wavefront): frames with f0 >= fs / 16 (6 kHz at
+  // 96 kHz) keep the default row there.
+  if constexpr (FD <= 4096) {
+    const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
+    hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab,
+                       b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);
+  }
   return wm_check(hipGetLastError());
 }
 
@@ -565,7 +569,7 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   hipStream_t st = c.stream;
   const int fs = b.p.fs;
   const int FD = d4c_fft_size(fs), FL = lovetrain_fft_size(fs);
-  if (FD != FL || (FD != 1024 && FD != 2048 && FD != 4096)) {
+  if (FD != FL || (FD != 1024 && FD != 2048 && FD != 4096 && FD != 8192)) {
     return WM_ERR_UNSUPPORTED_FFT;
   }
   int rc = c.ensure_rng(b.rng_bound_d4c());
@@ -621,6 +625,12 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
         WM_LT_CASE(1024)
         WM_LT_CASE(2048)
         WM_LT_CASE(4096)
+        case 8192: {
+          const int per_ = persistent_grid(c, d4cb_lovetrain_kernel<8192>, 64, (int64_t)1 << 40);
+          hipLaunchKernelGGL(d4cb_lovetrain_kernel<8192>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
+                             b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, (const int*)b.d_perm,
+                             (const int*)b.d_part_n, b.d_ap0);
+        } break;
       }
     }
   }
@@ -652,7 +662,11 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
       WM_D4C_CASE(1024, 2)
       WM_D4C_CASE(2048, 2)
       case 4096: {              // four kernels on the 1024-point transform (d4c_big.hpp)
-        rc = launch_d4c_big(b, d_x, d_t, d_f0, tab, d_ap);
+        rc = launch_d4c_big<4096>(b, d_x, d_t, d_f0, tab, d_ap);
+        if (rc) return rc;
+      } break;
+      case 8192: {              // the same on the 2048-point transform (fs above 48.1 kHz)
+        rc = launch_d4c_big<8192>(b, d_x, d_t, d_f0, tab, d_ap);
         if (rc) return rc;
       } break;
     }

@@ -1,5 +1,6 @@
-// d4c_big.hpp -- D4CGeneralBody for fft_size_d4c = 4096 (fs above 24 kHz: the recipe's own 48 kHz), as four
-// kernels on the 1024-point wavefront transform.  Included by d4c.hip.
+// d4c_big.hpp -- D4CGeneralBody for fft_size_d4c = 4096 (fs above 24 kHz: the recipe's own 48 kHz) and 8192 (fs above
+// 48.1 kHz: 88.2 and 96 kHz), as four kernels on the quarter-size wavefront transform (1024 points, two waves per SIMD;
+// 2048 points at 8192, one wave per SIMD).  Included by d4c.hip.
 //
 // One wavefront per frame with a 2048-point complex engine (32 complex values per lane and operand) needs all 512
 // registers of a SIMD, i.e. one wave per SIMD with nothing to hide latency behind, and still keeps two 2049-bin
@@ -82,7 +83,7 @@ __device__ __forceinline__ void d4cb_quarter_input_p(const double* xs, double s,
                                                      cpx (&v)[D4cBig<FD>::MS]) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
   constexpr int G = P == 1 ? MS : (P == 2 ? MS / 2 : MS / 4);     // elements per group: 12 to 16 loads in flight
-  const cpx w64 = cis64(4096 / FD);                               // W_FD^64
+  const cpx w64 = FD <= 4096 ? cis64(FD <= 4096 ? 4096 / FD : 1) : cis_neg2pi(64.0 / (double)FD);   // W_FD^64
   cpx w = wl;
 #pragma unroll
   for (int g0 = 0; g0 < MS; g0 += G) {
@@ -150,7 +151,7 @@ __device__ __forceinline__ int d4cb_chunk_count(const int* __restrict__ n_listed
 }
 
 template <int FD>
-__global__ __launch_bounds__(64, 2) void d4cb_centroid_kernel(
+__global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_centroid_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
@@ -356,7 +357,7 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
 }
 
 template <int FD>
-__global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
+__global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
     const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, const int* __restrict__ perm,
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64, 2) void d4cb_spectrum_kernel(
 
 // One wavefront per (listed frame, band).
 template <int FD>
-__global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restrict__ f0, int fs, D4CTables tab,
+__global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_band_kernel(const double* __restrict__ f0, int fs, D4CTables tab,
                                                           const int* __restrict__ perm,
                                                           const int* __restrict__ n_listed, int begin, int chunk,
                                                           const double* __restrict__ GD,
@@ -546,6 +547,61 @@ __global__ __launch_bounds__(64, 2) void d4cb_band_kernel(const double* __restri
     c = c + (cf0 - 100.0) / 50.0;                                 // d4c.cpp:309-311
     c = 0.0 < c ? 0.0 : c;                                        // MyMinDouble(0.0, c)
     if (lane == 0) COARSE[(int64_t)frame * 8 + band] = c;
+    wave_sync();
+  }
+}
+
+// D4CLoveTrainSub (d4c.cpp:225-250) where its transform has 8192 points (fs above 54.6 kHz): the power spectrum by
+// the same even / odd halves on the quarter-size engine; aperiodicity0 = cum[boundary1] / cum[boundary2] with the
+// bins up to boundary0 left out.  One wavefront per listed (f0 != 0) frame; the others get 0 (d4c.cpp:231-233).
+template <int FL>
+__global__ __launch_bounds__(64, FL > 4096 ? 1 : 2) void d4cb_lovetrain_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
+    const int* __restrict__ frame_utt, const double* __restrict__ tpos, const double* __restrict__ f0,
+    const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs, int64_t total_frames,
+    const int* __restrict__ perm, const int* __restrict__ n_listed, double* __restrict__ ap0) {
+  constexpr int NS = D4cBig<FL>::NS, MS = D4cBig<FL>::MS;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<NS>::kElems];
+  cpx* img = reinterpret_cast<cpx*>(smem);
+  const int lane0 = threadIdx.x;
+  FftTw<NS> tw;
+  tw.init(lane0);
+  const int b0 = (int)ceil(100.0 * FL / fs), b1 = (int)ceil(4000.0 * FL / fs), b2 = (int)ceil(7900.0 * FL / fs);
+  const int n_run = *n_listed;
+  for (int64_t i = n_run + blockIdx.x * 64 + lane0; i < total_frames; i += (int64_t)gridDim.x * 64)
+    ap0[perm[i]] = 0.0;
+  FramePipe pipe;
+  pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    const int lane = opaque_lane(lane0);
+    tw.fence();
+    const double cf0 = uniform_d(sc.f0 > 40.0 ? sc.f0 : 40.0);
+    const FrameGeom fg = frame_geom(fs, cf0, uniform_d(sc.tpos), 3.0);
+    cpx va[MS], vb[MS];
+    {
+      cpx vp[2 * MS];
+      frame_packed<kBlackman, false, 2 * MS>(sc.xu, sc.xlen, fg, rtab, sc.roff, lane, vp);
+#pragma unroll
+      for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
+    }
+    double pe[MS + 1], po[MS];
+    real_power_halves<FL>(va, vb, fg.L > 2 * NS, img, tw, lane, pe, po);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      const int ke = 2 * (lane + 64 * m), ko = ke + 1;
+      if (ke > b0 && ke <= b1) s1 += pe[m];
+      if (ke > b0 && ke <= b2) s2 += pe[m];
+      if (ko > b0 && ko <= b1) s1 += po[m];
+      if (ko > b0 && ko <= b2) s2 += po[m];
+    }
+    if (lane == 0) {                                              // bin FL / 2 only if a boundary reaches it
+      if (FL / 2 <= b1) s1 += pe[MS];
+      if (FL / 2 <= b2) s2 += pe[MS];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) ap0[sc.frame] = s1 / s2;
     wave_sync();
   }
 }

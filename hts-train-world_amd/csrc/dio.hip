@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void dio_lowcut_fft_kernel(
 // (delayed) Nuttall spectrum, the inverse transform and the four zero-crossing passes.  All bands share
 // ntap0 = 4 hal[0], bias0 = 2 hal[0]: band b's window is delayed by 2 (hal[0] - hal[b]) samples.
 template <int B>
-__global__ __launch_bounds__(64, 2) void dio_band_fft_kernel(
+__global__ __launch_bounds__(64, B > 2048 ? 1 : 2) void dio_band_fft_kernel(
     const int* __restrict__ ylen_a, const int64_t* __restrict__ z_off, const double* __restrict__ z,
     const cpx* __restrict__ H, DioMeta meta, int tiles_max, int* __restrict__ tile_cnt,
     const int64_t* __restrict__ slot_off, double* __restrict__ slots) {
@@ -503,8 +503,10 @@ static int dio_setup(Batch& b) {
   m.pad = 2 * m.hal[0];
   m.cut = matlab_round(m.afs / 50.0);                                                  // :86
   // block FFT convolution where the filters fit a block comfortably (fftconv.hpp), the direct FIR otherwise
-  m.band_conv = 4 * m.hal[0] <= 1024 ? 2048 : 0;
-  m.lc_conv = 2 * m.cut + 1 <= 1024 ? 2048 : (2 * m.cut + 1 <= 3072 ? 4096 : 0);
+  // (blocks of 4096 carry the filters of the rates above 51 kHz: 1 912 band taps and 3 841 low-cut taps at 96 kHz
+  // and speed 1 -- the low-cut then yields only 256 outputs per block: it works, at a sixteenth of the efficiency)
+  m.band_conv = 4 * m.hal[0] <= 1024 ? 2048 : (4 * m.hal[0] <= 2560 ? 4096 : 0);
+  m.lc_conv = 2 * m.cut + 1 <= 1024 ? 2048 : (2 * m.cut + 1 <= 4000 ? 4096 : 0);
   m.step = m.band_conv ? imin(m.band_conv - 4 * m.hal[0] + 1 - 2, 64 * kDioConvC) : kZcStep;
   // Nuttall low-pass windows (dio.cpp:301, common.cpp:113-121)
   H->win.resize((size_t)woff);
@@ -612,7 +614,10 @@ static int dio_setup(Batch& b) {
       else if (m.lc_conv == 4096)
         hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(1), dim3(64), 0, st, b.d_dio_lowcut, d_desc, d_desc + n1,
                            d_desc + 2 * n1, H);
-      if (m.band_conv)
+      if (m.band_conv == 4096)
+        hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(m.nb), dim3(64), 0, st, b.d_dio_win, d_desc + 1,
+                           d_desc + n1 + 1, d_desc + 2 * n1 + 1, (cpx*)b.d_dio_H + n_lc);
+      else if (m.band_conv)
         hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(m.nb), dim3(64), 0, st, b.d_dio_win, d_desc + 1,
                            d_desc + n1 + 1, d_desc + 2 * n1 + 1, H + n_lc);
       rc = wm_check(hipGetLastError());
@@ -663,7 +668,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     const int tiles = (total_max + kBandTile - 1) / kBandTile;
     const int ntap = 2 * m.cut + 1;
     const bool small = ntap <= zc_max_taps<kZcStrideHarvest>();
-    if (!small && ntap > zc_max_taps<kZcStrideLong>()) return WM_ERR_UNSUPPORTED;
+    if (!m.lc_conv && !small && ntap > zc_max_taps<kZcStrideLong>()) return WM_ERR_UNSUPPORTED;
     const size_t lds = sizeof(double) * (size_t)((small ? kZcStrideHarvest : kZcStrideLong) * kBandK + zc_pad16(ntap));
     TimedScope ts_(b.ctx, "dio_lowcut_kernel");
     if (m.lc_conv) {
@@ -688,17 +693,24 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     // row stride of the LDS tile by the longest filter: 16 kHz fits the small one, 48 kHz needs the large
     const int ntap_max = 4 * m.hal[0];
     const bool small = ntap_max <= zc_max_taps<kZcStrideDio>();
-    if (!small && ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
+    if (!m.band_conv && !small && ntap_max > zc_max_taps<kZcStrideHarvest>()) return WM_ERR_UNSUPPORTED;
     const size_t lds = sizeof(double) * (size_t)(small ? zc_lds_doubles<kZcStrideDio>(ntap_max)
                                                        : zc_lds_doubles<kZcStrideHarvest>(ntap_max));
     const int tiles_max = dio_tiles(b.max_x_len / m.ratio + 1, m.step);
     TimedScope ts_(b.ctx, "dio_band_kernel");
     if (m.band_conv) {
       const cpx* Hb = (const cpx*)b.d_dio_H + (m.lc_conv ? m.lc_conv / 2 + 1 : 0);
-      allow_dynamic_lds(*b.ctx, dio_band_fft_kernel<2048>, (int)(ConvEvCfg<2048, kDioConvC>::kLdsBytes));
-      hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), (ConvEvCfg<2048, kDioConvC>::kLdsBytes), st,
-                         b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
-                         b.d_dio_slots);
+      if (m.band_conv == 4096) {
+        allow_dynamic_lds(*b.ctx, dio_band_fft_kernel<4096>, (int)(ConvEvCfg<4096, kDioConvC>::kLdsBytes));
+        hipLaunchKernelGGL(dio_band_fft_kernel<4096>, dim3(tiles_max, b.n_utt), dim3(64), (ConvEvCfg<4096, kDioConvC>::kLdsBytes), st,
+                           b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
+                           b.d_dio_slots);
+      } else {
+        allow_dynamic_lds(*b.ctx, dio_band_fft_kernel<2048>, (int)(ConvEvCfg<2048, kDioConvC>::kLdsBytes));
+        hipLaunchKernelGGL(dio_band_fft_kernel<2048>, dim3(tiles_max, b.n_utt), dim3(64), (ConvEvCfg<2048, kDioConvC>::kLdsBytes), st,
+                           b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, Hb, m, tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off,
+                           b.d_dio_slots);
+      }
     } else if (small)
       hipLaunchKernelGGL((dio_band_kernel<kZcStrideDio>), dim3(tiles_max, m.nb, b.n_utt), dim3(256), lds, st,
                          b.d_dio_ylen, b.d_dio_z_off, b.d_dio_z, b.d_dio_win, m, tiles_max, b.d_dio_tile_cnt,

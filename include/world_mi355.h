@@ -34,7 +34,7 @@ extern "C" {
 #define WM_OK 0
 #define WM_ERR_HIP 1              /* a HIP runtime call failed; see WorldMi355LastError() */
 #define WM_ERR_BAD_ARG 2
-#define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048,4096}; D4C's own size outside {1024,2048,4096} */
+#define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048,4096}; D4C's own size outside {1024,2048,4096,8192} */
 #define WM_ERR_NO_DEVICE 4        /* no HIP device: the product path never falls back to CPU */
 #define WM_ERR_UNSUPPORTED 5
 #define WM_ERR_IO 6                /* a file could not be written (WorldMi355WriteFiles); see WorldMi355LastError() */

@@ -221,29 +221,36 @@ def test_fft_size_512_at_8khz(gpu, pkg, oracle):
     np.testing.assert_allclose(C.synthesis(r["f0"], r["sp"], r["ap"], 512, 5.0, fs), r["y"], atol=Y_TOL, rtol=0)
 
 
-def test_fft_size_4096_at_96khz(gpu, oracle):
-    """fs > 51.2 kHz: CheapTrick / Synthesis / codec at fft_size 4096 (configure.ac:540-549 lists it).  D4C's own
-    transform would be 8192 points there, beyond the one-wavefront engine: that call is refused, not answered wrongly."""
+@pytest.mark.parametrize("fs", [96000, 88200])
+def test_fft_size_4096_above_51khz(gpu, oracle, fs):
+    """fs > 51.2 kHz (configure.ac:540-549 lists FFTLEN 4096 up to 102.4 kHz): CheapTrick / Synthesis / codec at
+    fft_size 4096 and D4C with its own transform of 8192 points (d4c.cpp:344-346) -- the whole chain against the
+    oracle, with the recipe's threshold 0 and with the API's default 0.85 (LoveTrain at 8192 points as well)."""
     torch, W, ctx = gpu
-    fs = 96000
     x = sd.make_utterance(112, fs, duration=0.5)
-    t, f0d = oracle.dio(x, fs)
-    f0 = oracle.stonemask(x, fs, t, f0d)
     F = oracle.cheaptrick_fft_size(fs)
     assert F == 4096
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    r = oracle_chain(oracle, x, fs)
     b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
     assert b.fft_size == 4096
-    sp = b.cheaptrick(dev(x), dev(t), dev(f0))
-    spo = oracle.cheaptrick(x, fs, t, f0, -0.15, F)
-    sp_close(sp.cpu().numpy(), spo)
-    with pytest.raises(RuntimeError):
-        b.d4c(dev(x), dev(t), dev(f0))
-    # Synthesis from a plausible aperiodicity (a smooth ramp; D4C is not available at this rate)
-    ap = np.tile(np.linspace(0.02, 0.9, F // 2 + 1), (len(f0), 1))
-    y = b.synthesize(dev(f0), sp, dev(ap))
-    yo = oracle.synthesis(f0, sp.cpu().numpy(), ap, F, 5.0, fs)
-    np.testing.assert_allclose(y.cpu().numpy(), yo, atol=Y_TOL, rtol=0)
+    xd = torch.from_numpy(x).cuda()
+    t, f0, sp, ap = b.analyze(xd)
+    y = b.synthesize(f0, sp, ap)
+    np.testing.assert_array_equal(t.cpu().numpy(), r["t"])
+    assert ((f0.cpu().numpy() > 0) == (r["f0"] > 0)).all() and (r["f0"] > 0).sum() > 20
+    np.testing.assert_allclose(f0.cpu().numpy(), r["f0"], atol=F0_TOL, rtol=0)
+    sp_close(sp.cpu().numpy(), r["sp"])
+    np.testing.assert_allclose(ap.cpu().numpy(), r["ap"], atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y.cpu().numpy(), r["y"], atol=Y_TOL, rtol=0)
+    b.close()
+    # D4C alone with the default threshold of InitializeD4COption (d4c.cpp:399-401): LoveTrain decides per frame
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, d4c_threshold=0.85), x_lengths=[len(x)])
+    ap85 = b.d4c(xd, dev(r["t"]), dev(r["f0"])).cpu().numpy()
+    want = oracle.d4c(x, fs, r["t"], r["f0"], F, 0.85)
+    np.testing.assert_allclose(ap85, want, atol=AP_TOL, rtol=0)
+    assert not np.array_equal(want, r["ap"])                          # the threshold did skip some frames
+    # the codec at this size
     csp = b.code_spectral_envelope(sp, 60).cpu().numpy()
     ref = oracle.code_spectral_envelope(sp.cpu().numpy(), fs, F, 60)
     np.testing.assert_allclose(csp, ref, atol=1e-11, rtol=0)
