@@ -616,9 +616,6 @@ __global__ __launch_bounds__(256) void d4cb_output_kernel(int fs, D4CTables tab,
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (int64_t)gridDim.x * 4;
   const int out_bins = out_fft / 2 + 1;
   const int n_run = *n_listed;
-  const double bin_hz = (double)fs / out_fft;
-  const double last_w = fs / 2.0 - tab.nap * kFreqInterval;
-  const double inv_last = 1.0 / last_w;
   for (int64_t k = wave; k < total_frames; k += waves) {
     const int frame = perm[k];
     double* row = ap + frame * (int64_t)out_bins;
@@ -627,17 +624,8 @@ __global__ __launch_bounds__(256) void d4cb_output_kernel(int fs, D4CTables tab,
       continue;
     }
     const double* cz = COARSE + (int64_t)frame * 8;
-    for (int i = lane; i < out_bins; i += 64) {
-      const double f = (double)i * bin_hz;
-      int kk = (int)(f * (1.0 / kFreqInterval));
-      kk = kk > tab.nap ? tab.nap : kk;
-      const double x0 = kk * kFreqInterval;
-      const double sfr = (f - x0) * (kk == tab.nap ? inv_last : 1.0 / kFreqInterval);
-      const double y0 = kk == 0 ? -60.0 : cz[kk - 1];
-      const double y1 = kk == tab.nap ? -kSafe : cz[kk];
-      const double yi = y0 + sfr * (y1 - y0);
-      row[i] = exp(yi * (2.302585092994045684 / 20.0));          // 10^(yi/20), d4c.cpp:331-332
-    }
+    d4c_write_row([&](int k) { return k == 0 ? -60.0 : (k > tab.nap ? -kSafe : cz[k - 1]); }, tab.nap, fs, out_fft, out_bins,
+                  lane, row);
   }
 }
 
