@@ -3,9 +3,10 @@
 // Replaces decimate / FilterForDecimate (externs/WORLD_v2/src/matlabfunctions.cpp:27-125, 184-210):
 // reflect-pad by 9 samples, run the IIR forward, reverse, run it again, reverse, keep every r-th
 // sample.  The recursion is sequential in the reference; here each thread runs it over its own
-// 256-sample chunk after a 512-sample warm-up from zero state.  The filters' largest pole radius is
-// 0.89 (r = 12), so the warm-up state differs from the sequential one by < 1e-26 relative and the
-// outputs round to the same doubles.  FMA contraction is off to keep the reference's operation order.
+// 256-sample chunk after a warm-up from zero state whose length follows the filter's largest pole radius
+// (0.66 at r = 2, 0.80 at r = 6, 0.89 at r = 12: 160 ... 512 samples), so that the warm-up state differs from
+// the sequential one by < 1e-26 relative and the outputs round to the same doubles.  FMA contraction is off
+// to keep the reference's operation order.
 #pragma once
 #include "common.hpp"
 
@@ -14,6 +15,7 @@ namespace wm {
 struct DecMeta {
   int r;                       // decimation ratio 2..12
   int lag;                     // edge padding applied before decimating (Harvest, harvest.cpp:50-59); 0 for DIO
+  int warm;                    // warm-up samples in front of a chunk: radius^warm < 1e-26
   double a0, a1, a2, b0, b1;   // matlabfunctions.cpp:29-113
 };
 
@@ -47,6 +49,9 @@ static const double kDecimateB[13][2] = {
 inline DecMeta make_dec_meta(int r, int lag) {
   DecMeta d;
   d.r = r; d.lag = lag;
+  // largest pole radius of z^3 - a0 z^2 - a1 z - a2 by ratio: 0.657 0.686 0.731 0.769 0.799 0.822 0.841 0.857 0.869 0.880 0.889
+  static const int kWarm[13] = {0, 0, 160, 176, 208, 256, 288, 336, 384, 432, 464, 512, 512};
+  d.warm = kWarm[r];
   d.a0 = kDecimateA[r][0]; d.a1 = kDecimateA[r][1]; d.a2 = kDecimateA[r][2];
   d.b0 = kDecimateB[r][0]; d.b1 = kDecimateB[r][1];
   return d;
@@ -56,14 +61,8 @@ __device__ __forceinline__ double hv_nx(const double* __restrict__ x, int n, int
   // new_x of GetWaveformAndSpectrumSub (harvest.cpp:55-59): x edge-padded by lag samples
   return x[imin(n - 1, imax(0, j - lag))];
 }
-__device__ __forceinline__ double hv_dec_in(const double* __restrict__ x, int n, int lag, int nn, int i) {
-  // tmp1 of decimate (matlabfunctions.cpp:189-192): new_x reflect-padded by 9 samples
-  if (i < 9) return 2 * hv_nx(x, n, lag, 0) - hv_nx(x, n, lag, 9 - i);
-  if (i >= 9 + nn) return 2 * hv_nx(x, n, lag, nn - 1) - hv_nx(x, n, lag, nn - 2 - (i - (9 + nn)));
-  return hv_nx(x, n, lag, i - 9);
-}
-
-constexpr int kDecChunk = 256, kDecWarm = 512;
+constexpr int kDecChunk = 256;
+constexpr int kDecBlk = 16;     // samples fetched per trip to memory: the recursion is the chain, the loads must not be on it
 
 // pass 1: tmp2[i] = IIR(tmp1)[i]
 static __global__ __launch_bounds__(64) void decim_fwd_kernel(const double* __restrict__ x,
@@ -79,13 +78,29 @@ static __global__ __launch_bounds__(64) void decim_fwd_kernel(const double* __re
   const double* xu = x + x_off[u];
   double* out = tmp + toff[u];
   double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  const int start = imax(0, c0 - kDecWarm);
+  const int start = imax(0, c0 - m.warm);
   const int end = imin(len, c0 + kDecChunk);
-  for (int i = start; i < end; ++i) {
-    const double wt = hv_dec_in(xu, n, m.lag, nn, i) + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
-    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
-    w2 = w1; w1 = w0; w0 = wt;
-    if (i >= c0) out[i] = o;
+  // tmp1 of decimate (matlabfunctions.cpp:189-192): new_x reflect-padded by 9 samples, 2 edge - mirrored inside the pads
+  const double e_lo = hv_nx(xu, n, m.lag, 0), e_hi = hv_nx(xu, n, m.lag, nn - 1);
+  for (int i0 = start; i0 < end; i0 += kDecBlk) {
+    double v[kDecBlk];
+#pragma unroll
+    for (int r = 0; r < kDecBlk; ++r) {                          // sixteen independent loads, then the chain
+      const int i = imin(i0 + r, len - 1);
+      const int j = i < 9 ? 9 - i : (i >= 9 + nn ? nn - 2 - (i - (9 + nn)) : i - 9);
+      v[r] = hv_nx(xu, n, m.lag, j);
+    }
+#pragma unroll
+    for (int r = 0; r < kDecBlk; ++r) {
+      const int i = i0 + r;
+      if (i < end) {
+        const double in = i < 9 ? 2 * e_lo - v[r] : (i >= 9 + nn ? 2 * e_hi - v[r] : v[r]);
+        const double wt = in + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
+        const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
+        w2 = w1; w1 = w0; w0 = wt;
+        if (i >= c0) out[i] = o;
+      }
+    }
   }
 }
 
@@ -108,18 +123,31 @@ static __global__ __launch_bounds__(64) void decim_bwd_kernel(const int* __restr
   const int nbeg = m.r - m.r * nout + nn;
   const int shift = m.lag / m.r;
   double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  const int start = imax(0, c0 - kDecWarm);
+  const int start = imax(0, c0 - m.warm);
   const int end = imin(len, c0 + kDecChunk);
-  for (int i = start; i < end; ++i) {
-    const double wt = in[len - 1 - i] + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
-    const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
-    w2 = w1; w1 = w0; w0 = wt;
-    if (i >= c0) {
-      const int j = len - 1 - i;                 // index in the final (re-reversed) array
-      const int q = j - 8 - nbeg;                // = c * r
-      if (q >= 0 && q % m.r == 0 && q + nbeg < nn + 9) {
-        const int c = q / m.r - shift;
-        if (c >= 0 && c < ylen) yu[c] = o;
+  // sample i lands at j = len - 1 - i of the re-reversed array, which is output c = (j - 8 - nbeg) / r when that
+  // divides: q = j - 8 - nbeg falls by one per step, so its remainder and quotient are counted down, not divided out
+  int q = len - 1 - start - 8 - nbeg;
+  int ph = q % m.r;
+  if (ph < 0) ph += m.r;
+  int cq = (q - ph) / m.r;                                       // floor(q / r)
+  for (int i0 = start; i0 < end; i0 += kDecBlk) {
+    double v[kDecBlk];
+#pragma unroll
+    for (int r = 0; r < kDecBlk; ++r) v[r] = in[len - 1 - imin(i0 + r, len - 1)];
+#pragma unroll
+    for (int r = 0; r < kDecBlk; ++r) {
+      const int i = i0 + r;
+      if (i < end) {
+        const double wt = v[r] + m.a0 * w0 + m.a1 * w1 + m.a2 * w2;
+        const double o = m.b0 * wt + m.b1 * w0 + m.b1 * w1 + m.b0 * w2;
+        w2 = w1; w1 = w0; w0 = wt;
+        if (i >= c0 && ph == 0 && q >= 0 && q + nbeg < nn + 9) {
+          const int c = cq - shift;
+          if (c >= 0 && c < ylen) yu[c] = o;
+        }
+        --q;
+        if (ph == 0) { ph = m.r - 1; --cq; } else { --ph; }
       }
     }
   }

@@ -249,15 +249,15 @@ __global__ __launch_bounds__(256) void dio_band_compact_kernel(
     const int* __restrict__ ylen_a, DioMeta meta, int tiles_max, const int* __restrict__ tile_cnt,
     const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ ev_off,
     double* __restrict__ events) {
-  const int u = blockIdx.z, band = blockIdx.y, tile = blockIdx.x;
+  __shared__ int lds_off[4 * (kZcCompactTiles + 1)];
+  const int u = blockIdx.y, band = blockIdx.x;
   const int ylen = ylen_a[u];
   const int nt = dio_tiles(ylen, meta.step);
-  if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
-  const int* off = tile_cnt + (((int64_t)u * meta.nb + band) * (tiles_max + 1) + tile) * 4;
-  zc_compact_tile(slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, tile, off, off + 4,
-                  events + ev_off[u] + (int64_t)band * 4 * cap, cap);
+  zc_compact_signal(slots + slot_off[u] + (int64_t)band * 4 * slot_cap, slot_cap, nt,
+                    tile_cnt + ((int64_t)u * meta.nb + band) * (tiles_max + 1) * 4,
+                    events + ev_off[u] + (int64_t)band * 4 * cap, cap, lds_off);
 }
 
 __global__ __launch_bounds__(256) void dio_candidate_kernel(
@@ -721,7 +721,7 @@ int launch_dio(Batch& b, const double* d_x, double* d_t, double* d_f0) {
                          b.d_dio_slot_off, b.d_dio_slots);
     hipLaunchKernelGGL(dio_band_scan_kernel, dim3(m.nb, b.n_utt), dim3(64), 0, st, b.d_dio_ylen, m, tiles_max,
                        b.d_dio_tile_cnt, b.d_dio_ev_cnt);
-    hipLaunchKernelGGL(dio_band_compact_kernel, dim3(tiles_max, m.nb, b.n_utt), dim3(256), 0, st, b.d_dio_ylen, m,
+    hipLaunchKernelGGL(dio_band_compact_kernel, dim3(m.nb, b.n_utt), dim3(256), 0, st, b.d_dio_ylen, m,
                        tiles_max, b.d_dio_tile_cnt, b.d_dio_slot_off, b.d_dio_slots, b.d_dio_ev_off,
                        b.d_dio_events);
   }

@@ -194,15 +194,15 @@ __global__ __launch_bounds__(256) void hv_band_compact_kernel(
     const int* __restrict__ ylen_a, int nch, int step, int tiles_max, const int* __restrict__ tile_cnt,
     const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ evoff,
     double* __restrict__ events) {
-  const int u = blockIdx.z, ch = blockIdx.y, tile = blockIdx.x;
+  __shared__ int lds_off[4 * (kZcCompactTiles + 1)];
+  const int u = blockIdx.y, ch = blockIdx.x;
   const int ylen = ylen_a[u];
   const int nt = hv_tiles(ylen, step);
-  if (tile >= nt) return;
   const int cap = ylen / 2 + 2;
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
-  const int* off = tile_cnt + (((int64_t)u * nch + ch) * (tiles_max + 1) + tile) * 4;
-  zc_compact_tile(slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, tile, off, off + 4,
-                  events + evoff[u] + (int64_t)ch * 4 * cap, cap);
+  zc_compact_signal(slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, nt,
+                    tile_cnt + ((int64_t)u * nch + ch) * (tiles_max + 1) * 4, events + evoff[u] + (int64_t)ch * 4 * cap, cap,
+                    lds_off);
 }
 
 // raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
@@ -630,9 +630,11 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const int* __restrict__ 
   }
 }
 
-// RemoveUnreliableCandidates (harvest.cpp:652-688): one thread per (frame, slot); neighbours are
-// read from the unmodified table.  Rows 0 and T-1 of the reference's scratch are uninitialised
-// memory; they read as zero here.
+// RemoveUnreliableCandidates (harvest.cpp:652-688): half a wavefront per frame, a lane per slot (the occupied slots
+// are the first ncand1 * 7 of the row's maxc = 105: a thread per (frame, slot of the full row) left three threads in
+// four without work); neighbours are read from the unmodified table.  Rows 0 and T-1 of the reference's scratch are
+// uninitialised memory; they read as zero here.
+constexpr int kRmFrames = 8;       // frames per workgroup
 __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ bframe_utt,
                                                         const int64_t* __restrict__ boff,
                                                         const int* __restrict__ nb1_a, HvMeta m,
@@ -640,52 +642,49 @@ __global__ __launch_bounds__(256) void hv_remove_kernel(const int* __restrict__ 
                                                         const double* __restrict__ rc,
                                                         const double* __restrict__ rs, int64_t tot_b,
                                                         double* __restrict__ rc2, double* __restrict__ rs2) {
-  // The 256 (frame, slot) items of a workgroup cover 256 / maxc frames; every item compares its candidate with all
-  // candidates of the two neighbouring frames, so the rows of those frames (and one frame either side) are staged
-  // in LDS once instead of being fetched by every item (2 maxc loads each, all served by L1 but one at a time).
-  extern __shared__ double rows[];                              // [(frames of the group + 2)][maxc]
-  const int64_t id0 = (int64_t)blockIdx.x * 256;
-  const int64_t fr_lo = id0 / m.maxc;
-  int64_t fr_hi = (id0 + 255) / m.maxc;
+  // Every item compares its candidate with all candidates of the two neighbouring frames, so the rows of the
+  // workgroup's frames (and one frame either side) are staged in LDS once instead of being fetched by every item.
+  extern __shared__ double rows[];                              // [kRmFrames + 2][maxc]
+  const int64_t fr_lo = (int64_t)blockIdx.x * kRmFrames;
+  int64_t fr_hi = fr_lo + kRmFrames - 1;
   if (fr_hi > tot_b - 1) fr_hi = tot_b - 1;
   const int64_t st_lo = fr_lo > 0 ? fr_lo - 1 : 0, st_hi = fr_hi + 1 < tot_b ? fr_hi + 1 : tot_b - 1;
   const int n_stage = (int)((st_hi - st_lo + 1) * m.maxc);
   for (int i = threadIdx.x; i < n_stage; i += 256) rows[i] = rc[st_lo * m.maxc + i];
   __syncthreads();
-  const int64_t id = id0 + threadIdx.x;
-  const int64_t fr = id / m.maxc;
-  const int s = (int)(id - fr * m.maxc);
+  const int64_t fr = fr_lo + (threadIdx.x >> 5);
   if (fr >= tot_b) return;
   const int u = bframe_utt[fr];
   const int nc = ncand1_a[u] * kHvOverlap;
-  if (s >= nc) return;
   const int k = (int)(fr - boff[u]);
   const int nb1 = nb1_a[u];
-  double c = rows[(fr - st_lo) * m.maxc + s], sc = rs[fr * m.maxc + s];
-  if (k >= 1 && k < nb1 - 1 && c != 0) {
-    // SelectBestF0 with allowed_range 1.0 on both neighbours (:652-688) only keeps the smaller relative
-    // error: min over q of fl(|c - v_q| / c), capped at 1.  Correctly rounded division by c > 0 is
-    // monotone, so that is fl(min |c - v_q| / c) -- one division instead of one per candidate.
-    double dmin = HUGE_VAL;
+  for (int s = threadIdx.x & 31; s < nc; s += 32) {
+    double c = rows[(fr - st_lo) * m.maxc + s], sc = rs[fr * m.maxc + s];
+    if (k >= 1 && k < nb1 - 1 && c != 0) {
+      // SelectBestF0 with allowed_range 1.0 on both neighbours (:652-688) only keeps the smaller relative
+      // error: min over q of fl(|c - v_q| / c), capped at 1.  Correctly rounded division by c > 0 is
+      // monotone, so that is fl(min |c - v_q| / c) -- one division instead of one per candidate.
+      double dmin = HUGE_VAL;
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const int nk = side == 0 ? k + 1 : k - 1;
-      const bool zero_row = nk == 0 || nk == nb1 - 1;
-      const double* row = rows + (fr + (side == 0 ? 1 : -1) - st_lo) * m.maxc;
-      for (int q0 = 0; q0 < nc; q0 += 8) {
-        double v[8];
+      for (int side = 0; side < 2; ++side) {
+        const int nk = side == 0 ? k + 1 : k - 1;
+        const bool zero_row = nk == 0 || nk == nb1 - 1;
+        const double* row = rows + (fr + (side == 0 ? 1 : -1) - st_lo) * m.maxc;
+        for (int q0 = 0; q0 < nc; q0 += 8) {
+          double v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = zero_row ? 0.0 : row[imin(nc - 1, q0 + r)];
+          for (int r = 0; r < 8; ++r) v[r] = zero_row ? 0.0 : row[imin(nc - 1, q0 + r)];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) dmin = fmin(dmin, fabs(c - v[r]));
+          for (int r = 0; r < 8; ++r) dmin = fmin(dmin, fabs(c - v[r]));
+        }
       }
+      const double er = dmin / c;
+      const double me = er > 1.0 ? 1.0 : er;
+      if (!(me <= 0.05)) { c = 0; sc = 0; }
     }
-    const double er = dmin / c;
-    const double me = er > 1.0 ? 1.0 : er;
-    if (!(me <= 0.05)) { c = 0; sc = 0; }
+    rc2[fr * m.maxc + s] = c;
+    rs2[fr * m.maxc + s] = sc;
   }
-  rc2[fr * m.maxc + s] = c;
-  rs2[fr * m.maxc + s] = sc;
 }
 
 // SearchF0Base (harvest.cpp:693-705) and FixStep1 (:710-722, allowed 0.008) for every basic frame of the batch:
@@ -937,6 +936,82 @@ constexpr int kSmLag = 300;      // SmoothF0Contour lag (harvest.cpp:1085)
 constexpr int kSmPar = 32;       // sections filtered concurrently
 constexpr int kSmTail = 320;     // frames beyond a section over which the smoothing filter settles (0.875^320 = 3e-19)
 
+// One pass of FilteringF0's second-order recursion (harvest.cpp:1057-1062)
+//     wt[i] = x[i] + a0 wt[i-1] + a1 wt[i-2],   y[i] = b0 wt[i] + b1 wt[i-1] + b0 wt[i-2]
+// over n samples by ONE WAVEFRONT, 64 * kIirB samples per trip: lane l owns kIirB consecutive samples, runs them from
+// a zero state, the block-end states are chained over the lanes by a scan of the affine maps s -> M s + e (M, the
+// block's transition matrix, is the same for every lane, so the scan needs M^(2^d) only), and every lane then adds
+// the response of its true incoming state, p[k] s1 + q[k] s2.  A thread per section walking its samples one by one
+// -- every step a trip to memory for the input and one for the intermediate array -- took 1.35 ms for the longest
+// utterance of configs[2], two thirds of the contour kernel.  The filter's poles have radius 0.875: the blocked form
+// is as stable as the sequential one; results differ from it by rounding.
+constexpr int kIirB = 16;
+struct IirBlock {
+  double a0, a1, b0, b1;
+  double p[kIirB], q[kIirB];     // wt[k] of a block for the incoming states (1, 0) and (0, 1), zero input
+  double mp[6][4];               // M^(2^d), row-major, M = [[p[B-1], q[B-1]], [p[B-2], q[B-2]]]
+  double ml[4];                  // M^lane
+  __device__ __forceinline__ void init(double fa0, double fa1, double fb0, double fb1, int lane) {
+    a0 = fa0; a1 = fa1; b0 = fb0; b1 = fb1;
+    double u1 = 1.0, u2 = 0.0, v1 = 0.0, v2 = 1.0;
+#pragma unroll
+    for (int k = 0; k < kIirB; ++k) {
+      const double pu = a0 * u1 + a1 * u2, qv = a0 * v1 + a1 * v2;
+      p[k] = pu; q[k] = qv;
+      u2 = u1; u1 = pu; v2 = v1; v1 = qv;
+    }
+    mp[0][0] = p[kIirB - 1]; mp[0][1] = q[kIirB - 1]; mp[0][2] = p[kIirB - 2]; mp[0][3] = q[kIirB - 2];
+#pragma unroll
+    for (int d = 1; d < 6; ++d) {
+      const double* m = mp[d - 1];
+      mp[d][0] = m[0] * m[0] + m[1] * m[2]; mp[d][1] = m[0] * m[1] + m[1] * m[3];
+      mp[d][2] = m[2] * m[0] + m[3] * m[2]; mp[d][3] = m[2] * m[1] + m[3] * m[3];
+    }
+    ml[0] = 1.0; ml[1] = 0.0; ml[2] = 0.0; ml[3] = 1.0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      if ((lane >> d) & 1) {
+        const double* m = mp[d];
+        const double r0 = m[0] * ml[0] + m[1] * ml[2], r1 = m[0] * ml[1] + m[1] * ml[3];
+        const double r2 = m[2] * ml[0] + m[3] * ml[2], r3 = m[2] * ml[1] + m[3] * ml[3];
+        ml[0] = r0; ml[1] = r1; ml[2] = r2; ml[3] = r3;
+      }
+    }
+  }
+  // x[k]: this lane's inputs (zero beyond the end); (s1, s2): the state entering the trip's first sample (uniform).
+  // On exit y[k] are the outputs and (s1, s2) the state after the trip's last sample.
+  __device__ __forceinline__ void trip(const double (&x)[kIirB], double (&y)[kIirB], double& s1, double& s2, int lane) const {
+    double w[kIirB];
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < kIirB; ++k) {
+      const double wt = x[k] + a0 * a + a1 * b;
+      w[k] = wt;
+      b = a; a = wt;
+    }
+    double g1 = a, g2 = b;                                        // e = zero-state end of the block
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      double t1 = __shfl_up(g1, 1 << d, 64), t2 = __shfl_up(g2, 1 << d, 64);
+      if (lane < (1 << d)) { t1 = 0.0; t2 = 0.0; }
+      g1 += mp[d][0] * t1 + mp[d][1] * t2;
+      g2 += mp[d][2] * t1 + mp[d][3] * t2;
+    }
+    double f1 = __shfl_up(g1, 1, 64), f2 = __shfl_up(g2, 1, 64);
+    if (lane == 0) { f1 = 0.0; f2 = 0.0; }
+    const double i1 = ml[0] * s1 + ml[1] * s2 + f1, i2 = ml[2] * s1 + ml[3] * s2 + f2;   // state entering this lane's block
+    double m1 = i1, m2 = i2;
+#pragma unroll
+    for (int k = 0; k < kIirB; ++k) {
+      const double wt = w[k] + p[k] * i1 + q[k] * i2;
+      y[k] = b0 * wt + b1 * m1 + b0 * m2;
+      m2 = m1; m1 = wt;
+    }
+    s1 = __shfl(m1, 63, 64);
+    s2 = __shfl(m2, 63, 64);
+  }
+};
+
 __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     const int64_t* __restrict__ boff, const int* __restrict__ nb1_a, HvMeta m, const int* __restrict__ ncand1_a,
     const double* __restrict__ rc2, const double* __restrict__ rs2, int64_t tot_b, int n_utt,
@@ -1109,67 +1184,62 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     if (tid == 0) sh_n = cnt / 2;
   }
   __syncthreads();
-  // FilteringF0 (:1049-1074) per section, kSmPar sections at a time, one thread each.  The reference runs both
-  // passes of the zero-lag filter over the whole padded contour; outside [st, ed] the input is constant (x[st]
-  // before, x[ed] after, :1054-1055) for at least the 300 frames of padding, and the filter's poles have radius
-  // 0.875 (0.875^300 = 4e-18): at st the forward pass is in its steady state for the constant x[st], and the
-  // backward pass, which only has to deliver [st, ed], is in its steady state kSmTail frames beyond ed.  Both
-  // passes therefore run over [st, ed + kSmTail] from those states -- a few hundred steps per section instead of
-  // two times the utterance.
+  // FilteringF0 (:1049-1074) per section, a wavefront each.  The reference runs both passes of the zero-lag filter
+  // over the whole padded contour; outside [st, ed] the input is constant (x[st] before, x[ed] after, :1054-1055) for
+  // at least the 300 frames of padding, and the filter's poles have radius 0.875 (0.875^300 = 4e-18): at st the
+  // forward pass is in its steady state for the constant x[st], and the backward pass, which only has to deliver
+  // [st, ed], is in its steady state kSmTail frames beyond ed.  Both passes therefore run over [st, ed + kSmTail]
+  // from those states, 1024 samples per trip of the wavefront (IirBlock).
   {
     const int nsec = sh_n;
     const int nn = nf + 2 * kSmLag;
     const double fb0 = 0.0078202080334971724, fb1 = 0.015640416066994345;
     const double fa0 = 1.7347257688092754, fa1 = -0.76600660094326412;
     const double dc = 1.0 - fa0 - fa1;                                // w = x / dc for a constant input x
-    double* sm = smbuf + smoff[u];
-    for (int base = 0; base < nsec; base += kSmPar) {
-      const int sidx = base + threadIdx.x;
-      if (threadIdx.x < kSmPar && sidx < nsec) {
-#pragma clang fp contract(off)
-        const int st = bl[sidx * 2], ed = bl[sidx * 2 + 1];          // padded coordinates
-        const int last = imin(nn - 1, ed + kSmTail);
-        double* tmp = sm + (int64_t)threadIdx.x * nn;                 // forward output at padded position st + q
-        const double xe = best[ed - kSmLag];
-        // Both passes are strictly sequential recurrences; what can be taken off the chain is the
-        // memory traffic: inputs are fetched 16 steps at a time (independent loads, one round trip per
-        // block instead of one per step) and results are stored without waiting.
-        constexpr int kBlk = 16;
-        double w0 = best[st - kSmLag] / dc, w1 = w0;
-        for (int i0 = st; i0 <= last; i0 += kBlk) {
-          double xin[kBlk];
+    IirBlock f;
+    f.init(fa0, fa1, fb0, fb1, lane);
+    double* tmp = smbuf + smoff[u] + (int64_t)wv * nn;                // forward output at padded position st + q
+    for (int sidx = wv; sidx < nsec; sidx += kCtWaves) {
+      const int st = bl[sidx * 2], ed = bl[sidx * 2 + 1];            // padded coordinates
+      const int last = imin(nn - 1, ed + kSmTail);
+      const int n = last - st + 1;
+      const double xe = best[ed - kSmLag];
+      double s1 = best[st - kSmLag] / dc, s2 = s1;
+      for (int t0 = 0; t0 < n; t0 += 64 * kIirB) {
+        double x[kIirB], y[kIirB];
 #pragma unroll
-          for (int r = 0; r < kBlk; ++r) xin[r] = best[imin(ed, i0 + r) - kSmLag];
-#pragma unroll
-          for (int r = 0; r < kBlk; ++r) {
-            const int i = i0 + r;
-            if (i <= last) {
-              const double xi = i > ed ? xe : xin[r];
-              const double wt = xi + fa0 * w0 + fa1 * w1;
-              tmp[i - st] = fb0 * wt + fb1 * w0 + fb0 * w1;
-              w1 = w0; w0 = wt;
-            }
-          }
+        for (int k = 0; k < kIirB; ++k) {
+          const int i = st + t0 + kIirB * lane + k;
+          const double v = best[imin(ed, i) - kSmLag];
+          x[k] = i > last ? 0.0 : (i > ed ? xe : v);
         }
-        __threadfence_block();                                    // the second pass reads what the first wrote
-        w0 = w1 = tmp[last - st] / dc;
-        for (int i0 = last; i0 >= st; i0 -= kBlk) {
-          double tin[kBlk];
+        f.trip(x, y, s1, s2, lane);
 #pragma unroll
-          for (int r = 0; r < kBlk; ++r) tin[r] = tmp[imax(st, i0 - r) - st];
-#pragma unroll
-          for (int r = 0; r < kBlk; ++r) {
-            const int i = i0 - r;
-            if (i >= st) {
-              const double wt = tin[r] + fa0 * w0 + fa1 * w1;
-              const double o = fb0 * wt + fb1 * w0 + fb0 * w1;
-              w1 = w0; w0 = wt;
-              if (i <= ed) smooth[i - kSmLag] = o;
-            }
-          }
+        for (int k = 0; k < kIirB; ++k) {
+          const int q = t0 + kIirB * lane + k;
+          if (q < n) tmp[q] = y[k];
         }
       }
-      __syncthreads();
+      // the wave's own stores are visible to its own loads (same wavefront: in order through the same L1 / L2 path)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // backward: position r counts down from `last`; the state there is the steady state of the forward output
+      s1 = s2 = tmp[n - 1] / dc;
+      for (int t0 = 0; t0 < n; t0 += 64 * kIirB) {
+        double x[kIirB], y[kIirB];
+#pragma unroll
+        for (int k = 0; k < kIirB; ++k) {
+          const int r = t0 + kIirB * lane + k;                        // steps back from `last`
+          x[k] = r < n ? tmp[imax(0, n - 1 - r)] : 0.0;
+        }
+        f.trip(x, y, s1, s2, lane);
+#pragma unroll
+        for (int k = 0; k < kIirB; ++k) {
+          const int r = t0 + kIirB * lane + k;
+          const int i = last - r;
+          if (r < n && i <= ed) smooth[i - kSmLag] = y[k];
+        }
+      }
     }
   }
   __syncthreads();
@@ -1385,7 +1455,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     }
     hipLaunchKernelGGL(hv_band_scan_kernel, dim3(m.nch, n_utt), dim3(64), 0, st, W.d_ylen, m.nch, m.step, W.tiles_max,
                        W.d_tile_cnt, W.d_evcnt);
-    hipLaunchKernelGGL(hv_band_compact_kernel, dim3(W.tiles_max, m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
+    hipLaunchKernelGGL(hv_band_compact_kernel, dim3(m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
                        m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
   }
   {
@@ -1416,10 +1486,9 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   }
   {
     TimedScope ts_(b.ctx, "hv_remove_kernel");
-    const int64_t items = W.tot_b * m.maxc;
-    const size_t lds_rm = sizeof(double) * (size_t)((256 / m.maxc + 4) * m.maxc);
-    hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), lds_rm, st, W.d_bframe_utt,
-                       W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc, W.d_rs, W.tot_b, W.d_rc2, W.d_rs2);
+    const size_t lds_rm = sizeof(double) * (size_t)((kRmFrames + 2) * m.maxc);
+    hipLaunchKernelGGL(hv_remove_kernel, dim3((unsigned)((W.tot_b + kRmFrames - 1) / kRmFrames)), dim3(256), lds_rm, st,
+                       W.d_bframe_utt, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc, W.d_rs, W.tot_b, W.d_rc2, W.d_rs2);
   }
   {
     TimedScope ts_(b.ctx, "hv_contour_kernel");

@@ -9,7 +9,7 @@
 //   filter_tile_events   filter the tile, write its events (in order) into the tile's own slot of a
 //                        staging array and its four counts
 //   zc_scan_tiles        per-tile counts -> exclusive offsets, list lengths
-//   zc_compact_tile      move the tile's events from the slot to offset + rank of the ordered lists
+//   zc_compact_signal    move the events from the tiles' slots to offset + rank of the ordered lists
 // Only actual events travel twice; the FIR runs once.
 #pragma once
 #include "common.hpp"
@@ -221,18 +221,33 @@ __device__ __forceinline__ void zc_scan_tiles(int* __restrict__ tile_cnt, int nt
   }
 }
 
-// move one tile's staged events to their place in the ordered lists: off4 / end4 are the tile's and
-// the next tile's entries of the scanned offsets
-__device__ __forceinline__ void zc_compact_tile(const double* __restrict__ slot, int64_t slot_cap, int tile,
-                                                const int* __restrict__ off4, const int* __restrict__ end4,
-                                                double* __restrict__ ev, int cap) {
-#pragma unroll
+// Move a signal's staged events to their places in the ordered lists, by one workgroup: its scanned offsets (4 * (ntiles + 1) ints, layout [tile][kind]) go to
+// LDS once (`lds_off`, kZcCompactTiles + 1 tiles at most; longer signals search the offsets in memory), then every
+// thread takes places of the ordered lists, finds the tile a place belongs to by bisection of the offsets and
+// fetches the event from that tile's slot.  One workgroup per (tile, signal) -- a handful of events each, 1.6 M
+// workgroups on configs[2] -- cost more in dispatch than the copies themselves.
+constexpr int kZcCompactTiles = 1023;
+__device__ __forceinline__ void zc_compact_signal(const double* __restrict__ slot, int64_t slot_cap, int ntiles,
+                                                  const int* __restrict__ off, double* __restrict__ ev, int cap,
+                                                  int* lds_off) {
+  const bool staged = ntiles <= kZcCompactTiles;
+  if (staged)
+    for (int i = threadIdx.x; i < 4 * (ntiles + 1); i += blockDim.x) lds_off[i] = off[i];
+  __syncthreads();
+  const int* o4 = staged ? lds_off : off;
+#pragma unroll 1
   for (int ty = 0; ty < 4; ++ty) {
-    const int off = off4[ty];
-    const int n = end4[ty] - off;
-    const double* src = slot + (int64_t)ty * slot_cap + (int64_t)tile * kZcSlot;
-    for (int j = threadIdx.x; j < n; j += blockDim.x)
-      if (off + j < cap) ev[(int64_t)ty * cap + off + j] = src[j];
+    const int total = imin(o4[4 * ntiles + ty], cap);
+    const double* src = slot + (int64_t)ty * slot_cap;
+    double* dst = ev + (int64_t)ty * cap;
+    for (int o = threadIdx.x; o < total; o += blockDim.x) {
+      int lo = 0, hi = ntiles;                                    // last tile whose offset is <= o
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (o4[4 * mid + ty] <= o) lo = mid; else hi = mid;
+      }
+      dst[o] = src[(int64_t)lo * kZcSlot + (o - o4[4 * lo + ty])];
+    }
   }
 }
 
