@@ -73,6 +73,7 @@ struct HarvestWs {
   double* d_work = nullptr;                    // [8][tot_b] contour work arrays
   int* d_bl = nullptr;                         // [2][tot_b + 8 n_utt] boundary lists
   double* d_md = nullptr;                      // banded multi-channel contours
+  double* d_mds = nullptr;                     // their search scores
   int* d_sec = nullptr;                        // [3][tot_b/4 ...] section descriptors (lo, hi, off)
   double* d_sm = nullptr;                      // smoothing scratch
   cpx* d_twid = nullptr;                       // [kHvTwid] exp(-2 pi i k / kHvTwid), the refinement's twiddles
@@ -909,25 +910,58 @@ __device__ __forceinline__ int hv_extend_f0_wave(int origin, int last_point, int
 __device__ __forceinline__ double hv_search_score_row(double f0, const double* __restrict__ c,
                                                       const double* __restrict__ sc, int n) {
   double score = 0.0;
-  for (int i0 = 0; i0 < n; i0 += 8) {
-    double cv[8], sv[8];
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    double cv[16], sv[16];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { const int i = imin(n - 1, i0 + r); cv[r] = c[i]; sv[r] = sc[i]; }
+    for (int r = 0; r < 16; ++r) { const int i = imin(n - 1, i0 + r); cv[r] = c[i]; sv[r] = sc[i]; }
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < 16; ++r)
       if (i0 + r < n && f0 == cv[r] && score < sv[r]) score = sv[r];
   }
   return score;
 }
 
-// x += v[0] + v[1] + ... + v[n-1] in exactly that order, the values read 64 at a time by the lanes of
-// a wavefront (uniform result; adding 0.0 for the lanes beyond n is exact)
-template <class F>
-__device__ __forceinline__ double hv_seq_sum_wave(double x, F value, int n, int lane) {
+// Ordering of one wavefront's own LDS traffic inside a workgroup of SEVERAL wavefronts (wave_sync() is a workgroup
+// barrier there): LDS operations of a wave complete in issue order, so a write is seen by the wave's later reads
+// once the compiler keeps them apart and the write has left the queue.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// x += v[0] + v[1] + ... + v[n-1] in exactly that order (adding 0.0 for the places beyond n is exact), the same on
+// every lane: 64 values at a time are parked in the wave's LDS row `row` and read back by all lanes at uniform
+// addresses, sixteen reads in flight ahead of the sixteen dependent additions (a shuffle per addend put an LDS
+// round trip on the chain for every element).  Two sums at once share the trips: their chains interleave.
+template <class F, class G>
+__device__ __forceinline__ void hv_seq_sum2_wave(double& x, double& y, F value_x, G value_y, int n, int lane, double* row) {
   for (int j0 = 0; j0 < n; j0 += 64) {
-    const double v = (j0 + lane < n) ? value(j0 + lane) : 0.0;
+    const bool in = j0 + lane < n;
+    row[lane] = in ? value_x(j0 + lane) : 0.0;
+    row[64 + lane] = in ? value_y(j0 + lane) : 0.0;
+    wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 64; ++r) x += __shfl(v, r, 64);
+    for (int g = 0; g < 4; ++g) {
+      double a[16], b[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[q] = row[16 * g + q]; b[q] = row[64 + 16 * g + q]; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { x += a[q]; y += b[q]; }
+    }
+    wave_lds_fence();
+  }
+}
+template <class F>
+__device__ __forceinline__ double hv_seq_sum_wave(double x, F value, int n, int lane, double* row) {
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    row[lane] = (j0 + lane < n) ? value(j0 + lane) : 0.0;
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double a[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q] = row[16 * g + q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x += a[q];
+    }
+    wave_lds_fence();
   }
   return x;
 }
@@ -1016,7 +1050,7 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     const int64_t* __restrict__ boff, const int* __restrict__ nb1_a, HvMeta m, const int* __restrict__ ncand1_a,
     const double* __restrict__ rc2, const double* __restrict__ rs2, int64_t tot_b, int n_utt,
     double* __restrict__ work, int* __restrict__ blist, const int64_t* __restrict__ mdoff, double* __restrict__ mdata,
-    int* __restrict__ secd, const int64_t* __restrict__ smoff, double* __restrict__ smbuf,
+    double* __restrict__ mscore, int* __restrict__ secd, const int64_t* __restrict__ smoff, double* __restrict__ smbuf,
     const int64_t* __restrict__ f_off, double frame_period, double* __restrict__ t_out, double* __restrict__ f0_out) {
   const int u = blockIdx.x;
   const int nf = nb1_a[u];
@@ -1031,6 +1065,7 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
   int* bl = blist + (b0 + 8 * u);
   int* bl2 = blist + (tot_b + 8 * (int64_t)n_utt) + (b0 + 8 * u);      // up to nf + 600 boundaries? (<= nf+8 used)
   double* md = mdata + mdoff[u];
+  double* mds = mscore + mdoff[u];           // SearchScore (:901-907) of every entry of md, filled once after Extend
   // section descriptors: lo[], hi[], off[] (as int offsets relative to md)
   const int sec_cap = nf / 4 + 8;
   int* s_lo = secd + 3 * (b0 / 4 + 8 * (int64_t)u);
@@ -1042,6 +1077,7 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
   // ---- from here on all threads run with uniform control flow; bulk loops are thread-parallel,
   // decisions are recomputed by every thread from values in memory, single writers are thread 0 ----
   __shared__ int sh4[kCtWaves];
+  __shared__ double sh_row[kCtWaves][128];          // per wave: the parked addends of hv_seq_sum_wave
   __shared__ int sh_key[2048], sh_ord[2048];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
@@ -1081,6 +1117,24 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     if (lane == 0) { bl[i * 2 + 1] = e1; bl[i * 2] = e0; }
   }
   __syncthreads();
+  // SearchScore (:901-907) of every entry of the extended rows, all at once: MergeF0Sub (:912-932) sums these over the
+  // overlap of two contours, and looking them up merge by merge (two candidate rows per frame, a barrier either
+  // side) was most of the merging.  c1 is free from here on and carries the scores of the merged contour c2.
+  {
+    // flattened over the entries of all rows (a loop over the sections with a row per trip left most threads idle and
+    // paid a trip to memory per section): entry e belongs to the last section whose offset is <= e
+    const int total = nsec > 0 ? s_of[nsec - 1] + (s_hi[nsec - 1] - s_lo[nsec - 1] + 1) : 0;
+    for (int e = tid; e < total; e += kCtThreads) {
+      int lo_i = 0, hi_i = nsec;
+      while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (s_of[mid] <= e) lo_i = mid; else hi_i = mid;
+      }
+      const int j = s_lo[lo_i] + (e - s_of[lo_i]);
+      mds[e] = hv_search_score_row(md[e], cd.c + (int64_t)j * cd.stride, cd.s + (int64_t)j * cd.stride, nc);
+    }
+  }
+  __syncthreads();
   // ExtendSub :840-856: the running mean is NOT reset between sections (quirk), so the sections are
   // walked in order on wave 0 and every sum keeps the reference's sequential association
   if (wv == 0) {
@@ -1089,7 +1143,7 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     for (int i = 0; i < nsec; ++i) {
       HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
       const int st = bl[i * 2], ed = bl[i * 2 + 1];
-      mean_f0 = hv_seq_sum_wave(mean_f0, [&](int q) { return hv_get(md, sc, st + q); }, ed - st, lane);
+      mean_f0 = hv_seq_sum_wave(mean_f0, [&](int q) { return hv_get(md, sc, st + q); }, ed - st, lane, sh_row[wv]);
       mean_f0 /= ed - st;
       if (2200.0 / mean_f0 < ed - st) {                            // Swap :826-838
         if (lane == 0 && nchn != i) {
@@ -1128,7 +1182,7 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
     __syncthreads();
     {
       HvSec s0; s0.lo = s_lo[0]; s0.hi = s_hi[0]; s0.off = s_of[0];
-      for (int i = tid; i < nf; i += kCtThreads) c2[i] = hv_get(md, s0, i);
+      for (int i = tid; i < nf; i += kCtThreads) { c2[i] = hv_get(md, s0, i); c1[i] = hv_get(mds, s0, i); }
     }
     // boundary_list[0], [1] of the reference double as the running start / end of the merged contour
     int run_st = bl[0], run_ed = bl[1];
@@ -1138,25 +1192,19 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
       HvSec so; so.lo = s_lo[o]; so.hi = s_hi[o]; so.off = s_of[o];
       const int st2 = o == 0 ? run_st : bl[o * 2], ed2 = o == 0 ? run_ed : bl[o * 2 + 1];
       if (st2 - run_ed > 0) {
-        for (int j = st2 + tid; j <= ed2; j += kCtThreads) c2[j] = hv_get(md, so, j);
+        for (int j = st2 + tid; j <= ed2; j += kCtThreads) { c2[j] = hv_get(md, so, j); c1[j] = hv_get(mds, so, j); }
         run_st = st2;
         run_ed = ed2;
       } else {                                                     // MergeF0Sub :912-932
         const int st1 = run_st, ed1 = run_ed;
         if (!(st1 <= st2 && ed1 >= ed2)) {
-          // per-frame scores in parallel (c1 / best are free here), then the two sums in frame order
-          for (int k = st2 + tid; k <= ed1; k += kCtThreads) {
-            const double* cr = cd.c + (int64_t)k * cd.stride;
-            const double* sr = cd.s + (int64_t)k * cd.stride;
-            c1[k] = hv_search_score_row(c2[k], cr, sr, nc);
-            best[k] = hv_search_score_row(hv_get(md, so, k), cr, sr, nc);
-          }
-          __syncthreads();
-          const double sc1 = hv_seq_sum_wave(0.0, [&](int q) { return c1[st2 + q]; }, ed1 - st2 + 1, lane);
-          const double sc2 = hv_seq_sum_wave(0.0, [&](int q) { return best[st2 + q]; }, ed1 - st2 + 1, lane);
-          __syncthreads();
-          if (sc1 > sc2) { for (int k = ed1 + tid; k <= ed2; k += kCtThreads) c2[k] = hv_get(md, so, k); }
-          else { for (int k = st2 + tid; k <= ed2; k += kCtThreads) c2[k] = hv_get(md, so, k); }
+          // the two sums of scores over the overlap, in frame order (every wave computes them: uniform result)
+          double sc1 = 0.0, sc2 = 0.0;
+          hv_seq_sum2_wave(sc1, sc2, [&](int q) { return c1[st2 + q]; }, [&](int q) { return hv_get(mds, so, st2 + q); },
+                           ed1 - st2 + 1, lane, sh_row[wv]);
+          __syncthreads();                                         // every wave has read c1 before it is overwritten
+          const int from = sc1 > sc2 ? ed1 : st2;
+          for (int k = from + tid; k <= ed2; k += kCtThreads) { c2[k] = hv_get(md, so, k); c1[k] = hv_get(mds, so, k); }
           run_ed = ed2;
         }
       }
@@ -1374,6 +1422,7 @@ static int hv_setup(Batch& b) {
   al((void**)&W->d_work, sizeof(double) * 4 * (size_t)W->tot_b);
   al((void**)&W->d_bl, sizeof(int) * 2 * ((size_t)W->tot_b + 8 * (size_t)n_utt));
   al((void**)&W->d_md, sizeof(double) * (size_t)W->tot_md);
+  al((void**)&W->d_mds, sizeof(double) * (size_t)W->tot_md);
   al((void**)&W->d_sec, sizeof(int) * 3 * ((size_t)W->tot_b / 4 + 8 * (size_t)n_utt + 8));
   al((void**)&W->d_sm, sizeof(double) * (size_t)W->tot_sm);
   al((void**)&W->d_twid, sizeof(cpx) * (size_t)kHvTwid);
@@ -1495,7 +1544,7 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     hipLaunchKernelGGL(hv_base_kernel, dim3((unsigned)((W.tot_b + 255) / 256)), dim3(256), 0, st, W.d_bframe_utt, W.d_boff, m,
                        W.d_ncand1, W.d_rc2, W.d_rs2, W.tot_b, W.d_work, W.d_work + W.tot_b, W.d_work + 3 * W.tot_b);
     hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(kCtThreads), 0, st, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc2,
-                       W.d_rs2, W.tot_b, n_utt, W.d_work, W.d_bl, W.d_mdoff, W.d_md, W.d_sec, W.d_smoff, W.d_sm,
+                       W.d_rs2, W.tot_b, n_utt, W.d_work, W.d_bl, W.d_mdoff, W.d_md, W.d_mds, W.d_sec, W.d_smoff, W.d_sm,
                        b.d_f_off, b.p.frame_period, d_t, d_f0);
   }
   return wm_check(hipGetLastError());
