@@ -177,6 +177,26 @@ __device__ __forceinline__ int wave_scan_incl_i(int v, int /*lane*/ = 0) {
   return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_scan_incl_i(v), 63); }
+// maximum of unsigned values over the wave (lanes without a DPP source contribute 0)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  auto mx = [](unsigned a, int b) { const unsigned ub = (unsigned)b; return a > ub ? a : ub; };
+  v = mx(v, dpp_get_i<0x111, 0xf, 0xf>((int)v));
+  v = mx(v, dpp_get_i<0x112, 0xf, 0xf>((int)v));
+  v = mx(v, dpp_get_i<0x114, 0xf, 0xf>((int)v));
+  v = mx(v, dpp_get_i<0x118, 0xf, 0xf>((int)v));
+  v = mx(v, dpp_get_i<0x142, 0xa, 0xf>((int)v));
+  v = mx(v, dpp_get_i<0x143, 0xc, 0xf>((int)v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// exact minimum of NON-NEGATIVE doubles over the wave (+inf for lanes that have none): the bit patterns of
+// non-negative doubles order like the values, so the minimum is the maximum of the inverted patterns, high word
+// first, then the low word among the lanes that hold that high word
+__device__ __forceinline__ double wave_min_nonneg(double e) {
+  const unsigned hi = ~(unsigned)__double2hiint(e), lo = ~(unsigned)__double2loint(e);
+  const unsigned hi_max = wave_max_u32(hi);
+  const unsigned lo_max = wave_max_u32(hi == hi_max ? lo : 0u);
+  return __hiloint2double((int)~hi_max, (int)~lo_max);
+}
 
 // interp1Q on an LDS array (matlabfunctions.cpp:220-241): y has n entries,
 // delta_y[n-1] := 0.

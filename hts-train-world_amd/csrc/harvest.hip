@@ -695,17 +695,16 @@ __global__ __launch_bounds__(256) void hv_base_kernel(const int* __restrict__ bf
                                                       HvMeta m, const int* __restrict__ ncand1_a,
                                                       const double* __restrict__ rc2, const double* __restrict__ rs2,
                                                       int64_t tot_b, double* __restrict__ c1, double* __restrict__ c2,
-                                                      double* __restrict__ sm) {
-  __shared__ double bs_[258];
+                                                      double* __restrict__ bscore, double* __restrict__ sm) {
+  __shared__ double bs_[258], bsc_[258];
   const int64_t fr0 = (int64_t)blockIdx.x * 256;
   for (int e = threadIdx.x; e < 258; e += 256) {
     const int64_t fr = fr0 - 2 + e;
-    double bv = 0.0;
+    double bv = 0.0, bsc = 0.0;
     if (fr >= 0 && fr < tot_b) {
       const int nc = ncand1_a[bframe_utt[fr]] * kHvOverlap;
       const double* cr = rc2 + fr * m.maxc;
       const double* sr = rs2 + fr * m.maxc;
-      double bsc = 0.0;
       for (int j0 = 0; j0 < nc; j0 += 8) {
         double cv[8], sv[8];
 #pragma unroll
@@ -716,6 +715,7 @@ __global__ __launch_bounds__(256) void hv_base_kernel(const int* __restrict__ bf
       }
     }
     bs_[e] = bv;
+    bsc_[e] = bsc;
   }
   __syncthreads();
   const int64_t fr = fr0 + threadIdx.x;
@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void hv_base_kernel(const int* __restrict__ bf
   }
   c1[fr] = b0;
   c2[fr] = v;
+  bscore[fr] = bsc_[threadIdx.x + 2];        // SearchScore of the base value: it is the best score of its frame
   sm[fr] = 0.0;
 }
 
@@ -838,39 +839,63 @@ __device__ __forceinline__ int hv_boundaries_wg(F voiced, int n, int* __restrict
 
 // SelectBestF0 (harvest.cpp:783-797) with the candidates of the row spread over the lanes of a wave.
 // The sequential rule "skip if e > best_e, else take" keeps the LAST candidate among those of minimal
-// error (<= allowed).  cv[q] is this lane's candidate lane + 64 q (nc <= 64 * kSelPer).
+// error (<= allowed).  cv[q] / sv[q] are this lane's candidate lane + 64 q and its score (nc <= 64 * kSelPer).
+// Also returns, in `score`, SearchScore (:901-907) of the value selected: the largest score among the candidates
+// equal to it.  Reductions on DPP steps and ballots, no LDS crossbar (two shuffled reductions and three shuffles
+// per step were 0.8 us of a step that ExtendF0 repeats up to 200 times per section).
 constexpr int kSelPer = 3;
-__device__ __forceinline__ double hv_select_wave(double ref, const double (&cv)[kSelPer], int nc, double allowed,
-                                                 int lane) {
+__device__ __forceinline__ double hv_select_wave(double ref, const double (&cv)[kSelPer], const double (&sv)[kSelPer],
+                                                 int nc, double allowed, int lane, double& score) {
   double be = HUGE_VAL;
-  int bi = -1;
+  double eq[kSelPer];
+  bool any_nan = false;
 #pragma unroll
   for (int q = 0; q < kSelPer; ++q) {
-    if (lane + 64 * q < nc) {
-      const double e = fabs(ref - cv[q]) / ref;
-      if (!(e > allowed) && !(e > be)) { be = e; bi = lane + 64 * q; }
+    eq[q] = HUGE_VAL;
+    if (64 * q < nc) {                                     // wave-uniform
+      bool is_nan = false;
+      if (lane + 64 * q < nc) {
+        const double e = fabs(ref - cv[q]) / ref;
+        is_nan = e != e;
+        if (e <= allowed) eq[q] = e;
+      }
+      any_nan = any_nan || __ballot(is_nan) != 0ull;
+      be = fmin(be, eq[q]);
     }
   }
-  double mn = be;
+  const double mn = wave_min_nonneg(be);
+  score = 0.0;
+  int pick = -1;
+  if (any_nan) {
+    // a NaN error is taken by the sequential rule (`tmp > best` is false) and then so is everything after it: the
+    // last candidate of the row comes out (non-finite samples only)
+    pick = nc - 1;
+  } else {
+    if (!(mn <= allowed)) return 0.0;                      // nobody within the allowed range
 #pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) mn = fmin(mn, __shfl_xor(mn, sh, 64));
-  int pick = (bi >= 0 && be == mn) ? bi : -1;
-#pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) pick = max(pick, __shfl_xor(pick, sh, 64));
-  if (pick < 0) return 0.0;
+    for (int q = kSelPer - 1; q >= 0; --q) {
+      if (pick < 0 && 64 * q < nc) {
+        const unsigned long long b = __ballot(eq[q] == mn);
+        if (b) pick = 64 * q + 63 - __clzll((long long)b);
+      }
+    }
+  }
   double out = 0.0;
 #pragma unroll
-  for (int q = 0; q < kSelPer; ++q) {
-    const double a = __shfl(cv[q], pick & 63, 64);
-    if ((pick >> 6) == q) out = a;
-  }
+  for (int q = 0; q < kSelPer; ++q)
+    if ((pick >> 6) == q) out = readlane_d(cv[q], pick & 63);     // pick is wave-uniform
+  double sc = 0.0;
+#pragma unroll
+  for (int q = 0; q < kSelPer; ++q)
+    if (64 * q < nc) sc = fmax(sc, (lane + 64 * q < nc && cv[q] == out) ? sv[q] : 0.0);
+  score = wave_max(sc);
   return out;
 }
 
 // ExtendF0 (harvest.cpp:791-820) on one wavefront: uniform control flow, candidates over lanes, the
-// row of the next step requested while the current one is evaluated.
+// rows of the next step requested while the current one is evaluated.  The score of every value set goes to mds.
 __device__ __forceinline__ int hv_extend_f0_wave(int origin, int last_point, int shift, const HvCand& cd,
-                                                 double allowed, double* md, const HvSec& sec, int lane) {
+                                                 double allowed, double* md, double* mds, const HvSec& sec, int lane) {
   double tmp_f0 = hv_get(md, sec, origin);
   int shifted_origin = origin;
   const int distance = last_point > origin ? last_point - origin : origin - last_point;
@@ -878,22 +903,23 @@ __device__ __forceinline__ int hv_extend_f0_wave(int origin, int last_point, int
   int li[kSelPer];
 #pragma unroll
   for (int q = 0; q < kSelPer; ++q) li[q] = lane + 64 * q < cd.nc ? lane + 64 * q : 0;
-  const double* row = cd.c + (int64_t)(origin + shift) * cd.stride;
-  double nx[kSelPer];
+  const int64_t r0 = (int64_t)(origin + shift) * cd.stride;
+  double nx[kSelPer], ns[kSelPer];
 #pragma unroll
-  for (int q = 0; q < kSelPer; ++q) nx[q] = row[li[q]];
+  for (int q = 0; q < kSelPer; ++q) { nx[q] = cd.c[r0 + li[q]]; ns[q] = cd.s[r0 + li[q]]; }
   for (int i = 0; i <= distance; ++i) {
     const int idx = origin + shift * i;
-    double cur[kSelPer];
+    double cur[kSelPer], cus[kSelPer];
 #pragma unroll
-    for (int q = 0; q < kSelPer; ++q) cur[q] = nx[q];
-    if (i < distance) {                                  // next step's row
-      const double* nrow = cd.c + (int64_t)(idx + 2 * shift) * cd.stride;
+    for (int q = 0; q < kSelPer; ++q) { cur[q] = nx[q]; cus[q] = ns[q]; }
+    if (i < distance) {                                  // next step's rows
+      const int64_t rn = (int64_t)(idx + 2 * shift) * cd.stride;
 #pragma unroll
-      for (int q = 0; q < kSelPer; ++q) nx[q] = nrow[li[q]];
+      for (int q = 0; q < kSelPer; ++q) { nx[q] = cd.c[rn + li[q]]; ns[q] = cd.s[rn + li[q]]; }
     }
-    const double v = hv_select_wave(tmp_f0, cur, cd.nc, allowed, lane);
-    if (lane == 0) hv_set(md, sec, idx + shift, v);
+    double sc;
+    const double v = hv_select_wave(tmp_f0, cur, cus, cd.nc, allowed, lane, sc);
+    if (lane == 0) { hv_set(md, sec, idx + shift, v); hv_set(mds, sec, idx + shift, sc); }
     if (v == 0.0) {
       count++;
     } else {
@@ -1105,36 +1131,25 @@ __global__ __launch_bounds__(kCtThreads) void hv_contour_kernel(
   __syncthreads();
   for (int i = 0; i < nsec; ++i) {
     const int lo = s_lo[i], hi = s_hi[i], of = s_of[i], v0 = bl[i * 2], v1 = bl[i * 2 + 1];
-    for (int j = lo + tid; j <= hi; j += kCtThreads) md[of + (j - lo)] = (j >= v0 && j <= v1) ? c1[j] : 0.0;
+    for (int j = lo + tid; j <= hi; j += kCtThreads) {
+      const double v = (j >= v0 && j <= v1) ? c1[j] : 0.0;
+      md[of + (j - lo)] = v;
+      mds[of + (j - lo)] = v != 0.0 ? best[j] : 0.0;       // `best` holds the base scores until FixStep4 (hv_base_kernel)
+    }
   }
   __syncthreads();
   // Extend :861-878 (in place): a section only touches its own row, so sections go to the four waves
   for (int i = wv; i < nsec; i += kCtWaves) {
     HvSec sc; sc.lo = s_lo[i]; sc.hi = s_hi[i]; sc.off = s_of[i];
     const int o1 = bl[i * 2 + 1], o0 = bl[i * 2];
-    const int e1 = hv_extend_f0_wave(o1, imin(nf - 2, o1 + 100), 1, cd, 0.18, md, sc, lane);
-    const int e0 = hv_extend_f0_wave(o0, imax(1, o0 - 100), -1, cd, 0.18, md, sc, lane);
+    const int e1 = hv_extend_f0_wave(o1, imin(nf - 2, o1 + 100), 1, cd, 0.18, md, mds, sc, lane);
+    const int e0 = hv_extend_f0_wave(o0, imax(1, o0 - 100), -1, cd, 0.18, md, mds, sc, lane);
     if (lane == 0) { bl[i * 2 + 1] = e1; bl[i * 2] = e0; }
   }
   __syncthreads();
-  // SearchScore (:901-907) of every entry of the extended rows, all at once: MergeF0Sub (:912-932) sums these over the
-  // overlap of two contours, and looking them up merge by merge (two candidate rows per frame, a barrier either
-  // side) was most of the merging.  c1 is free from here on and carries the scores of the merged contour c2.
-  {
-    // flattened over the entries of all rows (a loop over the sections with a row per trip left most threads idle and
-    // paid a trip to memory per section): entry e belongs to the last section whose offset is <= e
-    const int total = nsec > 0 ? s_of[nsec - 1] + (s_hi[nsec - 1] - s_lo[nsec - 1] + 1) : 0;
-    for (int e = tid; e < total; e += kCtThreads) {
-      int lo_i = 0, hi_i = nsec;
-      while (hi_i - lo_i > 1) {
-        const int mid = (lo_i + hi_i) >> 1;
-        if (s_of[mid] <= e) lo_i = mid; else hi_i = mid;
-      }
-      const int j = s_lo[lo_i] + (e - s_of[lo_i]);
-      mds[e] = hv_search_score_row(md[e], cd.c + (int64_t)j * cd.stride, cd.s + (int64_t)j * cd.stride, nc);
-    }
-  }
-  __syncthreads();
+  // mds holds SearchScore (:901-907) of every entry of the rows by now (the base contour's from hv_base_kernel, the
+  // extensions' from the selection itself): MergeF0Sub (:912-932) only sums them.  c1 is free from here on and carries
+  // the scores of the merged contour c2.
   // ExtendSub :840-856: the running mean is NOT reset between sections (quirk), so the sections are
   // walked in order on wave 0 and every sum keeps the reference's sequential association
   if (wv == 0) {
@@ -1542,7 +1557,8 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
   {
     TimedScope ts_(b.ctx, "hv_contour_kernel");
     hipLaunchKernelGGL(hv_base_kernel, dim3((unsigned)((W.tot_b + 255) / 256)), dim3(256), 0, st, W.d_bframe_utt, W.d_boff, m,
-                       W.d_ncand1, W.d_rc2, W.d_rs2, W.tot_b, W.d_work, W.d_work + W.tot_b, W.d_work + 3 * W.tot_b);
+                       W.d_ncand1, W.d_rc2, W.d_rs2, W.tot_b, W.d_work, W.d_work + W.tot_b, W.d_work + 2 * W.tot_b,
+                       W.d_work + 3 * W.tot_b);
     hipLaunchKernelGGL(hv_contour_kernel, dim3(n_utt), dim3(kCtThreads), 0, st, W.d_boff, W.d_nb1, m, W.d_ncand1, W.d_rc2,
                        W.d_rs2, W.tot_b, n_utt, W.d_work, W.d_bl, W.d_mdoff, W.d_md, W.d_mds, W.d_sec, W.d_smoff, W.d_sm,
                        b.d_f_off, b.p.frame_period, d_t, d_f0);
