@@ -81,6 +81,16 @@ __device__ __forceinline__ double uniform_d(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// Four consecutive doubles from an address that is only 8-byte aligned, as two 16-byte loads (global_load_dwordx4 takes
+// any dword-aligned address).  For kernels in which every LANE streams through its own run of samples: a load
+// instruction then costs a tag lookup per lane whatever its width, so the wider load halves the lookups per sample.
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void load4_a8(const double* __restrict__ p, double (&v)[4]) {
+  const double2_a8 a = *reinterpret_cast<const double2_a8*>(p);
+  const double2_a8 b = *reinterpret_cast<const double2_a8*>(p + 2);
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
 // ---- wavefront collectives (64 lanes) ----------------------------------------
 // Built on DPP row shifts / row broadcasts (gfx9 family) instead of ds_bpermute shuffles: six
 // dependent VALU steps with no LDS round trip.  The six steps are a complete inclusive scan over

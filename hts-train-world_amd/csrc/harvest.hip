@@ -577,8 +577,13 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const int* __restrict__ 
     // does not depend on which other refinements share its wavefront
     for (int i0 = 0; i0 < L; i0 += 4) {
       double xv[4];
+      const int r0 = basic + i0 - 1;
+      if (r0 >= 0 && r0 + 3 < ylen) {                               // four consecutive samples inside the signal
+        load4_a8(ys + r0, xv);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xv[q] = ys[imax(0, imin(ylen - 1, basic + i0 + q - 1))];   // :481-484
+        for (int q = 0; q < 4; ++q) xv[q] = ys[imax(0, imin(ylen - 1, r0 + q))];   // :481-484
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = i0 + q;
