@@ -157,10 +157,13 @@ def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ct
                     f0o, spo, apo = f0.float(), sp.float(), ap.float()                      # :360-390
                 f0h, sph, aph = (v.cpu().numpy() for v in (f0o, spo, apo))
                 fo = b.frame_offsets
+                items = []                     # row slices of contiguous slabs: contiguous themselves
                 for k, i in enumerate(group):
                     a, e = fo[k], fo[k + 1]
-                    for path, arr in zip(jobs[i][1:], (f0h[a:e], sph[a:e], aph[a:e])):
-                        writes.append(pool.submit(np.ascontiguousarray(arr).tofile, path))
+                    items.extend(zip(jobs[i][1:], (f0h[a:e], sph[a:e], aph[a:e])))
+                # the batch's files in ONE native call (WorldMi355WriteFiles: plain threads, no interpreter lock),
+                # beside the next batch's decoding and analysis; the slabs live on in the job's arguments
+                writes.append(pool.submit(W.write_files, items, io_threads))
                 done += int(b.total_frames)
                 b.close()
         for w_ in writes:

@@ -183,6 +183,23 @@ def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
 
 
 @pytest.mark.gpu
+def test_headline_line_at_two_ranks_carries_the_gather():
+    """`bench.py --gpus 2` on the headline workload (two gloo ranks sharing the box's GPU): one line from rank 0, weak
+    scaling over both ranks' frames, and `with_gather` -- the same step followed by the gather-v of the float32 slabs to
+    rank 0 -- under the same timing contract."""
+    lines = _bench("--gpus", 2, "--backend", "gloo", "--utts", 6, "--dur", 0.5, 1.2, "--steps", 2, "--warmup", 1,
+                   "--prewarm", 0, "--no-cpu-baseline", "--no-side", "--workers", 1)
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["scaling"] == "weak" and ln["config"]["utterances_per_gpu"] == 6
+    wg = ln["with_gather"]
+    assert wg["value"] > 0 and wg["ms_per_step"] >= ln["ms_per_step"] * 0.5
+    frames = ln["config"]["frames_per_gpu"]
+    assert wg["gathered_bytes_per_step"] == 4 * frames * (1 + 2 * 513)      # one peer's f0 + sp + ap, float32
+    assert ln["roofline"]["kernel"] == "d4c_kernel" and ln["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
 def test_recipe_gather_mode_writes_the_same_files(tmp_path):
     """recipe.analysis_files(gather=True) on one rank = the plain driver (same files)."""
     from test_cli_relink import write_wav as write_wav_py
