@@ -9,6 +9,7 @@
 // table lookup at a per-frame offset computed by cheaptrick_offsets_kernel.
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "fft.hpp"
 #include "frame.hpp"
 #include "partition.hpp"
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
 #pragma unroll
       for (int m = 0; m <= M; ++m) {
         const int i = lane + 64 * m;
-        const double val = log(pw[imin(i, H)] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
+        const double val = wm_log(pw[imin(i, H)] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
         if (m < M || lane == 0) pw[i] = val;
         __builtin_amdgcn_sched_barrier(0);                        // one bin at a time: keeps the register peak low
       }
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int i0 = 2 * (lane + 64 * m);
-      if (i0 <= H) row[i0] = exp(v[m].x);
-      if (i0 + 1 <= H) row[i0 + 1] = exp(v[m].y);
+      if (i0 <= H) row[i0] = wm_exp(v[m].x);
+      if (i0 + 1 <= H) row[i0 + 1] = wm_exp(v[m].y);
     }
     wave_sync();
   }

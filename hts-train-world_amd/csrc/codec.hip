@@ -23,6 +23,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "fft.hpp"
 #include "window.hpp"
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64) void codec_code_sp_kernel(const double* __restr
       for (int m = 0; m <= M; ++m) {
         double v = rv[m] * o.pre_scale;
         if (o.zero_value != 0.0 && v == 0.0) v = o.zero_value;
-        const double lv = log(v);
+        const double lv = wm_log(v);
         if (m < M || lane == 0) ls[lane + 64 * m] = lv;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64) void codec_decode_sp_kernel(const IN* __restric
       for (int q = 0; q <= M; ++q) {
         const int b = lane + 64 * q;
         const double y0 = knots[kk[q] - 1];
-        const double e = exp((y0 + sf[q] * (knots[kk[q]] - y0)) * inv_md);
+        const double e = wm_exp((y0 + sf[q] * (knots[kk[q]] - y0)) * inv_md);
         if (q < M || lane == 0) orow[b] = o.post_div != 0.0 ? e / o.post_div : e;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void codec_decode_ap_kernel(const double* __re
   const double y0 = k - 1 == 0 ? -60.0 : c[k - 2];
   const double y1 = k == nap + 1 ? -kSafe : c[k - 1];
   const double s = (f - x0) / (x1 - x0);
-  ap[idx] = exp((y0 + s * (y1 - y0)) * (2.302585092994045684 / 20.0));   // 10^(x/20), codec.cpp:52-53
+  ap[idx] = wm_exp((y0 + s * (y1 - y0)) * (2.302585092994045684 / 20.0));   // 10^(x/20), codec.cpp:52-53
 }
 
 // lf0 = log f0, 0 where unvoiced (analysis.cpp:216-224), as float32

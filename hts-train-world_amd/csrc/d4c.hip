@@ -28,6 +28,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "fft.hpp"
 #include "frame.hpp"
 #include "partition.hpp"
@@ -279,10 +280,10 @@ __device__ __forceinline__ void d4c_write_row(Knot kv, int nap, int fs, int out_
       const double inv_w = kk == nap ? inv_last : 1.0 / kFreqInterval;
       const double y0 = kv(kk), y1 = kv(kk + 1);
       slope = inv_w * (y1 - y0);
-      cur = exp((y0 + (f - x0) * slope) * ln10_20);
+      cur = wm_exp((y0 + (f - x0) * slope) * ln10_20);
     } else {
       if (!have_ratio) {                                         // second bin in the segment: the step of 64 bins
-        ratio64 = exp(64.0 * bin_hz * slope * ln10_20);
+        ratio64 = wm_exp(64.0 * bin_hz * slope * ln10_20);
         have_ratio = true;
       }
       cur *= ratio64;

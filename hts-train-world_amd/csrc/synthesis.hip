@@ -17,6 +17,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "fft.hpp"
 #include "partition.hpp"
 
@@ -346,7 +347,7 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
   for (int m = 0; m <= M; ++m) {
     const int k = m < M ? lane + 64 * m : N;
     const cpx s = img[k];
-    const double amp = exp(s.x / F);                              // :210-218
+    const double amp = wm_exp(s.x / F);                              // :210-218
     double sn, cs;
     sincospi(s.y * (1.0 / (kPi * F)), &sn, &cs);                  // phase in half-turns: no Payne-Hanek path
     mp[m] = make_double2(amp * cs, amp * sn);
@@ -472,10 +473,10 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
       auto log_periodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          ls[lane + 64 * m] = log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+          ls[lane + 64 * m] = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (lane == 0) ls[H] = log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
+        if (lane == 0) ls[H] = wm_log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
       };
       if constexpr (LEAN) {
         double env[MB], rat[MB];
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
           const int k = m < M ? lane + 64 * m : H;
-          const double val = log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
+          const double val = wm_log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
           if (m < M || lane == 0) ls[k] = val;
           __builtin_amdgcn_sched_barrier(0);
         }
