@@ -18,44 +18,81 @@
 
 namespace wm {
 
+// x = m 2^k with m in [0.5, 1), for normal finite x: one instruction each on the device (the library's frexp() adds
+// seventy for the cases excluded here)
+WM_FM_HD double fm_frexp(double x, int* k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *k = __builtin_amdgcn_frexp_exp(x);
+  return __builtin_amdgcn_frexp_mant(x);
+#else
+  return frexp(x, k);
+#endif
+}
+// A coefficient held in scalar registers on the device: as a VOP3 operand it costs the vector ALU nothing, while the
+// compiler's own choice (two v_mov_b32 per 64-bit literal in front of every v_fmac_f64) doubles the vector
+// instructions of a polynomial.
+WM_FM_HD double fm_k(double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(c));
+#endif
+  return c;
+}
+WM_FM_HD double fm_ldexp(double x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ldexp(x, k);
+#else
+  return ldexp(x, k);
+#endif
+}
+
 WM_FM_HD double wm_log(double x) {
   if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
   int k;
-  double m = frexp(x, &k);                          // x = m 2^k, m in [0.5, 1)
+  double m = fm_frexp(x, &k);                       // x = m 2^k, m in [0.5, 1)
   if (m < 0.70710678118654752440) { m += m; --k; }  // m in [sqrt(1/2), sqrt(2))
   const double f = m - 1.0;
+  // s = f / (2 + f): it only scales the small term s (hfsq + R) below, so a reciprocal refined to 1 ulp will do (six
+  // instructions where the IEEE division takes twelve)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double d = 2.0 + f;
+  double rc = __builtin_amdgcn_rcp(d);
+  rc = fma(fma(-d, rc, 1.0), rc, rc);
+  rc = fma(fma(-d, rc, 1.0), rc, rc);
+  const double s = f * rc;
+#else
   const double s = f / (2.0 + f);
+#endif
   const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-                            6.666666666666735130e-01);
+  const double t1 = w * fma(w, fma(w, fm_k(1.531383769920937332e-01), fm_k(2.222219843214978396e-01)), fm_k(3.999999999940941908e-01));
+  const double t2 = z * fma(w, fma(w, fma(w, fm_k(1.479819860511658591e-01), fm_k(1.818357216161805012e-01)),
+                                   fm_k(2.857142874366239149e-01)), fm_k(6.666666666666735130e-01));
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)k;
   // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
-  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  return dk * fm_k(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * fm_k(1.90821492927058770002e-10))) - f);
 }
 
 WM_FM_HD double wm_exp(double x) {
   if (!(x >= -700.0 && x <= 700.0)) return exp(x);
-  const double kd = rint(x * 1.44269504088896338700e+00);
-  double r = fma(-kd, 6.93147180369123816490e-01, x);
-  r = fma(-kd, 1.90821492927058770002e-10, r);      // |r| <= 0.3466
-  double p = 1.6059043836821613e-10;                // 1/13!
-  p = fma(p, r, 2.08767569878681e-09);              // 1/12!
-  p = fma(p, r, 2.505210838544172e-08);             // 1/11!
-  p = fma(p, r, 2.755731922398589e-07);             // 1/10!
-  p = fma(p, r, 2.7557319223985893e-06);            // 1/9!
-  p = fma(p, r, 2.48015873015873e-05);              // 1/8!
-  p = fma(p, r, 1.984126984126984e-04);             // 1/7!
-  p = fma(p, r, 1.388888888888889e-03);             // 1/6!
-  p = fma(p, r, 8.333333333333333e-03);             // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);            // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);            // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)kd);
+  const double kd = rint(x * fm_k(1.44269504088896338700e+00));
+  double r = fma(-kd, fm_k(6.93147180369123816490e-01), x);
+  r = fma(-kd, fm_k(1.90821492927058770002e-10), r);      // |r| <= 0.3466
+  double p = fm_k(1.6059043836821613e-10);                // 1/13!
+  p = fma(p, r, fm_k(2.08767569878681e-09));              // 1/12!
+  p = fma(p, r, fm_k(2.505210838544172e-08));             // 1/11!
+  p = fma(p, r, fm_k(2.755731922398589e-07));             // 1/10!
+  p = fma(p, r, fm_k(2.7557319223985893e-06));            // 1/9!
+  p = fma(p, r, fm_k(2.48015873015873e-05));              // 1/8!
+  p = fma(p, r, fm_k(1.984126984126984e-04));             // 1/7!
+  p = fma(p, r, fm_k(1.388888888888889e-03));             // 1/6!
+  p = fma(p, r, fm_k(8.333333333333333e-03));             // 1/5!
+  p = fma(p, r, fm_k(4.1666666666666664e-02));            // 1/4!
+  p = fma(p, r, fm_k(1.6666666666666666e-01));            // 1/3!
+  p = fma(p, r, fm_k(0.5));
+  p = fma(p, r, fm_k(1.0));
+  p = fma(p, r, fm_k(1.0));
+  return fm_ldexp(p, (int)kd);
 }
 
 }  // namespace wm
