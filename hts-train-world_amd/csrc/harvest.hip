@@ -27,6 +27,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "decimate.hpp"
 #include "fft.hpp"
 #include "fftconv.hpp"
@@ -555,8 +556,8 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const int* __restrict__ 
     const int basic = matlab_round((pos + bt0) * fs + 0.001);   // GetBaseIndex :434-441
     // GetMainWindow :446-456: cos(2 pi tm / wlen) at tm = (basic + i - 1) / fs - pos, advanced by a rotation per sample
     double c, sn, cd, sd;
-    sincospi(2.0 * ((basic - 1.0) * inv_fs - pos) * inv_wlen, &sn, &c);
-    sincospi(2.0 * inv_fs * inv_wlen, &sd, &cd);
+    wm_sincospi(2.0 * ((basic - 1.0) * inv_fs - pos) * inv_wlen, &sn, &c);
+    wm_sincospi(2.0 * inv_fs * inv_wlen, &sd, &cd);
     double coef[6], cw[6], sw[6];
     int bin[6];
 #pragma unroll

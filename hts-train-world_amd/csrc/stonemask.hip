@@ -22,6 +22,7 @@
 // have index[i] = index[0] + i.
 #include "batch.hpp"
 #include "common.hpp"
+#include "fastmath.hpp"
 #include "fft.hpp"
 #include "partition.hpp"
 
@@ -81,8 +82,8 @@ __device__ __forceinline__ void sm_walk(const SmFrame& fr, const int (&bin)[NB],
   // window: cos(2 pi tm / wlen), tm = (index[i] - 1) / fs - pos, advanced by a rotation per sample on regular frames
   double c, sn, cd, sd;
   int r_cur = fr.raw(0);
-  sincospi(2.0 * ((r_cur - 1.0) * fr.inv_fs - fr.pos) * fr.inv_wlen, &sn, &c);
-  sincospi(2.0 * fr.inv_fs * fr.inv_wlen, &sd, &cd);
+  wm_sincospi(2.0 * ((r_cur - 1.0) * fr.inv_fs - fr.pos) * fr.inv_wlen, &sn, &c);
+  wm_sincospi(2.0 * fr.inv_fs * fr.inv_wlen, &sd, &cd);
   double w_prev = 0.0, w_cur = sm_blackman(c);
   const int L = fr.L;
   // a lane leaves the loop after its own window (the wave runs on for the longest one): what a frame returns does

@@ -492,9 +492,13 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
       // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
       // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
       double rc, rs, dc64, ds64;
-      sincos(coef * lane, &rs, &rc);
-      sincos(coef * 64.0, &ds64, &dc64);
-      const double reH = cos(coef * H);
+      // in half-turns (coef / pi = 2 shift fs / F): the argument's own rounding, 1e-16 of up to 2000 half-turns,
+      // moves a phase by 1e-12 rad at most -- the size of the rounding of coef * k itself
+      const double ch = coef * (1.0 / kPi);
+      double snH, reH;
+      wm_sincospi(ch * lane, &rs, &rc);
+      wm_sincospi(ch * 64.0, &ds64, &dc64);
+      wm_sincospi(ch * H, &snH, &reH);
 #pragma unroll
       for (int m = 0; m < MB; ++m) {                                // :88-100
         const int k = m < M ? lane + 64 * m : H;

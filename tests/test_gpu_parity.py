@@ -1018,21 +1018,21 @@ def test_fast_log_exp_against_numpy(gpu):
     torch, W, ctx = gpu
     lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libfastmath_hook.so"))
     vp = C.c_void_p
-    lib.FastmathHook.argtypes = [vp, C.c_int64, vp, vp, vp]
+    lib.FastmathHook.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     rng = np.random.default_rng(11)
     pos = np.exp(rng.uniform(-100.0, 40.0, 400_000)) * rng.uniform(0.5, 2.0, 400_000)      # 1e-44 .. 1e17
     near1 = 1.0 + rng.uniform(-1e-3, 1e-3, 100_000)
-    expo = rng.uniform(-90.0, 40.0, 400_000)
+    expo = np.concatenate([rng.uniform(-90.0, 40.0, 300_000), rng.uniform(-2000.0, 2000.0, 100_000)])
     special = np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 2.2250738585072014e-308,
                         1.7976931348623157e308, 1.0, 709.0, -745.0, 800.0, -800.0, 700.0, -700.0])
     x = np.concatenate([pos, near1, expo, special])
     xd = torch.from_numpy(x).cuda()
-    lg, ex = torch.empty_like(xd), torch.empty_like(xd)
+    lg, ex, sn, cs = (torch.empty_like(xd) for _ in range(4))
     torch.cuda.synchronize()
     rc = lib.FastmathHook(vp(torch.cuda.current_stream().cuda_stream), len(x), vp(xd.data_ptr()), vp(lg.data_ptr()),
-                          vp(ex.data_ptr()))
+                          vp(ex.data_ptr()), vp(sn.data_ptr()), vp(cs.data_ptr()))
     assert rc == 0
-    lg, ex = lg.cpu().numpy(), ex.cpu().numpy()
+    lg, ex, sn, cs = (v.cpu().numpy() for v in (lg, ex, sn, cs))
     with np.errstate(all="ignore"):
         want_l, want_e = np.log(x), np.exp(x)
 
@@ -1041,8 +1041,14 @@ def test_fast_log_exp_against_numpy(gpu):
         return np.abs(got[ok] - want[ok]) / np.spacing(np.abs(want[ok]))
     n1 = len(pos) + len(near1)
     assert ulps(lg[:n1], want_l[:n1]).max() <= 2.0
-    sel = slice(n1, n1 + len(expo))
+    sel = slice(n1, n1 + 300_000)
     assert ulps(ex[sel], want_e[sel]).max() <= 2.0
+    # wm_sincospi on (-2000, 2000) half-turns: the reduction x - 2 round(x / 2) is exact in float64, the rest in
+    # extended precision on the host
+    sel = slice(n1, n1 + len(expo))
+    xr = (x[sel] - 2.0 * np.round(x[sel] / 2.0)).astype(np.longdouble)
+    ws, wc = np.sin(np.pi * xr), np.cos(np.pi * xr)            # np.pi is a double: its 1.2e-16 enters as 4e-17 * |pi x|
+    assert np.abs(sn[sel] - ws.astype(np.float64)).max() < 6e-16 and np.abs(cs[sel] - wc.astype(np.float64)).max() < 6e-16
     # special cases: the library's answers (the same NaNs and infinities, zero for underflow)
     tail = slice(n1 + len(expo), None)
     np.testing.assert_array_equal(np.isnan(lg[tail]), np.isnan(want_l[tail]))
