@@ -51,6 +51,8 @@ struct Context {
   // second stream + events of launch_analyze_synthesize (created on first use)
   hipStream_t side = nullptr;
   hipEvent_t ev_f0 = nullptr, ev_prep = nullptr;
+  hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
+  int ensure_side();                 // the second stream and its events, created on first use
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
   bool timing = false;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> timed;
@@ -187,7 +189,7 @@ struct Batch {
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
   double* d_dc_remover = nullptr;    // [fft_size]
-  int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per response chunk
+  int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per piece (half of the response scratch)
   bool syn_warm = false;                    // launch_analyze_synthesize has run once on this batch
 
   int64_t rng_bound_cheaptrick() const;

@@ -108,6 +108,10 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
   if (c.ev_f0) hipEventDestroy(c.ev_f0);
   if (c.ev_prep) hipEventDestroy(c.ev_prep);
+  for (int h = 0; h < 2; ++h) {
+    if (c.ev_pulse[h]) hipEventDestroy(c.ev_pulse[h]);
+    if (c.ev_ola[h]) hipEventDestroy(c.ev_ola[h]);
+  }
   delete h;
 }
 

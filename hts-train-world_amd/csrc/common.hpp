@@ -54,6 +54,7 @@ __device__ __forceinline__ int64_t xcd_dealt(int64_t round_base, int64_t total) 
 // arithmetic derived from the returned value cannot be hoisted out of the loop and spilled.
 __device__ __forceinline__ int opaque_lane(int lane) {
   asm volatile("" : "+v"(lane));
+  __builtin_assume((unsigned)lane < 64u);     // what the fence hides: predicates such as 2 (lane + 64 m) <= H fold again
   return lane;
 }
 

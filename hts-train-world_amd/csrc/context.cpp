@@ -201,6 +201,18 @@ int Context::ensure_scratch(int64_t doubles) {
   return WM_OK;
 }
 
+int Context::ensure_side() {
+  if (side) return WM_OK;
+  int rc = wm_check(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_f0, hipEventDisableTiming));
+  rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
+  for (int h = 0; h < 2 && !rc; ++h) {
+    rc = wm_check(hipEventCreateWithFlags(&ev_pulse[h], hipEventDisableTiming));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_ola[h], hipEventDisableTiming));
+  }
+  return rc;
+}
+
 // Analysis followed by Synthesis of the same features (BASELINE.json's metric), as one call.  Identical
 // launches and results; the only difference is where the f0-only first part of Synthesis runs: on a second
 // stream, as soon as StoneMask has produced f0, beside CheapTrick and D4C.  Its kernels are latency chains on
@@ -209,17 +221,13 @@ int Context::ensure_scratch(int64_t doubles) {
 int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
                               double* d_y) {
   Context& c = *b.ctx;
-  if (!c.side) {
-    int rc = wm_check(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_f0, hipEventDisableTiming));
-    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_prep, hipEventDisableTiming));
-    if (rc) return rc;
-  }
+  int rc = c.ensure_side();
+  if (rc) return rc;
   // the randn table may be reallocated when it grows: settle its size before two streams read it
   int64_t need = b.rng_bound_cheaptrick();
   if (b.rng_bound_d4c() > need) need = b.rng_bound_d4c();
   if (b.rng_bound_synthesis() > need) need = b.rng_bound_synthesis();
-  int rc = c.ensure_rng(need);
+  rc = c.ensure_rng(need);
   if (!rc && !b.syn_warm) {
     // first use of this batch: Synthesis allocates its work arrays and sizes the response scratch, and a
     // hipMalloc of gigabytes stalls kernels running beside it -- take the plain order once

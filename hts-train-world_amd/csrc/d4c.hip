@@ -26,6 +26,11 @@
 
 #include <type_traits>
 
+// fastmath.hpp's coefficients as plain literals in this file: the D4C kernels already spill scalar registers (frame
+// pipeline, kernel arguments, FFT constants), and every coefficient pinned to a scalar pair came back as a v_readlane
+#ifndef WM_AB
+#define WM_FM_PLAIN 1
+#endif
 #include "batch.hpp"
 #include "common.hpp"
 #include "fastmath.hpp"
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
 #pragma unroll
       for (int m = 0; m < MB; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;
       low = wave_sum(low);
-      double c = 10.0 * log10(low / tot);
+      double c = wm_log(low / tot) * 4.3429448190325182765;   // 10 log10(.)
       c = c + (cf0 - 100.0) / 50.0;                         // d4c.cpp:309-311
       c = 0.0 < c ? 0.0 : c;                                // MyMinDouble(0.0, c), common.h:80: a NaN stays a NaN
 #pragma unroll

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_band_kernel(const 
 #pragma unroll
     for (int m = 0; m < NP; ++m) low += (m >= taken && p[m] >= 0.0) ? p[m] : 0.0;
     low = wave_sum(low);
-    double c = 10.0 * log10(low / tot);
+    double c = wm_log(low / tot) * 4.3429448190325182765;   // 10 log10(.)
     c = c + (cf0 - 100.0) / 50.0;                                 // d4c.cpp:309-311
     c = 0.0 < c ? 0.0 : c;                                        // MyMinDouble(0.0, c)
     if (lane == 0) COARSE[(int64_t)frame * 8 + band] = c;

@@ -32,7 +32,7 @@ WM_FM_HD double fm_frexp(double x, int* k) {
 // compiler's own choice (two v_mov_b32 per 64-bit literal in front of every v_fmac_f64) doubles the vector
 // instructions of a polynomial.
 WM_FM_HD double fm_k(double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WM_FM_PLAIN)
   asm volatile("" : "+s"(c));
 #endif
   return c;
@@ -73,69 +73,101 @@ WM_FM_HD double wm_log(double x) {
   return dk * fm_k(6.93147180369123816490e-01) - ((hfsq - (s * (hfsq + R) + dk * fm_k(1.90821492927058770002e-10))) - f);
 }
 
-WM_FM_HD double wm_exp(double x) {
+// The coefficients of wm_exp as a pack: a loop over bins loads them once (fourteen scalar register pairs) instead of
+// once per call -- the scalar unit issues for all four SIMDs of a CU, so 2 x 14 s_mov per call are not free either.
+struct ExpK {
+  double l2e, ln2h, ln2l, c[11];
+  WM_FM_HD void load() {
+    l2e = fm_k(1.44269504088896338700e+00);
+    ln2h = fm_k(6.93147180369123816490e-01);
+    ln2l = fm_k(1.90821492927058770002e-10);
+    c[0] = fm_k(1.6059043836821613e-10);                  // 1/13!
+    c[1] = fm_k(2.08767569878681e-09);                    // 1/12!
+    c[2] = fm_k(2.505210838544172e-08);                   // 1/11!
+    c[3] = fm_k(2.755731922398589e-07);                   // 1/10!
+    c[4] = fm_k(2.7557319223985893e-06);                  // 1/9!
+    c[5] = fm_k(2.48015873015873e-05);                    // 1/8!
+    c[6] = fm_k(1.984126984126984e-04);                   // 1/7!
+    c[7] = fm_k(1.388888888888889e-03);                   // 1/6!
+    c[8] = fm_k(8.333333333333333e-03);                   // 1/5!
+    c[9] = fm_k(4.1666666666666664e-02);                  // 1/4!
+    c[10] = fm_k(1.6666666666666666e-01);                 // 1/3!
+  }
+};
+WM_FM_HD double wm_exp_k(double x, const ExpK& k) {
   if (!(x >= -700.0 && x <= 700.0)) return exp(x);
-  const double kd = rint(x * fm_k(1.44269504088896338700e+00));
-  double r = fma(-kd, fm_k(6.93147180369123816490e-01), x);
-  r = fma(-kd, fm_k(1.90821492927058770002e-10), r);      // |r| <= 0.3466
-  double p = fm_k(1.6059043836821613e-10);                // 1/13!
-  p = fma(p, r, fm_k(2.08767569878681e-09));              // 1/12!
-  p = fma(p, r, fm_k(2.505210838544172e-08));             // 1/11!
-  p = fma(p, r, fm_k(2.755731922398589e-07));             // 1/10!
-  p = fma(p, r, fm_k(2.7557319223985893e-06));            // 1/9!
-  p = fma(p, r, fm_k(2.48015873015873e-05));              // 1/8!
-  p = fma(p, r, fm_k(1.984126984126984e-04));             // 1/7!
-  p = fma(p, r, fm_k(1.388888888888889e-03));             // 1/6!
-  p = fma(p, r, fm_k(8.333333333333333e-03));             // 1/5!
-  p = fma(p, r, fm_k(4.1666666666666664e-02));            // 1/4!
-  p = fma(p, r, fm_k(1.6666666666666666e-01));            // 1/3!
-  p = fma(p, r, fm_k(0.5));
-  p = fma(p, r, fm_k(1.0));
-  p = fma(p, r, fm_k(1.0));
+  const double kd = rint(x * k.l2e);
+  double r = fma(-kd, k.ln2h, x);
+  r = fma(-kd, k.ln2l, r);                                // |r| <= 0.3466
+  double p = k.c[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 1; i < 11; ++i) p = fma(p, r, k.c[i]);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
   return fm_ldexp(p, (int)kd);
+}
+WM_FM_HD double wm_exp(double x) {
+  ExpK k;
+  k.load();
+  return wm_exp_k(x, k);
 }
 
 // sin(pi x) and cos(pi x) (the library's sincospi() is 71 vector instructions; this one is about 30): x is split into
 // a count n of quarter turns and r = x - n / 2, |r| <= 1/4 (exact), both functions are Taylor polynomials in r with the
 // coefficients pi^k / k! (their tails at |r| = 1/4: 5e-17 and 2e-18), the quadrant swaps and negates.  Within 1.5 ulp
-// for |x| < 2^40 (tests/hooks, fastmath_check); larger, infinite and NaN arguments go to the library.
-WM_FM_HD void wm_sincospi(double x, double* sn, double* cs) {
-  if (!(fabs(x) < 1.0e12)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    sincospi(x, sn, cs);
-#else
-    *sn = sin(3.14159265358979323846 * x);
-    *cs = cos(3.14159265358979323846 * x);
-#endif
-    return;
+// (tests/hooks, fastmath_check).  No branch and no call: from 2^53 on every double is an even integer (sin 0, cos 1),
+// the quadrant n mod 4 is taken in floating point (exact for any n), infinities and NaN come out as NaN.
+struct SinCosPiK {
+  double s[9], c[8];
+  WM_FM_HD void load() {
+    s[0] = fm_k(7.952054001475513e-07);
+    s[1] = fm_k(-2.1915353447830217e-05);
+    s[2] = fm_k(0.00046630280576761255);
+    s[3] = fm_k(-0.0073704309457143504);
+    s[4] = fm_k(0.08214588661112823);
+    s[5] = fm_k(-0.5992645293207921);
+    s[6] = fm_k(2.5501640398773455);
+    s[7] = fm_k(-5.16771278004997);
+    s[8] = fm_k(3.141592653589793);
+    c[0] = fm_k(4.303069587032947e-06);
+    c[1] = fm_k(-0.0001046381049248457);
+    c[2] = fm_k(0.0019295743094039231);
+    c[3] = fm_k(-0.02580689139001406);
+    c[4] = fm_k(0.2353306303588932);
+    c[5] = fm_k(-1.3352627688545895);
+    c[6] = fm_k(4.0587121264167685);
+    c[7] = fm_k(-4.934802200544679);
   }
+};
+WM_FM_HD void wm_sincospi_k(double x, const SinCosPiK& k, double* sn, double* cs) {
+  x = fabs(x) < 9007199254740992.0 ? x : x * 0.0;
   const double n = rint(x + x);
   const double r = fma(-0.5, n, x);
   const double z = r * r;
-  double ps = fm_k(7.952054001475513e-07);
-  ps = fma(ps, z, fm_k(-2.1915353447830217e-05));
-  ps = fma(ps, z, fm_k(0.00046630280576761255));
-  ps = fma(ps, z, fm_k(-0.0073704309457143504));
-  ps = fma(ps, z, fm_k(0.08214588661112823));
-  ps = fma(ps, z, fm_k(-0.5992645293207921));
-  ps = fma(ps, z, fm_k(2.5501640398773455));
-  ps = fma(ps, z, fm_k(-5.16771278004997));
-  ps = fma(ps, z, fm_k(3.141592653589793));
+  double ps = k.s[0], pc = k.c[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 1; i < 9; ++i) ps = fma(ps, z, k.s[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 1; i < 8; ++i) pc = fma(pc, z, k.c[i]);
   const double s0 = ps * r;
-  double pc = fm_k(4.303069587032947e-06);
-  pc = fma(pc, z, fm_k(-0.0001046381049248457));
-  pc = fma(pc, z, fm_k(0.0019295743094039231));
-  pc = fma(pc, z, fm_k(-0.02580689139001406));
-  pc = fma(pc, z, fm_k(0.2353306303588932));
-  pc = fma(pc, z, fm_k(-1.3352627688545895));
-  pc = fma(pc, z, fm_k(4.0587121264167685));
-  pc = fma(pc, z, fm_k(-4.934802200544679));
   const double c0 = fma(pc, z, 1.0);
-  const int q = (int)(long long)n & 3;                 // quarter turns mod 4 (two's complement: also for negative n)
+  const int q = (int)fma(-4.0, rint(n * 0.25), n) & 3;   // quarter turns mod 4: -2 .. 2 -> two's complement & 3
   const bool swap = (q & 1) != 0;
   const double sv = swap ? c0 : s0, cv = swap ? s0 : c0;
   *sn = (q & 2) ? -sv : sv;
   *cs = ((q + 1) & 2) ? -cv : cv;
+}
+WM_FM_HD void wm_sincospi(double x, double* sn, double* cs) {
+  SinCosPiK k;
+  k.load();
+  wm_sincospi_k(x, k, sn, cs);
 }
 
 }  // namespace wm

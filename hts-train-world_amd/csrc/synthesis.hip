@@ -349,6 +349,9 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
     const cpx s = img[k];
     const double amp = wm_exp(s.x / F);                              // :210-218
     double sn, cs;
+    // the library's call here: in this loop it is 45 vector instructions; wm_sincospi is 30 plus 34 scalar moves for its
+    // coefficients, and the scalar registers to keep those across the nine bins are not there (they come back as
+    // v_readlane reloads): 4.86 ms against 4.40 for the kernel (tools/ab.sh)
     sincospi(s.y * (1.0 / (kPi * F)), &sn, &cs);                  // phase in half-turns: no Payne-Hanek path
     mp[m] = make_double2(amp * cs, amp * sn);
     __builtin_amdgcn_sched_barrier(0);                            // one bin at a time: keeps the VGPR peak low
@@ -754,12 +757,25 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   b.syn_total_p = total_p;
   b.syn_chunk = 0;
   if (total_p == 0) return WM_OK;
+  // The responses of a piece of the pulse list wait in scratch memory for the overlap-add.  The scratch holds two
+  // pieces: while one is added into y on the second stream the pulse kernel fills the other (synthesis_render).
+  // A piece is half of the list when that fits, else what half of the scratch cap holds.  Measured (tools/syn_sweep.sh,
+  // ms per pass, configs[1] | configs[4]): 1 piece 14.64 | 20.86, 2 pieces 14.64 | 20.73, 4 pieces 14.81 | 20.75,
+  // 8 pieces 15.76 | 20.62; without the second stream 14.61 | 21.24, 14.61 | 21.04, 15.01 | 21.11, 16.24 | 21.52 -- every
+  // launch of the pulse kernel has a tail, so a short list wants few pieces; the overlap-add beside the pulse kernel
+  // is worth 0.3 - 0.5 ms on a long one.  (One 4 GB piece at a time, the round-2 form, took 24.2 ms on configs[4].)
   int64_t cap_mb = 4096;
   if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
-  int64_t chunk = (cap_mb * 1024 * 1024 / 8) / F;
+  int64_t chunk = (cap_mb * 1024 * 1024 / 8) / F / 2;
   if (chunk < 1) chunk = 1;
+  int pieces = 2;
+  if (const char* e = getenv("WORLD_MI355_SYN_PIECES")) pieces = atoi(e) > 0 ? atoi(e) : pieces;
+  const int64_t quarter = (total_p + pieces - 1) / pieces;
+  if (quarter >= 16384 && chunk > quarter) chunk = quarter;       // short lists: one piece, nothing to overlap
   if (chunk > total_p) chunk = total_p;
-  rc = c.ensure_scratch(chunk * F);
+  rc = c.ensure_side();
+  if (rc) return rc;
+  rc = c.ensure_scratch((chunk < total_p ? 2 : 1) * chunk * F);
   if (rc) return rc;
   if (total_p > b.pulse_rec_cap) {
     if (b.d_pulse_rec) dev_free(b.d_pulse_rec);
@@ -791,10 +807,19 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
   const int64_t total_p = b.syn_total_p, chunk = b.syn_chunk;
   if (total_p == 0) return WM_OK;
   const int ola_tiles = (b.max_y_len + 255) / 256;
-  for (int64_t p0 = 0; p0 < total_p; p0 += chunk) {
+  // Piece k: pulse kernel on the caller's stream into half k & 1 of the scratch, overlap-add on the second stream.
+  // The overlap-adds run in list order on one stream, so every sample is summed in the order of one piece per launch
+  // whatever the timing; the pulse kernel of piece k + 2 waits for the overlap-add of piece k to release its half.
+  int rc = WM_OK;
+  int piece = 0;
+  for (int64_t p0 = 0; p0 < total_p && !rc; p0 += chunk, ++piece) {
     const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
     const int64_t np = p1 - p0;
+    const int h = piece & 1;
+    double* resp = c.d_scratch + (int64_t)h * chunk * F;
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
+    if (piece >= 2) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[h], 0));
+    if (rc) break;
     launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
                      b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm, b.d_pulse_perm + b.pulse_rec_cap);
 #define WM_SY_CASE(FF)                                                                                          \
@@ -802,7 +827,7 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
     const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
     hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
                        (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
-                       (const int*)b.d_pulse_perm, c.d_scratch);                                                \
+                       (const int*)b.d_pulse_perm, resp);                                                       \
   } break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
@@ -814,11 +839,25 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
       }
     }
 #undef WM_SY_CASE
-    TimedScope ts2_(b.ctx, "synth_ola_kernel");
-    hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(256), 0, st, b.d_y_off, b.d_pulse_off,
-                       b.d_pulse_idx, F, p0, p1, c.d_scratch, d_y);
+    static const bool overlap = !(getenv("WORLD_MI355_SYN_OVERLAP") && atoi(getenv("WORLD_MI355_SYN_OVERLAP")) == 0);
+    hipStream_t so = overlap ? c.side : st;
+    rc = wm_check(hipEventRecord(c.ev_pulse[h], st));
+    rc = rc ? rc : wm_check(hipStreamWaitEvent(so, c.ev_pulse[h], 0));
+    if (rc) break;
+    {
+      c.stream = so;                                       // the timing bracket records on the context's stream
+      TimedScope ts2_(b.ctx, "synth_ola_kernel");
+      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(256), 0, so, b.d_y_off, b.d_pulse_off,
+                         b.d_pulse_idx, F, p0, p1, resp, d_y);
+    }
+    c.stream = st;
+    rc = wm_check(hipEventRecord(c.ev_ola[h], so));
   }
-  return wm_check(hipGetLastError());
+  c.stream = st;
+  // y is complete, and both halves are free again, when the last overlap-add is: everything after this call on the
+  // caller's stream is ordered behind it
+  if (!rc && piece > 0) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[(piece - 1) & 1], 0));
+  return rc ? rc : wm_check(hipGetLastError());
 }
 
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
