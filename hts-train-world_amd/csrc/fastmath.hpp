@@ -120,6 +120,24 @@ WM_FM_HD double wm_exp(double x) {
 // coefficients pi^k / k! (their tails at |r| = 1/4: 5e-17 and 2e-18), the quadrant swaps and negates.  Within 1.5 ulp
 // (tests/hooks, fastmath_check).  No branch and no call: from 2^53 on every double is an even integer (sin 0, cos 1),
 // the quadrant n mod 4 is taken in floating point (exact for any n), infinities and NaN come out as NaN.
+// sqrt(x) for 0 <= x < 2^500, normal or zero (the library's sqrt() is 22 vector instructions: it rescales arguments
+// near the ends of the exponent range): v_rsq_f64 (26 bits) carried to 52 by one coupled step for the root g and the
+// half reciprocal root h, then one correction of g by its own residual.  Negative x and x = 0 give 0.
+WM_FM_HD double wm_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x > 0.0 ? g : 0.0;
+#else
+  return x > 0.0 ? sqrt(x) : 0.0;
+#endif
+}
+
 struct SinCosPiK {
   double s[9], c[8];
   WM_FM_HD void load() {

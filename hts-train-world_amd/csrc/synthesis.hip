@@ -351,8 +351,14 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
     double sn, cs;
     // the library's call here: in this loop it is 45 vector instructions; wm_sincospi is 30 plus 34 scalar moves for its
     // coefficients, and the scalar registers to keep those across the nine bins are not there (they come back as
-    // v_readlane reloads): 4.86 ms against 4.40 for the kernel (tools/ab.sh)
-    sincospi(s.y * (1.0 / (kPi * F)), &sn, &cs);                  // phase in half-turns: no Payne-Hanek path
+    // v_readlane reloads): 4.86 ms against 4.40 for the kernel (tools/ab.sh).  A 64-point table in LDS with short
+    // polynomials around it is 26 instructions, but the kernel then allocates 168 registers (three waves per SIMD)
+    if (m < M) {
+      sincospi(s.y * (1.0 / (kPi * F)), &sn, &cs);                // phase in half-turns: no Payne-Hanek path
+    } else {
+      sn = 0.0;                                                   // the Nyquist bin of a real sequence's transform is real
+      cs = 1.0;                                                   // (rfft_forward writes its imaginary part as 0.0)
+    }
     mp[m] = make_double2(amp * cs, amp * sn);
     __builtin_amdgcn_sched_barrier(0);                            // one bin at a time: keeps the VGPR peak low
   }
@@ -511,7 +517,9 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
           rs = rs * dc64 + rc * ds64;
           rc = nc;
         }
-        const double im2 = sqrt(1.0 - re2 * re2);
+        // synthesis.cpp:96 takes the sine as sqrt(1 - cos^2): always >= 0.  The rotated cosine can pass 1 by a
+        // rounding where the reference's cos() cannot: wm_sqrt returns 0 there instead of a NaN
+        const double im2 = wm_sqrt(1.0 - re2 * re2);
         const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
         if (m < M || lane == 0) img[k] = s;
         __builtin_amdgcn_sched_barrier(0);

@@ -1018,21 +1018,22 @@ def test_fast_log_exp_against_numpy(gpu):
     torch, W, ctx = gpu
     lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libfastmath_hook.so"))
     vp = C.c_void_p
-    lib.FastmathHook.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.FastmathHook.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     rng = np.random.default_rng(11)
     pos = np.exp(rng.uniform(-100.0, 40.0, 400_000)) * rng.uniform(0.5, 2.0, 400_000)      # 1e-44 .. 1e17
     near1 = 1.0 + rng.uniform(-1e-3, 1e-3, 100_000)
     expo = np.concatenate([rng.uniform(-90.0, 40.0, 300_000), rng.uniform(-2000.0, 2000.0, 100_000)])
     special = np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 2.2250738585072014e-308,
                         1.7976931348623157e308, 1.0, 709.0, -745.0, 800.0, -800.0, 700.0, -700.0])
-    x = np.concatenate([pos, near1, expo, special])
+    big = np.array([2.0 ** 51 + 0.5, 2.0 ** 52 + 1.0, 2.0 ** 53, -2.0 ** 53, 1e300, -1e300, 2.0 ** 40 + 0.25])
+    x = np.concatenate([pos, near1, expo, special, big])
     xd = torch.from_numpy(x).cuda()
-    lg, ex, sn, cs = (torch.empty_like(xd) for _ in range(4))
+    lg, ex, sn, cs, sq = (torch.empty_like(xd) for _ in range(5))
     torch.cuda.synchronize()
     rc = lib.FastmathHook(vp(torch.cuda.current_stream().cuda_stream), len(x), vp(xd.data_ptr()), vp(lg.data_ptr()),
-                          vp(ex.data_ptr()), vp(sn.data_ptr()), vp(cs.data_ptr()))
+                          vp(ex.data_ptr()), vp(sn.data_ptr()), vp(cs.data_ptr()), vp(sq.data_ptr()))
     assert rc == 0
-    lg, ex, sn, cs = (v.cpu().numpy() for v in (lg, ex, sn, cs))
+    lg, ex, sn, cs, sq = (v.cpu().numpy() for v in (lg, ex, sn, cs, sq))
     with np.errstate(all="ignore"):
         want_l, want_e = np.log(x), np.exp(x)
 
@@ -1050,7 +1051,17 @@ def test_fast_log_exp_against_numpy(gpu):
     ws, wc = np.sin(np.pi * xr), np.cos(np.pi * xr)            # np.pi is a double: its 1.2e-16 enters as 4e-17 * |pi x|
     assert np.abs(sn[sel] - ws.astype(np.float64)).max() < 6e-16 and np.abs(cs[sel] - wc.astype(np.float64)).max() < 6e-16
     # special cases: the library's answers (the same NaNs and infinities, zero for underflow)
-    tail = slice(n1 + len(expo), None)
+    tail = slice(n1 + len(expo), n1 + len(expo) + len(special))
+    # wm_sincospi without a branch: even integers from 2^53 on, the quadrant taken in floating point below that
+    sb, cb = sn[-len(big):], cs[-len(big):]
+    np.testing.assert_allclose(np.abs(sb), [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, np.sqrt(0.5)], atol=2e-16)
+    np.testing.assert_allclose(cb, [0.0, -1.0, 1.0, 1.0, 1.0, 1.0, np.sqrt(0.5)], atol=2e-16)
+    assert sb[0] == 1.0 and sb[6] > 0
+    assert np.isnan(sn[tail][3]) and np.isnan(cs[tail][4]) and np.isnan(sn[tail][5])       # +-inf, NaN
+    # wm_sqrt (the pulse kernel's sqrt(1 - cos^2)): within 1 ulp on normal arguments, 0 for zero and below
+    assert ulps(sq[:n1], np.sqrt(x[:n1])).max() <= 1.0
+    neg = x < 0
+    assert np.all(sq[neg] == 0.0) and sq[n1 + len(expo)] == 0.0
     np.testing.assert_array_equal(np.isnan(lg[tail]), np.isnan(want_l[tail]))
     np.testing.assert_array_equal(np.isnan(ex[tail]), np.isnan(want_e[tail]))
     fin = ~np.isnan(want_l[tail])
