@@ -68,7 +68,7 @@ def d4c_flops_per_voiced_frame(fs):
 # the sources have changed since the counters were collected the figure is stale and `traffic` is reported as null.
 # The counter readings are corrected by the factors measured with tools/micro/hbmcal.hip on this chip
 # (profiles/hbm_counter_calibration.json; MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half the bytes read).
-COMMON_SOURCES = ("fft.hpp", "common.hpp", "wavesync.hpp", "partition.hpp")
+COMMON_SOURCES = ("fft.hpp", "common.hpp", "wavesync.hpp", "partition.hpp", "fastmath.hpp")
 KERNEL_SOURCES = {
     "analysis_synthesis": ("d4c.hip", "d4c_big.hpp", "peel.hpp", "frame.hpp", "spectrum.hpp", "window.hpp") + COMMON_SOURCES,
     "harvest": ("harvest.hip", "fftconv.hpp", "zcfilter.hpp", "decimate.hpp") + COMMON_SOURCES,

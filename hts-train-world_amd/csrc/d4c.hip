@@ -28,9 +28,7 @@
 
 // fastmath.hpp's coefficients as plain literals in this file: the D4C kernels already spill scalar registers (frame
 // pipeline, kernel arguments, FFT constants), and every coefficient pinned to a scalar pair came back as a v_readlane
-#ifndef WM_AB
 #define WM_FM_PLAIN 1
-#endif
 #include "batch.hpp"
 #include "common.hpp"
 #include "fastmath.hpp"

@@ -69,13 +69,11 @@ __device__ __forceinline__ void frame_strided(const double* __restrict__ xu, int
 #pragma unroll
     for (int r = 0; r < G; ++r) {
       const int q = c * G + r;
-      xv[r] = 0.0;
-      rv[r] = 0u;
-      if (WM_FRAME_BRANCH(64 * q < L)) {                                  // wave-uniform
-        const int ic = imin(64 * q + lane, L - 1);
-        xv[r] = xu[imin(xl - 1, imax(0, fg.origin + ic - fg.hw))];
-        rv[r] = rtab[roff + ic];
-      }
+      // no branch around the loads: behind one, every register group is its own trip to memory (the compiler
+      // waits for the draw right where it is loaded); groups beyond the window re-read sample L - 1
+      const int ic = imin(64 * q + lane, L - 1);
+      xv[r] = xu[imin(xl - 1, imax(0, fg.origin + ic - fg.hw))];
+      rv[r] = rtab[roff + ic];
     }
 #pragma unroll
     for (int r = 0; r < G; ++r) {
@@ -213,15 +211,11 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
 #pragma unroll
     for (int r = 0; r < G; ++r) {
       const int m = c * G + r;
-      xa[r] = xb[r] = 0.0;
-      ra[r] = rb[r] = 0u;
-      if (WM_FRAME_BRANCH(128 * m < L)) {                                 // wave-uniform
-        const int i0 = imin(128 * m + 2 * lane, L - 1), i1 = imin(128 * m + 2 * lane + 1, L - 1);
-        xa[r] = xu[imin(xl - 1, imax(0, fg.origin + i0 - fg.hw))];
-        xb[r] = xu[imin(xl - 1, imax(0, fg.origin + i1 - fg.hw))];
-        ra[r] = rtab[roff + i0];
-        rb[r] = rtab[roff + i1];
-      }
+      const int i0 = imin(128 * m + 2 * lane, L - 1), i1 = imin(128 * m + 2 * lane + 1, L - 1);   // no branch: see above
+      xa[r] = xu[imin(xl - 1, imax(0, fg.origin + i0 - fg.hw))];
+      xb[r] = xu[imin(xl - 1, imax(0, fg.origin + i1 - fg.hw))];
+      ra[r] = rtab[roff + i0];
+      rb[r] = rtab[roff + i1];
     }
 #pragma unroll
     for (int r = 0; r < G; ++r) {
