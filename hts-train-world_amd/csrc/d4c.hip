@@ -424,13 +424,33 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       wave_sync();
       const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
       cpx v[M];
+      // Window values in groups of four register pairs: the loads of a group are issued together with clamped
+      // indices and the predicate goes on the value (behind a per-lane branch every pair was a trip to memory of its
+      // own); groups wholly beyond the window are skipped by a wave-uniform branch.
+      constexpr int GW = M < 4 ? M : 4;
+      const int lw = opaque_lane(lane);       // per band: the window values are not kept in registers across the bands
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const int i0 = 2 * (lane + 64 * m);
-        double a0 = 0.0, a1 = 0.0;
-        if (i0 < wl) a0 = arr[center - hwl + i0] * tab.nuttall[i0];
-        if (i0 + 1 < wl) a1 = arr[center - hwl + i0 + 1] * tab.nuttall[i0 + 1];
-        v[m] = make_double2(a0, a1);
+      for (int g0 = 0; g0 < M; g0 += GW) {
+        if (128 * g0 < wl) {
+          double na[GW], nb[GW], ga[GW], gb[GW];
+#pragma unroll
+          for (int r = 0; r < GW; ++r) {
+            const int i0 = 2 * (lw + 64 * (g0 + r));
+            const int j0 = imin(i0, wl - 1), j1 = imin(i0 + 1, wl - 1);
+            na[r] = tab.nuttall[j0];
+            nb[r] = tab.nuttall[j1];
+            ga[r] = arr[center - hwl + j0];
+            gb[r] = arr[center - hwl + j1];
+          }
+#pragma unroll
+          for (int r = 0; r < GW; ++r) {
+            const int i0 = 2 * (lw + 64 * (g0 + r));
+            v[g0 + r] = make_double2(i0 < wl ? ga[r] * na[r] : 0.0, i0 + 1 < wl ? gb[r] * nb[r] : 0.0);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < GW; ++r) v[g0 + r] = make_double2(0.0, 0.0);
+        }
       }
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];

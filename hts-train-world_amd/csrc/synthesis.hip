@@ -337,9 +337,10 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
-    double a = 0.0, b = 0.0;
-    if (i0 <= H) a = (i0 == 0 || i0 == H) ? img[i0].x : 2.0 * img[i0].x;
-    if (i1 < H) b = 2.0 * img[i1].x;
+    // reads with clamped indices and the predicate on the value (a read behind a per-lane branch is waited for on its own)
+    const double xa = img[imin(i0, H)].x, xb = img[imin(i1, H)].x;
+    const double a = i0 <= H ? ((i0 == 0 || i0 == H) ? xa : 2.0 * xa) : 0.0;
+    const double b = i1 < H ? 2.0 * xb : 0.0;
     v[m] = make_double2(a, b);
   }
   rfft_forward<N>(v, img, img, tw, lane);
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
 
 // One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
 template <int F>
-__global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth_pulse_kernel(
+__global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 : 2))) void synth_pulse_kernel(
     const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
     const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
     int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
@@ -449,21 +450,18 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const int k = m < M ? lane + 64 * m : H;
-        if (ff == fc) {
-          env[m] = fabs(s0[k]);
-          const double a = safe_ap(a0[k]);
-          rat[m] = a * a;
-        } else {
-          env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
-          const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
-          rat[m] = a * a;
-        }
+        // synthesis.cpp:140-178 copies row ff when the pulse sits on a frame (ff == fc) and interpolates otherwise; with
+        // wgt = 0 the interpolation IS the copy (1 x + 0 y = x for finite y, and y is then the same row), so there is
+        // one form and no branch inside the loop: behind one, every bin's loads were a trip to memory of their own
+        env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
+        const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
+        rat[m] = a * a;
       }
     };
     double env_keep[LEAN ? 1 : MB], rat_keep[LEAN ? 1 : MB];
     double rat0;
     if constexpr (LEAN) {
-      const double a = ff == fc ? safe_ap(a0[0]) : (1.0 - wgt) * safe_ap(a0[0]) + wgt * safe_ap(a1[0]);   // bin 0, every lane
+      const double a = (1.0 - wgt) * safe_ap(a0[0]) + wgt * safe_ap(a1[0]);   // bin 0, every lane
       rat0 = uniform_d(a * a);
     } else {
       spectral(env_keep, rat_keep);
@@ -616,15 +614,17 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F <= 1024 ? 3 : 2)) void synth
       if (m < M / 2) {                                // i < H  ->  j = i + H (second half)
         const double x0 = LEAN ? xq[LEAN ? m : 0].x : xp[LEAN ? 0 : 2 * m];
         const double x1 = LEAN ? xq[LEAN ? m : 0].y : xp[LEAN ? 0 : 2 * m + 1];
-        const double p0 = periodic ? x0 - dc * dcr[i0 + H] : 0.0;
-        const double p1 = periodic ? x1 - dc * dcr[i0 + 1 + H] : 0.0;
+        const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 + H);   // unconditional: a load behind the
+        const double p0 = periodic ? x0 - dc * dr.x : 0.0;                    // (uniform) branch is waited for on its own
+        const double p1 = periodic ? x1 - dc * dr.y : 0.0;
         r0 = (p0 * sq + v[m].x) / F;
         r1 = (p1 * sq + v[m].y) / F;
         out[i0 + H] = r0;
         out[i0 + 1 + H] = r1;
       } else {                                        // i >= H ->  j = i - H (first half, periodic overwritten)
-        const double p0 = periodic ? -dc * dcr[i0 - H] : 0.0;
-        const double p1 = periodic ? -dc * dcr[i0 + 1 - H] : 0.0;
+        const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 - H);
+        const double p0 = periodic ? -dc * dr.x : 0.0;
+        const double p1 = periodic ? -dc * dr.y : 0.0;
         r0 = (p0 * sq + v[m].x) / F;
         r1 = (p1 * sq + v[m].y) / F;
         out[i0 - H] = r0;
