@@ -135,12 +135,15 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     {
       // the draws of all bins first (one trip to memory; a rolled loop made each bin wait for its own)
       uint32_t rv[M + 1];
+      double pv[M + 1];
 #pragma unroll
       for (int m = 0; m <= M; ++m) rv[m] = rtab[roff + fg.L + imin(lane + 64 * m, H)];
 #pragma unroll
+      for (int m = 0; m <= M; ++m) pv[m] = pw[imin(lane + 64 * m, H)];        // and the smoothed bins in one round trip
+#pragma unroll
       for (int m = 0; m <= M; ++m) {
         const int i = lane + 64 * m;
-        const double val = wm_log(pw[imin(i, H)] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
+        const double val = wm_log(pv[m] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
         if (m < M || lane == 0) pw[i] = val;
         __builtin_amdgcn_sched_barrier(0);                        // one bin at a time: keeps the register peak low
       }
@@ -159,14 +162,19 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       // angle pi*f0*i/fs advances by a rotation per 64 bins; cos(2a) = 1 - 2 sin^2(a)
       CosGen g;
       g.init(cf0 / fs, lane, 64);
-      for (int i = lane; i <= H; i += 64) {
+      double cx[M + 1];
+#pragma unroll
+      for (int m = 0; m <= M; ++m) cx[m] = img[imin(lane + 64 * m, H)].x;      // the cepstrum in one round trip
+#pragma unroll
+      for (int m = 0; m <= M; ++m) {
+        const int i = lane + 64 * m;
         double sl = 1.0, cl = (1.0 - 2.0 * q1) + 2.0 * q1;
         if (i > 0) {
           const double quef = (double)i / fs;
           sl = g.s / (kPi * cf0 * quef);
           cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * g.s * g.s);
         }
-        img[i] = make_double2(img[i].x * sl * cl / F, 0.0);
+        if (m < M || lane == 0) img[i] = make_double2(cx[m] * sl * cl / F, 0.0);
         g.next();
       }
     }
