@@ -66,14 +66,23 @@ __device__ __forceinline__ void frame_strided(const double* __restrict__ xu, int
   for (int c = 0; c < QX / G; ++c) {
     double xv[G];
     uint32_t rv[G];
+    // No branch around the single loads: behind one, every register is its own trip to memory (the compiler waits
+    // for the draw right where it is loaded); registers beyond the window re-read sample L - 1.  Long frames (more
+    // than one group of 16) skip whole groups beyond the window: 64 unconditional loads cost the fft-4096 centroid
+    // kernel 156 bytes of spilled registers per lane.
 #pragma unroll
     for (int r = 0; r < G; ++r) {
-      const int q = c * G + r;
-      // no branch around the loads: behind one, every register group is its own trip to memory (the compiler
-      // waits for the draw right where it is loaded); groups beyond the window re-read sample L - 1
-      const int ic = imin(64 * q + lane, L - 1);
-      xv[r] = xu[imin(xl - 1, imax(0, fg.origin + ic - fg.hw))];
-      rv[r] = rtab[roff + ic];
+      xv[r] = 0.0;
+      rv[r] = 0u;
+    }
+    if (QX == G || 64 * G * c < L) {
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int q = c * G + r;
+        const int ic = imin(64 * q + lane, L - 1);
+        xv[r] = xu[imin(xl - 1, imax(0, fg.origin + ic - fg.hw))];
+        rv[r] = rtab[roff + ic];
+      }
     }
 #pragma unroll
     for (int r = 0; r < G; ++r) {
