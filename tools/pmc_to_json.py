@@ -1,5 +1,5 @@
 """Turn the two PMC passes of tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, counter_collection CSVs)
-into one record of profiles/pmc_traffic.json: HBM-side KB of the dominant kernel, the frames it processed, and a hash
+into one record of profiles/pmc_traffic.json: HBM-side KB of the dominant kernel per pass, the frames of a pass, and a hash
 of the kernel's sources (bench.py prints `roofline.traffic` only while that hash still matches).
 
     python tools/pmc_to_json.py FETCH_DIR WRITE_DIR FRAMES FS TAG [WORKLOAD]
@@ -35,30 +35,42 @@ MATCH = {"analysis_synthesis": is_usual_d4c,
          "synthesis": lambda n: "synth_pulse_kernel" in n}
 
 
-def total(dirname, counter, match=is_usual_d4c):
-    kb, launches, name = 0.0, 0, None
+# a kernel that runs exactly once per pass of the workload: its launches count the passes of a profiled run, so that a
+# pass that launches the dominant kernel several times (Synthesis in pieces, D4C in chunks) is still one pass
+PASS_MARK = {"analysis_synthesis": "synth_timebase_kernel", "synthesis": "synth_timebase_kernel",
+             "harvest": "hv_contour_kernel"}
+
+
+def total(dirname, counter, match=is_usual_d4c, mark=None):
+    kb, launches, name, passes = 0.0, 0, None, 0
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Counter_Name") == counter and match(row.get("Kernel_Name", "")):
+                if row.get("Counter_Name") != counter:
+                    continue
+                kn = row.get("Kernel_Name", "")
+                if mark and mark in kn:
+                    passes += 1
+                if match(kn):
                     kb += float(row["Counter_Value"])
-                    if counts_as_launch(row["Kernel_Name"]):
+                    if counts_as_launch(kn):
                         launches += 1
-                        name = row["Kernel_Name"]
-    return kb, launches, name
+                        name = kn
+    return kb, launches, name, passes
 
 
 def main():
     fdir, wdir, frames, fs, tag = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     workload = sys.argv[6] if len(sys.argv) > 6 else "analysis_synthesis"
-    fkb, fl, name = total(fdir, "FETCH_SIZE", MATCH[workload])
-    wkb, wl, _ = total(wdir, "WRITE_SIZE", MATCH[workload])
-    assert fl and fl == wl, (fl, wl)
+    fkb, fl, name, fp = total(fdir, "FETCH_SIZE", MATCH[workload], PASS_MARK[workload])
+    wkb, wl, _, wp = total(wdir, "WRITE_SIZE", MATCH[workload], PASS_MARK[workload])
+    assert fl and fl == wl and fp and fp == wp, (fl, wl, fp, wp)
     kname = (name or "d4c_kernel").split("(")[0]
     if "d4cb_" in kname:
         kname = "d4cb_centroid_kernel + d4cb_spectrum_kernel + d4cb_band_kernel (the D4C scope at fft 4096)"
-    rec = {"workload": workload, "kernel": kname, "fs": fs, "frames": frames, "launches": fl,
-           "fetch_kb": fkb / fl, "write_kb": wkb / wl, "source_sha": bench.kernel_source_hash(workload), "tag": tag,
+    # fetch_kb / write_kb: per PASS over `frames` frames (the sum of the kernel's launches of a pass)
+    rec = {"workload": workload, "kernel": kname, "fs": fs, "frames": frames, "launches": fl, "passes": fp,
+           "fetch_kb": fkb / fp, "write_kb": wkb / wp, "source_sha": bench.kernel_source_hash(workload), "tag": tag,
            "files": "profiles/%s_pmc_fetch.csv, profiles/%s_pmc_write.csv" % (tag, tag),
            "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); bench.py multiplies by the factors measured in "
                         "profiles/hbm_counter_calibration.json (reads x 2.0, writes x 1.0 on gfx950)"}
