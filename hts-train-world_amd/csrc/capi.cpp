@@ -85,6 +85,13 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) c.num_cu = prop.multiProcessorCount;
   c.frame_grid = c.num_cu * 128;
+  if (const char* e = getenv("WORLD_MI355_OVERSUB")) {          // workgroups per resident slot (batch.hpp)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) {
+      c.oversub = v;
+      c.frame_grid = c.num_cu * 16 * v;
+    }
+  }
   // NULL selects the legacy default stream (stream 0): it orders with every blocking stream, which
   // is what callers that allocate and copy with plain hipMemcpy / torch's default stream expect.
   c.stream = (hipStream_t)hip_stream;
