@@ -37,8 +37,12 @@ struct Context {
   bool own_stream = false;
   int num_cu = 256;
   int frame_grid = 256 * 8;          // upper bound on the workgroups of a grid-stride per-frame kernel
-  int oversub = 8;                   // workgroups per resident slot of those kernels (persistent_grid): measured on
-                                     // configs[1], 21.2 / 18.0 / 17.7 / 17.3 / 17.3 ms per step at 1 / 2 / 4 / 8 / 16
+  int oversub = 6;                   // workgroups per resident slot of those kernels (persistent_grid): measured on
+                                     // configs[1], round 2: 21.2 / 18.0 / 17.7 / 17.3 / 17.3 ms per step at 1 / 2 / 4 / 8 /
+                                     // 16; end of round 3 (tools/oversub_sweep.sh): 15.0 / 14.2 / 14.1 / 14.3 / 13.8 / 14.2 /
+                                     // 14.0 / 14.7 / 17.0 at 2 / 3 / 4 / 5 / 6 / 7 / 8 / 16 / 32 -- a workgroup's start (twiddle
+                                     // bases, the blocking fill of the scalar pipe, its share of the default rows) is
+                                     // worth most of a frame, a large share makes the last round ragged
   uint32_t* d_rng = nullptr;         // universal randn table, uint32 sums
   int64_t rng_cap = 0;
   uint32_t rng_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};   // matlabfunctions.cpp:247-250

@@ -84,7 +84,7 @@ int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** ou
   hipGetDevice(&c.device);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c.device) == hipSuccess) c.num_cu = prop.multiProcessorCount;
-  c.frame_grid = c.num_cu * 128;
+  c.frame_grid = c.num_cu * 16 * c.oversub;
   if (const char* e = getenv("WORLD_MI355_OVERSUB")) {          // workgroups per resident slot (batch.hpp)
     const int v = atoi(e);
     if (v >= 1 && v <= 64) {
