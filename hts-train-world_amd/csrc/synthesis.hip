@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
     // ---- GetSpectralEnvelope / GetAperiodicRatio (:140-178) ----
     const int ff = imin(nf - 1, (int)floor(ctime / fp));
     const int fc = imin(nf - 1, (int)ceil(ctime / fp));
-    const double wgt = ctime / fp - ff;
+    const double wgt = ff == fc ? 0.0 : ctime / fp - ff;    // beyond the last frame both indices are clamped: a copy there too
     const double* s0 = sp + (r.fbase + ff) * (int64_t)(H + 1);
     const double* s1 = sp + (r.fbase + fc) * (int64_t)(H + 1);
     const double* a0 = ap + (r.fbase + ff) * (int64_t)(H + 1);
@@ -450,9 +450,9 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const int k = m < M ? lane + 64 * m : H;
-        // synthesis.cpp:140-178 copies row ff when the pulse sits on a frame (ff == fc) and interpolates otherwise; with
-        // wgt = 0 the interpolation IS the copy (1 x + 0 y = x for finite y, and y is then the same row), so there is
-        // one form and no branch inside the loop: behind one, every bin's loads were a trip to memory of their own
+        // synthesis.cpp:140-178 copies row ff when ff == fc and interpolates otherwise; with wgt = 0 (set above for
+        // that case) the interpolation IS the copy (1 x + 0 y = x for finite y, and y is then the same row), so there
+        // is one form and no branch inside the loop: behind one, every bin's loads were a trip to memory of their own
         env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
         const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
         rat[m] = a * a;
