@@ -80,6 +80,84 @@ def codec_case(ref, name, index, fs, duration, spec_dim, frame_period=5.0):
     print(name, "frames", len(t), "coded", csp.shape, cap.shape)
 
 
+def read_wav_i16(path):
+    """The 16-bit payload of a mono PCM wav, and its rate (what wavread hands over divided by 2^15,
+    externs/WORLD_v2/test/audioio.cpp:236-249)."""
+    import wave
+    with wave.open(path, "rb") as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2
+        return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy(), w.getframerate()
+
+
+def real_case(ref, name, wav, frame_period=5.0, frame_step=16, sample_step=7):
+    """The reference's OWN inputs (wav_test/arctic_a0001.wav: SURVEY.md's config 1; test/vaiueo2d.wav): the
+    fixture holds the int16 samples (data) beside the compiled reference's outputs on them.  Real speech is where
+    the thresholded branches of Dio / StoneMask / Harvest (creak, onsets, near-silence) are taken."""
+    s, fs = read_wav_i16(wav)
+    x = s.astype(np.float64) / 32768.0
+    t, f0_dio = ref.dio(x, fs, frame_period)
+    f0 = ref.stonemask(x, fs, t, f0_dio)
+    th, f0_hv = ref.harvest(x, fs, frame_period)
+    np.testing.assert_array_equal(t, th)
+    fft_size = ref.cheaptrick_fft_size(fs)
+    sp = ref.cheaptrick(x, fs, t, f0, -0.15, fft_size)
+    ap = ref.d4c(x, fs, t, f0, fft_size, 0.0)
+    ap85 = ref.d4c(x, fs, t, f0, fft_size, 0.85)
+    y = ref.synthesis(f0, sp, ap, fft_size, frame_period, fs)
+    # Harvest's contour through the same back end (what a caller that picks Harvest gets)
+    f0_hs = ref.stonemask(x, fs, t, f0_hv)
+    sp_h = ref.cheaptrick(x, fs, t, f0_hs, -0.15, fft_size)
+    ap_h = ref.d4c(x, fs, t, f0_hs, fft_size, 0.85)
+    y_h = ref.synthesis(f0_hs, sp_h, ap_h, fft_size, frame_period, fs)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_i16=s, fs=fs, frame_period=frame_period,
+                        fft_size=fft_size, t=t, f0_dio=f0_dio, f0=f0, f0_harvest=f0_hv, f0_harvest_sm=f0_hs,
+                        frame_step=frame_step, sample_step=sample_step,
+                        sp_sub=sp[::frame_step], ap_sub=ap[::frame_step], ap85_sub=ap85[::frame_step],
+                        sp_check=checks(sp), ap_check=checks(ap), ap85_check=checks(ap85),
+                        y_sub=y[::sample_step], y_check=checks(y),
+                        sp_h_check=checks(sp_h), ap_h_check=checks(ap_h), y_h_sub=y_h[::sample_step],
+                        y_h_check=checks(y_h))
+    print(name, "fs", fs, "samples", len(s), "frames", len(t), "voiced dio", int((f0 > 0).sum()),
+          "harvest", int((f0_hv > 0).sum()))
+
+
+OPTION_Q1 = (-0.15, -0.09, 0.0)
+
+
+def option_fft_sizes(fs):
+    """default, twice and half the default of GetFFTSizeForCheapTrick (cheaptrick.cpp:191-194)."""
+    d = 2048 if fs > 25600 else 1024
+    return (d, 2 * d, d // 2)
+
+
+def option_case(ref, name, x, fs, frame_period=5.0, frame_step=8, sample_step=11):
+    """CheapTrickOption.q1 / fft_size away from their defaults (cheaptrick.h:16-20; cheaptrick.cpp:200-228 takes
+    the floor from the size: frames at or below 3 fs / (fft_size - 3) are analysed at the default f0), D4C with
+    that size for its rows (d4c.cpp:337-397: the transform inside follows fs, the rows follow the argument) and
+    Synthesis from the set (synthesis.cpp:338-397)."""
+    t, f0_dio = ref.dio(x, fs, frame_period)
+    f0 = ref.stonemask(x, fs, t, f0_dio)
+    out = dict(fs=fs, frame_period=frame_period, x_i16=np.round(x * 32768.0).astype(np.int16), t=t, f0=f0,
+               frame_step=frame_step, sample_step=sample_step, q1=np.array(OPTION_Q1),
+               fft_sizes=np.array(option_fft_sizes(fs)))
+    for F in option_fft_sizes(fs):
+        ap = ref.d4c(x, fs, t, f0, F, 0.85)
+        out["ap_%d_sub" % F] = ap[::frame_step]
+        out["ap_%d_check" % F] = checks(ap)
+        for qi, q1 in enumerate(OPTION_Q1):
+            sp = ref.cheaptrick(x, fs, t, f0, q1, F)
+            out["sp_%d_q%d_sub" % (F, qi)] = sp[::frame_step]
+            out["sp_%d_q%d_check" % (F, qi)] = checks(sp)
+            if qi == 1:
+                y = ref.synthesis(f0, sp, ap, F, frame_period, fs)
+                out["y_%d_sub" % F] = y[::sample_step]
+                out["y_%d_check" % F] = checks(y)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "frames", len(t), "sizes", option_fft_sizes(fs), "floors",
+          [round(3.0 * fs / (F - 3.0), 1) for F in option_fft_sizes(fs)],
+          "frames at or below", [int(((f0 > 0) & (f0 <= 3.0 * fs / (F - 3.0))).sum()) for F in option_fft_sizes(fs)])
+
+
 def primitives(ref):
     rng = np.random.default_rng(12345)
     out = {"randn4096": ref.randn_table(4096)}
@@ -114,6 +192,14 @@ def main():
     harvest_case(ref, "harvest_48k_1ms", 4, 48000, 1.0, 1.0)
     codec_case(ref, "codec_16k", 11, 16000, 1.6, 50)
     codec_case(ref, "codec_48k", 12, 48000, 0.8, 60)
+    W = "/root/reference/externs/WORLD_v2"
+    real_case(ref, "real_arctic_a0001", W + "/wav_test/arctic_a0001.wav")
+    real_case(ref, "real_vaiueo2d", W + "/test/vaiueo2d.wav")
+    s, fs = read_wav_i16(W + "/wav_test/arctic_a0001.wav")
+    option_case(ref, "options_16k", s[4000:24000].astype(np.float64) / 32768.0, fs, frame_step=16)   # 1.25 s of real speech
+    s, fs = read_wav_i16(W + "/test/vaiueo2d.wav")          # low voice: half the frames below the floor of fft 512
+    option_case(ref, "options_22k", s.astype(np.float64) / 32768.0, fs, frame_step=16)
+    option_case(ref, "options_48k", sd.make_utterance(49, 48000, duration=0.7), 48000, frame_step=24, sample_step=23)
 
 
 if __name__ == "__main__":

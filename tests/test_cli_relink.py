@@ -106,3 +106,46 @@ def test_relinked_cli_roundtrip(gpu, tmp_path, fs, F, dur, index):
     yg, fg = read_wav(tmp_path / "gpu_y.wav")
     assert fr == fg == fs and yr.shape == yg.shape
     assert np.abs(yr - yg).max() <= 1 and (yr != yg).mean() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["real_arctic_a0001", "real_vaiueo2d"])
+def test_relinked_cli_on_the_reference_wavs(gpu, tmp_path, name):
+    """The reference's own two wav payloads (tests/golden/real_*.npz holds their int16 samples) through its own
+    main()s on both link lines: uncompressed and coded analysis files, then synth from the reference's files."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    fs, F = int(g["fs"]), int(g["fft_size"])
+    wav = tmp_path / "in.wav"
+    with wave.open(str(wav), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(fs)
+        w.writeframes(g["x_i16"].astype("<i2").tobytes())
+    a_ref, a_gpu = cli("analysis_ref"), cli("analysis_mi355")
+    s_ref, s_gpu = cli("synth_ref"), cli("synth_mi355")
+    rf0, rsp, rap = analysis_files(a_ref, wav, tmp_path, "ref", (5, F))
+    gf0, gsp, gap = analysis_files(a_gpu, wav, tmp_path, "gpu", (5, F))
+    # the CLI's f0 file is what the fixture holds (Dio + StoneMask of the library, float32)
+    np.testing.assert_array_equal(rf0, g["f0"].astype(np.float32))
+    assert rf0.shape == gf0.shape and rsp.shape == gsp.shape == (len(rf0) * (F // 2 + 1),)
+    assert ((rf0 > 0) == (gf0 > 0)).all()
+    assert np.abs(rf0.astype(np.float64) - gf0).max() < 1e-3
+    # float32 files of doubles that agree to 1e-8 relative (the quiet bins of real speech: the blocked cumulative
+    # sum of LinearSmoothing, DESIGN.md section 3) differ by one float32 ulp where a value sits next to a rounding
+    # boundary: never more than that
+    assert (rf0 != gf0).mean() < 1e-2 and (rsp != gsp).mean() < 0.15 and (rap != gap).mean() < 1e-2
+    np.testing.assert_allclose(gsp, rsp, rtol=3e-7, atol=0)
+    np.testing.assert_allclose(gap, rap, rtol=3e-7, atol=1e-12)
+    rl, rm, rb = analysis_files(a_ref, wav, tmp_path, "refc", (5, F, 50, 25))
+    gl, gm, gb = analysis_files(a_gpu, wav, tmp_path, "gpuc", (5, F, 50, 25))
+    np.testing.assert_allclose(gl, rl, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(gm, rm, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(gb, rb, atol=2e-6, rtol=0)
+    names = [tmp_path / f"ref.{e}" for e in ("f0", "sp", "ap")]
+    run(s_ref, *names, tmp_path / "ref_y.wav", 5, F, fs)
+    run(s_gpu, *names, tmp_path / "gpu_y.wav", 5, F, fs)
+    yr, fr = read_wav(tmp_path / "ref_y.wav")
+    yg, fg = read_wav(tmp_path / "gpu_y.wav")
+    assert fr == fg == fs and yr.shape == yg.shape
+    assert np.abs(yr - yg).max() <= 1 and (yr != yg).mean() < 1e-3

@@ -59,6 +59,66 @@ def test_harvest_vs_reference_vectors(oracle, name):
     np.testing.assert_allclose(f0, g["f0"], atol=1e-8, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["real_arctic_a0001", "real_vaiueo2d"])
+def test_real_speech_vs_reference_vectors(oracle, name):
+    """The reference's own two wav files (wav_test/arctic_a0001.wav = SURVEY.md's config 1, test/vaiueo2d.wav):
+    the fixture holds their int16 samples and the compiled reference's outputs on them."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = g["x_i16"].astype(np.float64) / 32768.0
+    fs, fp, F = int(g["fs"]), float(g["frame_period"]), int(g["fft_size"])
+    t, f0_dio = oracle.dio(x, fs, fp)
+    np.testing.assert_array_equal(t, g["t"])
+    assert ((f0_dio > 0) == (g["f0_dio"] > 0)).all()
+    np.testing.assert_allclose(f0_dio, g["f0_dio"], atol=1e-7, rtol=0)
+    f0 = oracle.stonemask(x, fs, g["t"], g["f0_dio"])
+    np.testing.assert_allclose(f0, g["f0"], atol=1e-8, rtol=0)
+    th, f0_hv = oracle.harvest(x, fs, fp)
+    assert ((f0_hv > 0) == (g["f0_harvest"] > 0)).all()
+    np.testing.assert_allclose(f0_hv, g["f0_harvest"], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(oracle.stonemask(x, fs, g["t"], g["f0_harvest"]), g["f0_harvest_sm"], atol=1e-8, rtol=0)
+    fs_, ss = int(g["frame_step"]), int(g["sample_step"])
+    sp = oracle.cheaptrick(x, fs, g["t"], g["f0"], -0.15, F)
+    np.testing.assert_allclose(sp[::fs_], g["sp_sub"], rtol=1e-7, atol=1e-13)
+    np.testing.assert_allclose(checks(sp), g["sp_check"], rtol=1e-9)
+    ap = oracle.d4c(x, fs, g["t"], g["f0"], F, 0.0)
+    np.testing.assert_allclose(ap[::fs_], g["ap_sub"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(checks(ap), g["ap_check"], rtol=1e-9)
+    ap85 = oracle.d4c(x, fs, g["t"], g["f0"], F, 0.85)
+    np.testing.assert_allclose(ap85[::fs_], g["ap85_sub"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(checks(ap85), g["ap85_check"], rtol=1e-9)
+    y = oracle.synthesis(g["f0"], sp, ap, F, fp, fs)
+    np.testing.assert_allclose(y[::ss], g["y_sub"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(checks(y), g["y_check"], rtol=1e-7)
+    # Harvest's contour through the same back end
+    sp_h = oracle.cheaptrick(x, fs, g["t"], g["f0_harvest_sm"], -0.15, F)
+    ap_h = oracle.d4c(x, fs, g["t"], g["f0_harvest_sm"], F, 0.85)
+    np.testing.assert_allclose(checks(sp_h), g["sp_h_check"], rtol=1e-9)
+    np.testing.assert_allclose(checks(ap_h), g["ap_h_check"], rtol=1e-9)
+    y_h = oracle.synthesis(g["f0_harvest_sm"], sp_h, ap_h, F, fp, fs)
+    np.testing.assert_allclose(y_h[::ss], g["y_h_sub"], atol=1e-9, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["options_16k", "options_22k", "options_48k"])
+def test_option_sweep_vs_reference_vectors(oracle, name):
+    """CheapTrickOption.q1 / fft_size away from the defaults, D4C and Synthesis at that size
+    (cheaptrick.cpp:200-228, d4c.cpp:337-397, synthesis.cpp:338-397)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = g["x_i16"].astype(np.float64) / 32768.0
+    fs, fp, fs_, ss = int(g["fs"]), float(g["frame_period"]), int(g["frame_step"]), int(g["sample_step"])
+    for F in (int(v) for v in g["fft_sizes"]):
+        ap = oracle.d4c(x, fs, g["t"], g["f0"], F, 0.85)
+        np.testing.assert_allclose(ap[::fs_], g["ap_%d_sub" % F], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(checks(ap), g["ap_%d_check" % F], rtol=1e-9)
+        for qi, q1 in enumerate(g["q1"]):
+            sp = oracle.cheaptrick(x, fs, g["t"], g["f0"], float(q1), F)
+            np.testing.assert_allclose(sp[::fs_], g["sp_%d_q%d_sub" % (F, qi)], rtol=1e-7, atol=1e-13)
+            np.testing.assert_allclose(checks(sp), g["sp_%d_q%d_check" % (F, qi)], rtol=1e-9)
+            if qi == 1:
+                y = oracle.synthesis(g["f0"], sp, ap, F, fp, fs)
+                np.testing.assert_allclose(y[::ss], g["y_%d_sub" % F], atol=1e-9, rtol=0)
+                np.testing.assert_allclose(checks(y), g["y_%d_check" % F], rtol=1e-7)
+
+
 def recipe_pack(o, f0, sp, ap, fs, F, spec_dim, ap_dim=25):
     """test/analysis.cpp:292-366 around the coder (scaling, offsets, log f0, float32)."""
     sp4 = sp * 1e4

@@ -133,3 +133,49 @@ def test_unusual_inputs(oracle, reference, name):
             np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-300)
         else:
             np.testing.assert_allclose(a, b, atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("fs,index,dur", [(16000, 45, 1.0), (22050, 24, 0.8), (48000, 49, 0.6)])
+def test_cheaptrick_d4c_synthesis_options(oracle, reference, fs, index, dur):
+    """CheapTrickOption.q1 / fft_size away from their defaults, D4C and Synthesis at that size, full arrays
+    (cheaptrick.cpp:191-228, d4c.cpp:337-397, synthesis.cpp:338-397); the same grid as
+    tests/test_gpu_real_speech_and_options.py runs on the HIP path."""
+    x = sd.make_utterance(index, fs, duration=dur)
+    t, f0 = reference.dio(x, fs)
+    f0 = reference.stonemask(x, fs, t, f0)
+    d = reference.cheaptrick_fft_size(fs)
+    below = 0
+    for F in (d, 2 * d, d // 2):
+        below += int(((f0 > 0) & (f0 <= 3.0 * fs / (F - 3.0))).sum())
+        apr, apo = reference.d4c(x, fs, t, f0, F, 0.85), oracle.d4c(x, fs, t, f0, F, 0.85)
+        assert apr.shape == (len(f0), F // 2 + 1)
+        np.testing.assert_allclose(apo, apr, atol=1e-9, rtol=0)
+        for q1 in (-0.15, -0.09, 0.0):
+            spr, spo = reference.cheaptrick(x, fs, t, f0, q1, F), oracle.cheaptrick(x, fs, t, f0, q1, F)
+            np.testing.assert_allclose(spo, spr, rtol=1e-7, atol=1e-13)
+        yr, yo = reference.synthesis(f0, spr, apr, F, 5.0, fs), oracle.synthesis(f0, spr, apr, F, 5.0, fs)
+        np.testing.assert_allclose(yo, yr, atol=1e-9, rtol=0)
+    assert below > 0                                               # the default-f0 branch of cheaptrick.cpp:217 ran
+
+
+def test_reference_wavs(oracle, reference):
+    """The reference's own two inputs, read where they lie (this container only)."""
+    import os
+    import wave
+    W = "/root/reference/externs/WORLD_v2"
+    for path in (W + "/wav_test/arctic_a0001.wav", W + "/test/vaiueo2d.wav"):
+        if not os.path.exists(path):
+            pytest.skip("reference tree not present")
+        with wave.open(path, "rb") as w:
+            fs = w.getframerate()
+            x = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float64) / 32768.0
+        tr, fr = reference.dio(x, fs)
+        to, fo = oracle.dio(x, fs)
+        assert ((fr > 0) == (fo > 0)).all()
+        np.testing.assert_allclose(fo, fr, atol=1e-7, rtol=0)
+        r2, o2 = reference.stonemask(x, fs, tr, fr), oracle.stonemask(x, fs, tr, fr)
+        np.testing.assert_allclose(o2, r2, atol=1e-9, rtol=0)
+        th, hr = reference.harvest(x, fs)
+        th, ho = oracle.harvest(x, fs)
+        assert ((hr > 0) == (ho > 0)).all()
+        np.testing.assert_allclose(ho, hr, atol=1e-8, rtol=0)
