@@ -69,25 +69,27 @@ struct Context {
 // of Synthesis runs beside CheapTrick and D4C) delays a whole share by that much: the launch ends late by the
 // overlap.  With a few workgroups per slot the hardware dispatcher hands the shares out as slots become free; the
 // price is a last round that is not full (at most one share of 1 / oversub of a slot's work).
-// The occupancy query is made once per (device, kernel) -- a process may hold contexts on several GPUs -- and
-// remembered (context.cpp); `slot` is 0 for "never asked".
-int& occupancy_slot(int device, const void* kernel);
+// The occupancy query is made once per (device, kernel, block size) -- a process may hold contexts on several GPUs --
+// and remembered (context.cpp).  slot_get / slot_raise read and update an entry under the table's lock: two threads
+// that drive contexts concurrently may both ask the runtime the first time, neither reads a half-written value.
+int slot_get(int device, const void* kernel, int tag);                 // 0 = never set
+int slot_raise(int device, const void* kernel, int tag, int value);    // entry = max(entry, value); returns the old entry
 template <class K> inline int persistent_grid(const Context& c, K kernel, int block, int64_t items) {
-  int& per_cu = occupancy_slot(c.device, (const void*)kernel);
+  int per_cu = slot_get(c.device, (const void*)kernel, block);
   if (per_cu == 0) {
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, block, 0) != hipSuccess || q < 1) q = 4;
     per_cu = q;
+    (void)slot_raise(c.device, (const void*)kernel, block, q);
   }
   const int64_t g = (int64_t)c.num_cu * per_cu * c.oversub;
   return (int)(items < g ? items : g);
 }
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize): once per (device, kernel), and again whenever a launch asks for more
+// than the largest size granted so far (hv_refine_kernel's size varies with the batch).
 template <class K> inline void allow_dynamic_lds(const Context& c, K kernel, int bytes) {
-  int& done = occupancy_slot(c.device, (const void*)((const char*)(const void*)kernel + 1));   // its own key
-  if (done) return;
+  if (slot_raise(c.device, (const void*)kernel, -1, bytes) >= bytes) return;
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done = 1;
 }
 
 // Every entry point that takes a batch or a context runs on the context's device, whatever device is current on

@@ -167,6 +167,13 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
       wm::set_error("CreateBatch: negative length");
       return WM_ERR_BAD_ARG;
     }
+    if (x_lengths && b.x_len[u] == 0) {
+      // the reference's caller refuses a wav without samples (test/analysis.cpp:252-259); the kernels clamp their
+      // loads into [0, x_length - 1], which an empty utterance does not have
+      delete hb;
+      wm::set_error("CreateBatch: an utterance has no samples");
+      return WM_ERR_BAD_ARG;
+    }
     b.x_off[u + 1] = b.x_off[u] + b.x_len[u];
     b.f_off[u + 1] = b.f_off[u] + b.f0_len[u];
     b.y_off[u + 1] = b.y_off[u] + b.y_len[u];
@@ -659,7 +666,7 @@ int GetNumberOfAperiodicities(int fs) { return codec_num_aperiodicities(fs); }  
 
 namespace {
 // a frames-only batch: the codec needs fs, fft_size and the frame count
-WorldMi355Batch* codec_batch(int fs, int fft_size, int f0_length) {
+static WorldMi355Batch* codec_batch(int fs, int fft_size, int f0_length) {   // C linkage ignores the namespace
   WorldMi355Params p;
   WorldMi355DefaultParams(fs, 5.0, &p);
   p.fft_size = fft_size;

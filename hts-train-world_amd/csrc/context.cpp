@@ -129,11 +129,32 @@ void dev_free(void* p) {
 }
 
 void dev_cache_trim(size_t keep_bytes) { trim_locked_out(keep_bytes, -1); }
-int& occupancy_slot(int device, const void* kernel) {
-  static std::mutex mu;
-  static std::map<std::pair<int, const void*>, int>* slots = new std::map<std::pair<int, const void*>, int>;
-  std::lock_guard<std::mutex> g(mu);
-  return (*slots)[std::make_pair(device, kernel)];      // std::map nodes do not move: the reference stays valid
+namespace {
+struct SlotKey {
+  int device;
+  const void* kernel;
+  int tag;                 // block size of an occupancy entry, -1 for the dynamic-LDS entry
+  bool operator<(const SlotKey& o) const {
+    return device != o.device ? device < o.device : kernel != o.kernel ? kernel < o.kernel : tag < o.tag;
+  }
+};
+std::mutex g_slot_mu;
+std::map<SlotKey, int>& slot_table() {
+  static std::map<SlotKey, int>* t = new std::map<SlotKey, int>;   // never destroyed: used from atexit paths
+  return *t;
+}
+}  // namespace
+int slot_get(int device, const void* kernel, int tag) {
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  auto it = slot_table().find(SlotKey{device, kernel, tag});
+  return it == slot_table().end() ? 0 : it->second;
+}
+int slot_raise(int device, const void* kernel, int tag, int value) {
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  int& e = slot_table()[SlotKey{device, kernel, tag}];
+  const int old = e;
+  if (value > e) e = value;
+  return old;
 }
 const char* last_error() { return g_last_error.c_str(); }
 void set_error(const char* msg) { g_last_error = msg; }

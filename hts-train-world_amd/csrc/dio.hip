@@ -81,7 +81,7 @@ __device__ __forceinline__ double dio_y(const double* __restrict__ xu, int n, in
   // the load is unconditional (clamped address) and the case is applied to the VALUE: with the load behind a branch
   // the elements of a block are fetched one dependent trip at a time (32 pairs per lane at block 4096: the low-cut
   // kernel took 4.4 ms at 48 kHz)
-  const double xv = xu[imin(n - 1, imax(0, i))];
+  const double xv = xu[imax(0, imin(n - 1, i))];              // n >= 1: CreateBatch refuses empty utterances
   return i < n ? xv - mean : (i < ylen ? 0.0 - mean : 0.0);
 }
 

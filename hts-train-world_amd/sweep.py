@@ -70,7 +70,7 @@ class ShardedSweep:
         self.params = W.default_params(self.fs, self.fp)
         self.loaded = []                 # [(WorldBatch, x on device)] for this rank's batches
         self._pinned = {}                # rank 0's host staging of the gathered slabs
-        self._items = {}                 # (round, sink) -> the native writer's list for that round
+        self._items = {}                 # round -> (sink, pinned pointers, the native writer's list for that round)
         self._write_busy = 0.0
         self.total_frames = sum(self.frames)
         self.my_frames = sum(self.frames[i] for i in self.shards[rank])
@@ -95,6 +95,7 @@ class ShardedSweep:
         for b, _ in self.loaded:
             b.close()
         self.loaded = []
+        self._items = {}                 # the write lists hold views of the pinned slabs and their sinks
 
     # ---- one pass ---------------------------------------------------------------------------------------------
     def _features(self, b, x):
@@ -127,8 +128,10 @@ class ShardedSweep:
         the native writer; any other sink is called per utterance from the pool."""
         native = hasattr(sink, "paths")
         cached = self._items.get(key) if (native and key is not None) else None
-        if cached is not None and cached[0] == tuple(h.data_ptr() for h in host):
-            pending.append(pool.submit(self._timed_write, cached[1], io_threads))
+        # a hit needs the SAME sink object (the entry holds it, so its identity cannot be handed to another sink
+        # while the entry lives) and the same pinned slabs
+        if cached is not None and cached[0] is sink and cached[1] == tuple(h.data_ptr() for h in host):
+            pending.append(pool.submit(self._timed_write, cached[2], io_threads))
             return
         arrs = [h.numpy() for h in host]
         off = 0
@@ -143,7 +146,7 @@ class ShardedSweep:
                 off = e
         if items:
             if key is not None:
-                self._items[key] = (tuple(h.data_ptr() for h in host), items)
+                self._items[key] = (sink, tuple(h.data_ptr() for h in host), items)
             pending.append(pool.submit(self._timed_write, items, io_threads))
 
     def _timed_write(self, items, io_threads):
@@ -173,7 +176,7 @@ class ShardedSweep:
                 if sink is not None and hosts[k] is not None:
                     if t_first_submit[0] is None:
                         t_first_submit[0] = time.perf_counter()
-                    self._submit(pool, sink, hosts[k], round_groups[k], pending, io_threads, key=(k, id(sink)))
+                    self._submit(pool, sink, hosts[k], round_groups[k], pending, io_threads, key=k)
 
             for k in range(self.rounds):
                 c0, c1, x0, x1, x2 = ev(), ev(), ev(), ev(), ev()

@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libworld_mi355.so")
+# WORLD_MI355_LIB names another build of the same library (tools/ab_lib.sh: A/B runs that leave the in-tree file alone)
+LIB_PATH = os.environ.get("WORLD_MI355_LIB") or os.path.join(HERE, "libworld_mi355.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 

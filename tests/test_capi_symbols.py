@@ -92,3 +92,15 @@ def test_product_library_does_not_link_the_oracle():
         if src.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
             text = open(src).read()
             assert "oracle" not in text.replace("no oracle", ""), src
+
+
+def test_library_exports_only_its_abi():
+    """A library meant to be linked into someone else's binaries exports the WORLD entry points and the WorldMi355*
+    extension, nothing else: no wm:: internals, no kernel handles, no standard-library template instances
+    (csrc/exports.map + -fvisibility=hidden)."""
+    so = os.path.join(ROOT, "hts-train-world_amd", "libworld_mi355.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = declared_symbols()
+    assert exported == {n for n in declared if not n.startswith("WM_")}, sorted(exported ^ declared)[:20]
+    assert len([n for n in exported if not n.startswith("WorldMi355")]) == 19      # WORLD's own names

@@ -135,7 +135,16 @@ def test_relinked_cli_on_the_reference_wavs(gpu, tmp_path, name):
     # sum of LinearSmoothing) differ by one float32 ulp where a value sits next to a rounding
     # boundary: never more than that
     assert (rf0 != gf0).mean() < 1e-2 and (rsp != gsp).mean() < 0.15 and (rap != gap).mean() < 1e-2
-    np.testing.assert_allclose(gsp, rsp, rtol=3e-7, atol=0)
+    # One float32 ulp, plus 2e-14 of the frame's total: LinearSmoothing takes differences of a cumulative sum of the
+    # POWER spectrum (common.cpp:38-41, 99-108; harmonic peaks well above the envelope), so a bin 80-110 dB below the
+    # frame's strongest carries the rounding of the whole sum -- in the reference (sequential order) as much as here
+    # (blocked order); tools/sp_quiet_bins.py: bins more than 90 dB down differ by up to 7e-5 relative, 4e-16
+    # absolute, on these two files; the worst case against this bound is 8e-15 of the row sum.
+    rows_r, rows_g = rsp.reshape(len(rf0), -1).astype(np.float64), gsp.reshape(len(rf0), -1).astype(np.float64)
+    excess = np.abs(rows_g - rows_r) - (3e-7 * rows_r + 2e-14 * rows_r.sum(axis=1, keepdims=True))
+    i, j = np.unravel_index(np.argmax(excess), excess.shape)
+    assert excess[i, j] <= 0, "frame %d bin %d: %r against %r, row sum %r, f0 %r" % (i, j, rows_g[i, j], rows_r[i, j],
+                                                                                   rows_r[i].sum(), rf0[i])
     np.testing.assert_allclose(gap, rap, rtol=3e-7, atol=1e-12)
     rl, rm, rb = analysis_files(a_ref, wav, tmp_path, "refc", (5, F, 50, 25))
     gl, gm, gb = analysis_files(a_gpu, wav, tmp_path, "gpuc", (5, F, 50, 25))

@@ -259,6 +259,35 @@ def test_fft_size_4096_above_51khz(gpu, oracle, fs):
     b.close()
 
 
+def test_d4c_default_rows_above_fs_over_16_at_96khz(gpu, oracle):
+    """The one documented gap of D4C (include/world_mi355.h, WM_ERR_UNSUPPORTED_FFT): where its own transform has 8192
+    points, frames with f0 >= fs / 16 keep the default row (the reference analyses them).  Pinned: those frames read
+    1 - 1e-12, every other frame is the oracle's, and the utterance is reported through WM_UTT_D4C_DEFAULT_ROWS;
+    the same f0 values at 48 kHz (transform of 4096 points) are analysed and not flagged."""
+    torch, W, ctx = gpu
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    for fs, flagged in ((96000, True), (48000, False)):
+        x = sd.make_utterance(113, fs, duration=0.25)
+        t = np.arange(int(1000.0 * len(x) / fs / 5.0) + 1) * 0.005
+        f0 = np.full(len(t), 180.0)
+        f0[5] = fs / 16.0 + 50.0
+        f0[11] = fs / 16.0 - 50.0
+        b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x), len(x)])
+        xx, tt = dev(np.concatenate([x, x])), dev(np.concatenate([t, t]))
+        f2 = np.concatenate([f0, np.full(len(t), 180.0)])           # the second utterance has no such frame
+        ap = b.d4c(xx, tt, dev(f2))
+        st = b.utterance_status(xx, dev(f2), None, ap).cpu().numpy()
+        assert list(st) == ([8, 0] if flagged else [0, 0])
+        got = b.split_frames(ap)[0].cpu().numpy()
+        want = oracle.d4c(x, fs, t, f0, b.fft_size, 0.0)
+        keep = np.ones(len(t), dtype=bool)
+        if flagged:
+            keep[5] = False
+            assert np.all(got[5] == 1.0 - 1e-12) and not np.all(want[5] == 1.0 - 1e-12)
+        np.testing.assert_allclose(got[keep], want[keep], atol=AP_TOL, rtol=0)
+        b.close()
+
+
 @pytest.mark.parametrize("fs,fp", [(16000, 1.0), (16000, 10.0), (16000, 2.5), (22050, 3.0), (48000, 4.0)])
 def test_other_frame_periods(gpu, oracle, fs, fp):
     """Frame periods other than 5 ms, including ones that are not a whole number of samples (rounding ties)."""
@@ -860,6 +889,8 @@ def test_errors_are_reported_not_swallowed(gpu):
     with pytest.raises(RuntimeError):
         b.cheaptrick(x, t, f0)
     b.close()
+    with pytest.raises(RuntimeError, match="no samples"):  # as the reference's CLI refuses an empty wav (analysis.cpp:252-259)
+        W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[n, 0, n])
     b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[n])
     T = b.total_frames
     lf0 = torch.zeros(T, dtype=torch.float32, device="cuda")

@@ -216,3 +216,74 @@ def test_recipe_gather_mode_writes_the_same_files(tmp_path):
     for ja, jb in zip(jobs_a, jobs_b):
         for pa, pb in zip(ja[1:], jb[1:]):
             assert open(pa, "rb").read() == open(pb, "rb").read()
+
+
+@pytest.mark.gpu
+def test_full_corpus_sweep_on_one_rank(tmp_path):
+    """configs[3] at its stated size on one rank: 1000 utterances of 2-8 s (1.07 M frames), the recipe's coded
+    files.  Size-independent properties -- one file per utterance and feature, each exactly frames x width x 4
+    bytes, finite, voiced frames in Dio's range -- and the files of the corpus' shortest and longest utterance
+    against the oracle."""
+    line = _bench("--workload", "sweep", "--steps", 1, "--warmup", 0, "--no-cpu-baseline", "--out-dir", tmp_path,
+                  timeout=900)[0]
+    n = 1000
+    assert line["config"]["utterances"] == n and line["n_gpus"] == 1
+    counts = [sd.utterance_samples(i, 16000, (2.0, 8.0)) for i in range(n)]
+    frames = [sh.frame_count(c, 16000, 5.0) for c in counts]
+    assert line["config"]["frames"] == sum(frames)
+    widths = {"lf0": 1, "mgc": 50, "bap": 25}
+    assert sorted(os.listdir(tmp_path)) == sorted(widths)
+    for ext, w in widths.items():
+        names = sorted(os.listdir(tmp_path / ext))
+        assert names == ["utt%05d.%s" % (i, ext) for i in range(n)]
+        sizes = [os.path.getsize(tmp_path / ext / nm) for nm in names]
+        assert sizes == [4 * w * f for f in frames], ext
+    lf0 = np.concatenate([np.fromfile(tmp_path / "lf0" / ("utt%05d.lf0" % i), dtype=np.float32) for i in range(n)])
+    assert np.isfinite(lf0).all()
+    v = lf0[lf0 != 0]
+    # StoneMask moves Dio's 71-800 Hz estimates; what it lets through lies in (40 Hz, fs / 12] (stonemask.cpp:186-187)
+    assert 0.5 < len(v) / len(lf0) < 0.9 and np.log(40.0) < v.min() and v.max() <= np.log(16000 / 12.0) + 1e-6
+    for ext in ("mgc", "bap"):
+        for i in (0, n // 2, n - 1):
+            assert np.isfinite(np.fromfile(tmp_path / ext / ("utt%05d.%s" % (i, ext)), dtype=np.float32)).all()
+    from oracle.bindings import Oracle
+    from test_golden import recipe_pack
+    o = Oracle()
+    for i in (int(np.argmin(frames)), int(np.argmax(frames))):
+        x = sd.make_utterance(i, 16000, (2.0, 8.0))
+        t, f0 = o.dio(x, 16000)
+        f0 = o.stonemask(x, 16000, t, f0)
+        sp = o.cheaptrick(x, 16000, t, f0, -0.15, 1024)
+        ap = o.d4c(x, 16000, t, f0, 1024, 0.0)
+        lf0_o, mgc_o, bap_o = recipe_pack(o, f0, sp, ap, 16000, 1024, 50, 25)
+        rd = lambda ext, w: np.fromfile(tmp_path / ext / ("utt%05d.%s" % (i, ext)), dtype=np.float32).reshape(-1, w)
+        assert np.array_equal(rd("lf0", 1)[:, 0] != 0, lf0_o != 0)
+        np.testing.assert_allclose(rd("lf0", 1)[:, 0], lf0_o, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rd("mgc", 50), mgc_o, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(rd("bap", 25), bap_o, rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_a_second_sink_gets_its_own_files(tmp_path):
+    """One ShardedSweep, two DirSinks one after the other (the first dropped before the second is made, so that
+    CPython may hand out the same id): every file lands in the directory of the sink of ITS pass."""
+    W = pkg.world
+    W.load_library()
+    ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+    counts = [sd.utterance_samples(i, 16000, (0.3, 0.9)) for i in range(9)]
+    sw = sweep.ShardedSweep(ctx, 16000, 5.0, counts, 0, 1, spec_dim=50, ap_dim=25, rounds=3)
+    sw.load(lambda i: sd.make_utterance(i, 16000, (0.3, 0.9)))
+    for tag in ("first", "second", "third"):
+        sink = sweep.dir_sink(str(tmp_path / tag), ("lf0", "mgc", "bap"))
+        sw.run(sink)
+        sw.run(sink)                                  # the cached write list of the same sink is reused
+        del sink
+    for tag in ("first", "second", "third"):
+        for ext in ("lf0", "mgc", "bap"):
+            assert len(os.listdir(tmp_path / tag / ext)) == 9, (tag, ext)
+    a = [open(tmp_path / "first" / "mgc" / ("utt%05d.mgc" % i), "rb").read() for i in range(9)]
+    b = [open(tmp_path / "third" / "mgc" / ("utt%05d.mgc" % i), "rb").read() for i in range(9)]
+    assert a == b and all(len(v) > 0 for v in a)
+    sw.close()
+    assert sw._items == {}
+    ctx.close()

@@ -3,6 +3,10 @@
 #   tools/ab.sh "synthesis" [bench args...]
 set -e
 names="$1"; shift
+root="$(cd "$(dirname "$0")/.." && pwd)"
+# whatever happens (a bench run that times out, a JSON line that does not parse), the tree ends with the plain build
+restore() { cd "$root/hts-train-world_amd/csrc" && for n in $names; do touch $n.hip; done && make -s > "$root/gpurun_out/ab_make2.log" 2>&1; }
+trap restore EXIT
 run() { timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-side --cpu-utts 2 "$@" > gpurun_out/ab_$tag.log 2>&1
   python - <<PY
 import json
@@ -18,8 +22,6 @@ make -s EXTRA=-DWM_AB > ../../gpurun_out/ab_make.log 2>&1
 cd ../..
 tag=B; run "$@"
 tag=B2; run "$@"
-cd hts-train-world_amd/csrc
-for n in $names; do touch $n.hip; done
-make -s > ../../gpurun_out/ab_make2.log 2>&1
-cd ../..
+restore
+cd "$root"
 tag=A2; run "$@"
