@@ -159,12 +159,17 @@ def parse():
                     help="sweep: write raw float32 f0/sp/ap (4.1 KB per frame) instead of what the recipe's own call writes "
                          "(data/Makefile.in:214: coded lf0 / mgc[50] / bap[25], 304 B per frame)")
     ap.add_argument("--coded", action="store_true", help="sweep: the default since round 3 (kept for older command lines)")
-    ap.add_argument("--rounds", type=int, default=4,
-                    help="sweep: batches per rank; one round is gathered, copied and written while the next is analysed")
+    ap.add_argument("--rounds", type=int, default=0,
+                    help="sweep: batches per rank; one round is gathered, copied and written while the next is analysed.  "
+                         "0 = auto: as many rounds as keep a rank's batch at about 35 k frames or more (a batch must "
+                         "still fill the GPU), between 4 and 16 -- the more rounds, the smaller the one round of rank 0's "
+                         "copy + write that no compute hides")
     ap.add_argument("--writers", choices=("rank0", "all"), default="rank0",
                     help="sweep: rank0 = configs[3] as stated (gather-v, rank 0 writes everything); all = no gather, every "
                          "rank writes its own shard's files (shows what the rank-0 funnel costs)")
-    ap.add_argument("--io-threads", type=int, default=0, help="sweep: file-writing threads (0 = one per host core, 4..32)")
+    ap.add_argument("--io-threads", type=int, default=0,
+                    help="sweep: file-writing threads on the writing rank (0 = one per host core of the node, 4..64; "
+                         "with --writers all the cores are shared out over the ranks)")
     ap.add_argument("--plan-only", action="store_true",
                     help="print this rank's share of the workload as JSON and exit without touching the GPU")
     ap.add_argument("--out-dir", default=None, help="sweep: where rank 0 writes the feature files (default: a fresh temp dir, removed afterwards)")
@@ -226,6 +231,34 @@ class Env:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         return float(tmax[0]), float(tsum[1])
+
+    def comm_record(self):
+        """What the communicator itself reports at N > 1 (every rank calls this; rank 0 keeps the result): backend,
+        the world size as torch.distributed sees it, the RCCL version, and one entry per rank -- device index, name,
+        PCI bus id -- gathered THROUGH the communicator, so that a scaling record proves N ranks on N devices took part."""
+        if self.world == 1:
+            return None
+        torch, dist = self.torch, self.dist
+        dev = torch.cuda.current_device()
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": self.rank, "device": dev, "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename}
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine)
+        # a collective that every rank must take part in: the sum of (rank + 1) over the communicator
+        chk = torch.tensor([float(self.rank + 1)], dtype=torch.float64,
+                           device="cuda" if self.args.backend == "nccl" else "cpu")
+        dist.all_reduce(chk)
+        ver = None
+        if self.args.backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                       # noqa: BLE001 -- a record, not a dependency
+                ver = "unavailable: %s" % e
+        return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "version": ver,
+                "library": "RCCL (torch.distributed backend nccl on ROCm)" if self.args.backend == "nccl" else "gloo (rehearsal)",
+                "all_reduce_of_rank_plus_1": float(chk[0]), "expected": self.world * (self.world + 1) / 2.0,
+                "devices": everyone}
 
     def rehearsal_note(self):
         if self.shared_gpu or (self.world > 1 and self.args.backend == "gloo"):
@@ -403,11 +436,25 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
         env.barrier()
         eg, _ = env.reduce(time.perf_counter() - t0, frames)
         per_rank = 4 * frames * (1 + 2 * batch.bins)
+        # the exchange alone (features already computed): what the links into rank 0 carry
+        f0_, sp_, ap_ = compute()
+        gather(f0_, sp_, ap_)
+        env.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gather(f0_, sp_, ap_)
+        env.barrier()
+        ego, _ = env.reduce(time.perf_counter() - t0, frames)
+        del f0_, sp_, ap_
         with_gather = {"value": round(total_frames * args.steps / eg, 1), "unit": "frames/s",
                        "ms_per_step": round(eg / args.steps * 1e3, 3),
                        "gathered_bytes_per_step": per_rank * (world - 1),
-                       "note": "analysis + synthesis, then float32 f0/sp/ap of every rank gathered to rank 0 (%s)"
+                       "gather_alone_ms": round(ego / args.steps * 1e3, 3),
+                       "gather_alone_gbs_into_rank0": round(per_rank * (world - 1) * args.steps / ego / 1e9, 2),
+                       "note": "analysis + synthesis, then float32 f0/sp/ap of every rank gathered to rank 0 (%s); "
+                               "gather_alone includes the float64 -> float32 conversion of the slabs"
                                % ("RCCL send/recv" if args.backend == "nccl" else "gloo rehearsal")}
+    comm = env.comm_record()
     hi = host_inclusive(env, ctx, xs, fs, fp)
     hic = host_inclusive(env, ctx, xs, fs, fp, coded=(50, 25))
 
@@ -420,9 +467,11 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
                             "frac_hbm": round(value / world * bm["round_trip"] / 1e9 / HBM_PEAK_GBS, 6),
                             "achieved_fp64_tflops": round(value / world * FLOPS_PER_FRAME / 1e12, 4) if fs == 16000 else None}
         cpu = None
+        cpu_o2 = None
         parity = None
         if world == 1 and not args.no_cpu_baseline:
             cpu, parity = cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, args.cpu_utts)
+            cpu_o2 = cpu_baseline_o2(xs, fs, fp, batch.fft_size, args.cpu_utts)
         line = {
             "metric": "WORLD analysis+synthesis frames/sec @%dkHz, 5ms hop" % (fs // 1000),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -446,8 +495,12 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
             line["config"]["note"] = env.rehearsal_note()
         if with_gather:
             line["with_gather"] = with_gather
+        if comm:
+            line["rccl"] = comm
         line["host_inclusive"] = hi
         line["host_inclusive_coded"] = hic
+        if cpu_o2:
+            line["cpu_baseline_O2"] = cpu_o2
         if cpu_all:
             line["cpu_baseline_all_cores"] = cpu_all
         if parity:
@@ -487,7 +540,7 @@ def compact(line):
            "config": {"workload": line["config"]["workload"], "frames": line["config"].get("frames_per_gpu",
                                                                                            line["config"].get("frames"))},
            "roofline": keep_roof, "cpu_baseline": line.get("cpu_baseline"), "parity": line.get("parity")}
-    for k in ("phases_ms_per_step", "predicted", "value_compute_only"):
+    for k in ("phases_ms_per_step", "host_side", "predicted", "value_compute_only"):
         if k in line:
             out[k] = line[k]
     return out
@@ -604,6 +657,10 @@ def d4c_roofline(kernel_ms, frames, voiced, fs, bm, steps, workload="analysis_sy
 # ------------------------------------------------------------------------------------------------------------------
 # configs[3]: the corpus sweep
 # ------------------------------------------------------------------------------------------------------------------
+def sh_frames(n, fs, fp):
+    return int(1000.0 * n / fs / fp) + 1                      # GetSamplesForDIO, dio.cpp:638-640
+
+
 def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     """configs[3]: the data/ feature-extraction sweep over a fixed corpus (data/Makefile.in:125-242), sharded over the
     ranks; one step = every rank analyses its shard, the float32 feature slabs are gathered to rank 0, rank 0 writes
@@ -614,8 +671,12 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     args, torch, dist, pkg = env.args, env.torch, env.dist, env.pkg
     rank, world = env.rank, env.world
     W, sweep = pkg.world, pkg.sweep
+    rounds = args.rounds
+    if rounds <= 0:                                   # auto (see --rounds)
+        per_rank = sum(sh_frames(n, fs, fp) for n in counts) / float(world)
+        rounds = int(max(4, min(16, per_rank // 35000)))
     sw = sweep.ShardedSweep(ctx, fs, fp, counts, rank, world, spec_dim=50 if args.coded else 0, ap_dim=25,
-                            backend=args.backend, rounds=args.rounds, writers=args.writers)
+                            backend=args.backend, rounds=rounds, writers=args.writers)
     mine = sw.shards[rank]
     sw.load(lambda i: by_id[i])
     out_dir = None
@@ -633,7 +694,9 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     if out_dir:
         names = ("lf0", "mgc", "bap") if args.coded else ("f0", "sp", "ap")
         sink = sweep.dir_sink(out_dir, names)
-    io_threads = args.io_threads or None
+    ncpu = os.cpu_count() or 8
+    io_threads = args.io_threads or max(4, min(64, ncpu if args.writers == "rank0" else ncpu // max(1, world)))
+    comm = env.comm_record()
 
     for _ in range(warmup):
         sw.run(sink, io_threads)
@@ -674,6 +737,7 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
         c8 = comp_max / k / 8.0
         host_side = (phases["to_host"] + phases["gather"]) / k
         wr = phases["write"] / k
+        n_files = 3 * len(counts)
         pred8 = max(c8, host_side, wr) + (c8 + host_side + wr - max(c8, host_side, wr)) / R
         line = {
             "metric": "WORLD analysis sweep frames/sec @16kHz, 5ms hop (corpus -> float32 feature files on rank 0)",
@@ -697,15 +761,24 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
                                    "pass_wall_rank0": ms(phases["wall"]),
                                    "note": "busy times per stage (HIP events per stream; writes: time inside the native "
                                            "writer); they overlap inside pass_wall"},
+            "host_side": {"cpu_count": ncpu, "writer_threads": io_threads, "files_per_step": n_files,
+                          "files_per_s": round(n_files / wr, 1) if wr > 0 else None,
+                          "write_gbs": round(total * per_frame_out / wr / 1e9, 2) if wr > 0 else None,
+                          "to_host_gbs": round(total * per_frame_out / (phases["to_host"] / k) / 1e9, 2)
+                          if phases["to_host"] > 0 else None},
             "predicted": {"ranks": 8, "ms_per_step": round(pred8 * 1e3, 3),
                           "speedup_over_this_run": round(elapsed_max / steps / pred8, 2) if world == 1 and pred8 > 0 else None,
+                          "host_cores_assumed": ncpu, "writer_threads_assumed": io_threads,
                           "model": "max(compute/8, gather + to_host, write) + (the other two stages) / rounds, from "
-                                   "this run's phases; rank 0 keeps the host side"},
+                                   "this run's phases; rank 0 keeps the host side at THIS box's cores (the writes are "
+                                   "page-cache fills: they scale with the writer threads, 4..64, one per host core)"},
             "value_compute_only": round(total * k / comp_max, 1) if comp_max > 0 else None,
             "roofline": roof, "cpu_baseline": None,
         }
         if env.rehearsal_note():
             line["config"]["note"] = env.rehearsal_note()
+        if comm:
+            line["rccl"] = comm
         if world == 1 and cpu:
             line["cpu_baseline"], line["parity"] = sweep_cpu_baseline(by_id, mine, fs, fp, out_dir, args)
         if not args.out_dir:
@@ -1063,6 +1136,33 @@ def cpu_all_cores(xs, fs, fp, cores, n_utts):
                       "(%.1f s wall with start-up)" % (jobs[-1][1], frames, len(jobs), slowest, wall)}
 
 
+def cpu_baseline_o2(xs, fs, fp, F, n_cpu, budget_s=10.0):
+    """The reference's sources compiled at -O2 (oracle/_ref/libworld_ref_O2.so; SURVEY.md 8(d) asks for the CPU
+    baseline at the shipped -O1 and at -O2), single thread, on the first utterances of the same batch.  Timing only:
+    parity is taken against the shipped flags."""
+    from oracle.bindings import Reference
+    if not Reference.available(o2=True):
+        return None
+    lib = Reference(o2=True)
+    frames, cpu_time, n = 0, 0.0, 0
+    for x in xs[:n_cpu]:
+        a = time.perf_counter()
+        t, f0 = lib.dio(x, fs, fp)
+        f0 = lib.stonemask(x, fs, t, f0)
+        sp = lib.cheaptrick(x, fs, t, f0, -0.15, F)
+        ap = lib.d4c(x, fs, t, f0, F, 0.0)
+        lib.synthesis(f0, sp, ap, F, fp, fs)
+        cpu_time += time.perf_counter() - a
+        frames += len(f0)
+        n += 1
+        if cpu_time > budget_s:
+            break
+    return {"value": round(frames / cpu_time, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "flags": "-O2 (the reference ships -O1, externs/WORLD_v2/makefile:5: that build is cpu_baseline)",
+            "sample": "first %d utterances of the same batch (%d frames), Dio+StoneMask+CheapTrick+D4C+Synthesis, "
+                      "single thread, %.1f s" % (n, frames, cpu_time)}
+
+
 def cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, n_cpu):
     """Time the CPU path single-threaded on the first n_cpu utterances of the same workload and
     check the GPU results of those utterances against it (the checker, never the thing shipped)."""
@@ -1099,6 +1199,7 @@ def cpu_baseline_and_parity(xs, fs, fp, batch, outs, y, n_cpu):
             n_cpu = u + 1
             break
     cpu = {"value": round(frames / cpu_time, 1), "unit": "frames/s", "cores": 1, "kind": lib.kind,
+           "flags": "-O1 -g (the reference's own, externs/WORLD_v2/makefile:5)" if lib.kind == "reference" else "-O2 (oracle/Makefile)",
            "sample": "first %d utterances of the same batch (%d frames), Dio+StoneMask+CheapTrick+D4C+Synthesis, "
                      "single thread, %.1f s" % (n_cpu, frames, cpu_time)}
     parity = {"vs": lib.kind, "utterances": n_cpu, "max_abs_dF0_hz": df0, "sp_rmse": (se_sp / cnt) ** 0.5,

@@ -110,15 +110,18 @@ class ShardedSweep:
         valid until run() returns).  Returns the phase times in seconds on this rank: compute, gather, to_host, write
         (the last two are zero off rank 0) and, from the pipelined form, `wall`.
 
-        With the features on the GPU (one rank, or RCCL) the pass is a pipeline over the rounds: round k+1 is
-        analysed on the compute stream while round k's slabs are gathered and copied to pinned host memory on a
-        second stream and round k-1's files are being written by the pool; the phases are then busy times (HIP
-        events per stream, the pool's first submit to last completion) that overlap inside `wall`."""
+        With the features on the GPU the pass is a pipeline over the rounds: round k+1 is analysed on the compute
+        stream while round k's slabs are gathered and copied to pinned host memory on a second stream and round
+        k-1's files are being written by the pool; the phases are then busy times (HIP events per stream, the pool's
+        first submit to last completion) that overlap inside `wall`.  Over gloo (the rehearsal of N ranks on one GPU)
+        the same pipeline runs with the two transfer steps swapped: every rank copies its round to pinned host
+        memory on the second stream and the gather-v of round k is the host collective issued while round k+1 is
+        on the GPU."""
         import torch
         if io_threads is None:
-            io_threads = max(4, min(32, (os.cpu_count() or 8)))
+            io_threads = max(4, min(64, (os.cpu_count() or 8)))     # page-cache fills: they scale with the cores
         on_gpu = torch.cuda.is_available() and self.ctx is not None
-        if on_gpu and (self.world == 1 or self.backend != "gloo" or self.writers == "all"):
+        if on_gpu:
             return self._run_pipelined(sink, io_threads)
         return self._run_serial(sink, io_threads)
 
@@ -162,6 +165,9 @@ class ShardedSweep:
             self._xfer = torch.cuda.Stream()
         xfer = self._xfer
         me_writes = self.rank == 0 or self.writers == "all"
+        host_gather = self.world > 1 and self.backend == "gloo" and self.writers != "all"
+        gather_busy = [0.0]
+        round_counts = []
         ev = lambda: torch.cuda.Event(enable_timing=True)
         marks = []                                     # per round: (compute start, compute end, transfer start, gathered, on host)
         hosts, round_groups, keep = [], [], []
@@ -173,6 +179,12 @@ class ShardedSweep:
             def drain(k):
                 """round k is on the host: hand its utterances to the writers"""
                 marks[k][4].synchronize()
+                if host_gather:                        # every rank, every round, in the same order: a collective
+                    tg = time.perf_counter()
+                    res = sharding.gather_features(hosts[k], round_counts[k][self.rank], dst=0,
+                                                   all_counts=round_counts[k])
+                    gather_busy[0] += time.perf_counter() - tg
+                    hosts[k] = res[0] if self.rank == 0 else None
                 if sink is not None and hosts[k] is not None:
                     if t_first_submit[0] is None:
                         t_first_submit[0] = time.perf_counter()
@@ -193,6 +205,10 @@ class ShardedSweep:
                         if self.writers == "all":
                             groups = [g if r == self.rank else [] for r, g in enumerate(groups)]
                         got = feats
+                    elif host_gather:
+                        if feats is None:
+                            feats = self._empty()
+                        got = feats                    # down to the host first; drain() gathers over gloo
                     else:
                         if feats is None:
                             feats = self._empty()
@@ -203,7 +219,7 @@ class ShardedSweep:
                         for v in feats:
                             v.record_stream(xfer)
                         keep.append(feats)
-                    if me_writes and got is not None:
+                    if (me_writes or host_gather) and got is not None:
                         host = []
                         for j, v in enumerate(got):
                             # pinned staging, allocated once per (round, array) and reused by later passes
@@ -217,6 +233,7 @@ class ShardedSweep:
                 marks.append((c0, c1, x0, x1, x2))
                 hosts.append(host)
                 round_groups.append(groups)
+                round_counts.append(counts)
                 if k >= 1:
                     drain(k - 1)                      # while round k runs on the GPU
             if self.rounds:
@@ -230,6 +247,8 @@ class ShardedSweep:
             ph["compute"] += c0.elapsed_time(c1) * 1e-3
             ph["gather"] += x0.elapsed_time(x1) * 1e-3
             ph["to_host"] += x1.elapsed_time(x2) * 1e-3
+        if host_gather:
+            ph["gather"] = gather_busy[0]
         if t_first_submit[0] is not None:
             # time inside the native writer when the sink is a DirSink (jobs of different rounds may overlap), else the
             # span from the first submit to the last completion

@@ -458,13 +458,14 @@ class Reference(WorldCApi):
     """The compiled reference plus the primitives it happens to export."""
 
     PATH = os.path.join(HERE, "_ref", "libworld_ref.so")
+    PATH_O2 = os.path.join(HERE, "_ref", "libworld_ref_O2.so")      # same sources at -O2: timing only (bench.py)
 
     @classmethod
-    def available(cls) -> bool:
-        return os.path.exists(cls.PATH)
+    def available(cls, o2: bool = False) -> bool:
+        return os.path.exists(cls.PATH_O2 if o2 else cls.PATH)
 
-    def __init__(self):
-        super().__init__(self.PATH)
+    def __init__(self, o2: bool = False):
+        super().__init__(self.PATH_O2 if o2 else self.PATH)
         L = self.lib
         L.randn.restype = C.c_double
         L.interp1.argtypes = [_dp, _dp, C.c_int, _dp, C.c_int, _dp]

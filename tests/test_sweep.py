@@ -130,19 +130,26 @@ def test_two_rank_sweep_layout(limit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("coded", [False, True])
-def test_two_ranks_write_the_files_of_one_rank(tmp_path, coded):
-    """The sharded sweep (2 ranks, LPT shards, gather-v to rank 0, rank 0 writes) against the single-rank sweep:
-    every file of every utterance bit for bit.  Both ranks share the one GPU of the box, hence gloo."""
+@pytest.mark.parametrize("ranks,coded", [(2, False), (2, True), (4, True)])
+def test_sharded_sweep_writes_the_files_of_one_rank(tmp_path, ranks, coded):
+    """The sharded sweep (2 and 4 ranks, LPT shards, rounds pipelined, gather-v to rank 0, rank 0 writes) against the
+    single-rank sweep: every file of every utterance bit for bit.  The ranks share the one GPU of the box, hence
+    gloo; at 4 ranks with 3 rounds the batch counts are ragged (some ranks run out of batches before others)."""
     extra = [] if coded else ["--raw"]          # coded lf0 / mgc / bap is what the recipe writes, and the default
     common = ["--workload", "sweep", "--utts", 14, "--dur", 0.4, 1.6, "--steps", 1, "--warmup", 0, "--no-cpu-baseline",
-              "--workers", 1]
+              "--workers", 1, "--rounds", 3]
     one = _bench(*common, *extra, "--out-dir", tmp_path / "one")
-    two = _bench(*common, *extra, "--gpus", 2, "--backend", "gloo", "--out-dir", tmp_path / "two")
+    two = _bench(*common, *extra, "--gpus", ranks, "--backend", "gloo", "--out-dir", tmp_path / "two")
     assert len(one) == 1 and len(two) == 1                      # rank 0 prints the one line
-    assert one[0]["n_gpus"] == 1 and two[0]["n_gpus"] == 2 and two[0]["scaling"] == "strong"
+    assert one[0]["n_gpus"] == 1 and two[0]["n_gpus"] == ranks and two[0]["scaling"] == "strong"
     assert two[0]["config"]["frames"] == one[0]["config"]["frames"]
-    assert two[0]["config"]["frames_on_busiest_rank"] < one[0]["config"]["frames"] * 0.6
+    assert two[0]["config"]["frames_on_busiest_rank"] < one[0]["config"]["frames"] * (0.6 if ranks == 2 else 0.35)
+    # what the communicator itself reports: every rank took part
+    rc = two[0]["rccl"]
+    assert rc["world_size"] == ranks and rc["backend"] == "gloo" and len(rc["devices"]) == ranks
+    assert sorted(d["rank"] for d in rc["devices"]) == list(range(ranks))
+    assert rc["all_reduce_of_rank_plus_1"] == rc["expected"] == ranks * (ranks + 1) / 2
+    assert two[0]["host_side"]["files_per_step"] == 14 * 3 and two[0]["predicted"]["host_cores_assumed"] >= 1
     # one directory per feature, as the recipe lays them out (data/Makefile.in:214)
     listing = lambda d: sorted(os.path.join(sub, n) for sub in os.listdir(d) for n in os.listdir(d / sub))
     names = listing(tmp_path / "one")
@@ -196,6 +203,8 @@ def test_headline_line_at_two_ranks_carries_the_gather():
     assert wg["value"] > 0 and wg["ms_per_step"] >= ln["ms_per_step"] * 0.5
     frames = ln["config"]["frames_per_gpu"]
     assert wg["gathered_bytes_per_step"] == 4 * frames * (1 + 2 * 513)      # one peer's f0 + sp + ap, float32
+    assert wg["gather_alone_ms"] > 0 and wg["gather_alone_gbs_into_rank0"] > 0
+    assert ln["rccl"]["world_size"] == 2 and len(ln["rccl"]["devices"]) == 2
     assert ln["roofline"]["kernel"] == "d4c_kernel" and ln["roofline"]["frac"] > 0
 
 
