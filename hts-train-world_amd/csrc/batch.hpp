@@ -191,6 +191,7 @@ struct Batch {
   int* d_pulse_cnt = nullptr;        // [n_utt]
   int* d_pulse_tile_cnt = nullptr;   // [n_utt][tiles] pulses per search tile
   int64_t* d_pulse_off = nullptr;    // [n_utt+1]
+  int* d_pulse_first = nullptr;      // first pulse at or after every 128th sample of an utterance (the overlap-add's table)
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts

@@ -384,14 +384,23 @@ struct PulseVoicedPred {                       // synthesis.cpp:197: the pulses 
   __device__ bool operator()(int i) const { return rec[i].cvuv > 0.5; }
 };
 
+// The overlap-add finds the pulses of a stretch of output samples in a table: first[m] = number (within the
+// utterance) of the first pulse whose index is at least kOlaStep * m, m = 0 .. ceil(ylen / kOlaStep); utterance u owns
+// the entries from ola_table_base(yb, u) on (two spare entries per utterance keep the ranges apart whatever yb is).
+constexpr int kOlaStep = 128;
+__host__ __device__ inline int64_t ola_table_base(int64_t yb, int u) { return yb / kOlaStep + 2 * (int64_t)u; }
+
 __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
     const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
     const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift, const double* __restrict__ vuv,
-    PulseRec* __restrict__ rec) {
+    PulseRec* __restrict__ rec, int* __restrict__ first) {
   const int u = blockIdx.y;
   const int64_t pb = p_off[u];
   const int np = (int)(p_off[u + 1] - pb);
   const int64_t yb = y_off[u];
+  const int ylen = (int)(y_off[u + 1] - yb);
+  int* fu = first + ola_table_base(yb, u);
+  const int m_last = (ylen + kOlaStep - 1) / kOlaStep;
   for (int pi = blockIdx.x * 256 + threadIdx.x; pi < np; pi += gridDim.x * 256) {
     PulseRec r;
     r.fbase = f_off[u];
@@ -402,6 +411,12 @@ __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
     r.shift = pulse_shift[yb + pi];
     r.cvuv = vuv[yb + r.idx];
     rec[pb + pi] = r;
+    // table entries whose sample kOlaStep * m lies in (index of the pulse before, index of this pulse]: every entry
+    // is written by exactly one pulse; the last pulse also writes the entries behind it (= np: no such pulse)
+    const int prev = pi > 0 ? pulse_idx[yb + pi - 1] : -1;
+    for (int m = prev < 0 ? 0 : prev / kOlaStep + 1; m <= imin(m_last, r.idx / kOlaStep); ++m) fu[m] = pi;
+    if (pi == np - 1)
+      for (int m = r.idx / kOlaStep + 1; m <= m_last; ++m) fu[m] = np;
   }
 }
 
@@ -637,61 +652,84 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
 
 // y[n] += sum over pulses p (of this utterance, within [p_begin, p_end)) covering n, in pulse order:
 // index = j + idx - F/2 + 1  (synthesis.cpp:378-383)  ->  j = n - idx + F/2 - 1.
-// A workgroup owns 256 consecutive samples: the pulses that can touch any of them are found once
-// (two uniform binary searches), their indices staged in LDS, and every thread walks that list with
-// four response loads in flight; a pulse that does not cover the thread's sample contributes an exact
-// + 0.0, so the association is still the reference's sequential += in pulse order.
-__global__ __launch_bounds__(256) void synth_ola_kernel(const int64_t* __restrict__ y_off,
-                                                        const int64_t* __restrict__ p_off,
-                                                        const int* __restrict__ pulse_idx, int fft_size,
-                                                        int64_t p_begin, int64_t p_end,
-                                                        const double* __restrict__ resp, double* __restrict__ y) {
-  __shared__ int sidx[256];
+// ONE WAVEFRONT owns a stretch of kOlaSeg consecutive output samples (lane l the pairs 2 l + 128 q, q < kOlaQ) and
+// streams through the response rows of the pulses that reach into it, in pulse order, adding into registers: the
+// association is the reference's sequential += per sample, a row is read once per stretch it touches (1 + F / kOlaSeg
+// stretches: 3 at fft 1024), in 16-byte loads of consecutive lanes.  A chunk of 128 samples that a row does not reach
+// is skipped (wave-uniform), one that it covers whole takes one load per lane, the two at the row's ends two
+// predicated 8-byte loads.  Adding nothing where the round-3 kernel added an exact + 0.0 is the same sum: the
+// accumulator starts from y (+0.0 or a sum) and x + 0.0 == x unless x is -0.0, which a sum starting at +0.0 never is.
+// The pulse range of a stretch comes from the first-pulse table (synth_pulse_rec_kernel), not from a search.
+// Round 3 gave a thread one sample of a tile of 256 and walked every pulse near the tile with 8-byte loads, four in
+// flight: 0.8 TB/s where a stream reads at 6, 15.8 ms busy per configs[4] step beside the pulse kernel.
+constexpr int kOlaQ = 4, kOlaSeg = 128 * kOlaQ, kOlaWaves = 4;
+__global__ __launch_bounds__(64 * kOlaWaves) void synth_ola_kernel(const int64_t* __restrict__ y_off,
+                                                                   const int64_t* __restrict__ p_off,
+                                                                   const int* __restrict__ pulse_idx,
+                                                                   const int* __restrict__ first, int fft_size,
+                                                                   int64_t p_begin, int64_t p_end,
+                                                                   const double* __restrict__ resp,
+                                                                   double* __restrict__ y) {
   const int u = blockIdx.y;
+  const int lane = threadIdx.x & 63;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
-  const int n0 = blockIdx.x * 256;
-  const int n = n0 + threadIdx.x;
-  const int64_t pa = p_off[u] > p_begin ? p_off[u] : p_begin;
-  const int64_t pb = p_off[u + 1] < p_end ? p_off[u + 1] : p_end;
-  if (n0 >= ylen || pa >= pb) return;
+  const int n0 = (blockIdx.x * kOlaWaves + (threadIdx.x >> 6)) * kOlaSeg;      // wave-uniform
+  const int64_t pu = p_off[u];
+  const int np = (int)(p_off[u + 1] - pu);
+  if (n0 >= ylen || np == 0) return;
   const int h = fft_size / 2;
-  const int* pidx = pulse_idx + yb - p_off[u];        // pidx[p] = index of global pulse p
-  // pulses with n0 - h <= idx <= n0 + 255 + h - 1 (uniform)
-  int64_t lo = pa, hi = pb;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (pidx[mid] < n0 - h) lo = mid + 1; else hi = mid;
-  }
-  const int64_t first = lo;
-  hi = pb;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (pidx[mid] <= n0 + 255 + h - 1) lo = mid + 1; else hi = mid;
-  }
-  const int64_t last = lo;                              // one past
-  const bool live = n < ylen;
-  double acc = live ? y[yb + n] : 0.0;
-  for (int64_t base = first; base < last; base += 256) {
-    const int cnt = (int)(last - base < 256 ? last - base : 256);
-    __syncthreads();
-    if ((int)threadIdx.x < cnt) sidx[threadIdx.x] = pidx[base + threadIdx.x];
-    __syncthreads();
-    for (int j0 = 0; j0 < cnt; j0 += 4) {
-      double r[4];
+  // pulses with n0 - h <= idx <= n0 + kOlaSeg + h - 2 reach into the stretch; the table brackets them (a few more on
+  // the left, whose rows end before the stretch and are skipped chunk by chunk)
+  const int* fu = first + ola_table_base(yb, u);
+  const int m_last = (ylen + kOlaStep - 1) / kOlaStep;
+  const int lo_s = imax(0, n0 - h), hi_s = n0 + kOlaSeg + h - 2;
+  int pa = fu[lo_s / kOlaStep];
+  int pb = fu[imin(m_last, hi_s / kOlaStep + 1)];
+  const int64_t rel_a = p_begin - pu, rel_b = p_end - pu;        // the piece's pulses, utterance-relative
+  pa = rel_a > pa ? (int)(rel_a < np ? rel_a : np) : pa;
+  pb = rel_b < pb ? (int)(rel_b > 0 ? rel_b : 0) : pb;
+  if (pa >= pb) return;
+  const int* pidx = pulse_idx + yb;
+  double2_a8 acc[kOlaQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int j = j0 + q;
-        const int idx = sidx[j < cnt ? j : cnt - 1];
-        const int off = n - idx + h - 1;
-        const bool cover = live && j < cnt && off >= 0 && off < fft_size;
-        r[q] = cover ? resp[(base + j - p_begin) * (int64_t)fft_size + off] : 0.0;
+  for (int q = 0; q < kOlaQ; ++q) {
+    const int n = n0 + 128 * q + 2 * lane;
+    acc[q].x = n < ylen ? y[yb + n] : 0.0;
+    acc[q].y = n + 1 < ylen ? y[yb + n + 1] : 0.0;
+  }
+  for (int base = pa; base < pb; base += 64) {
+    const int cnt = imin(64, pb - base);
+    const int my_idx = pidx[base + imin(lane, cnt - 1)];         // the indices of up to 64 pulses, one per lane
+    for (int k = 0; k < cnt; ++k) {
+      const int idx = __builtin_amdgcn_readlane(my_idx, k);
+      const int s = idx - h + 1 - n0;                             // stretch-relative sample of response[0]
+      const double* row = resp + ((int64_t)(pu + base + k) - p_begin) * fft_size;
+#pragma unroll
+      for (int q = 0; q < kOlaQ; ++q) {
+        const int c0 = 128 * q - s;                               // response index of the chunk's first sample
+        if (c0 + 127 < 0 || c0 >= fft_size) continue;             // the row does not reach the chunk
+        const int j = c0 + 2 * lane;
+        if (c0 >= 0 && c0 + 127 < fft_size) {
+          const double2_a8 v = *reinterpret_cast<const double2_a8*>(row + j);
+          acc[q].x += v.x;
+          acc[q].y += v.y;
+        } else {
+          const bool in0 = j >= 0 && j < fft_size, in1 = j + 1 >= 0 && j + 1 < fft_size;
+          const double v0 = row[imin(fft_size - 1, imax(0, j))];
+          const double v1 = row[imin(fft_size - 1, imax(0, j + 1))];
+          if (in0) acc[q].x += v0;
+          if (in1) acc[q].y += v1;
+        }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc += r[q];
     }
   }
-  if (live) y[yb + n] = acc;
+#pragma unroll
+  for (int q = 0; q < kOlaQ; ++q) {
+    const int n = n0 + 128 * q + 2 * lane;
+    if (n < ylen) y[yb + n] = acc[q].x;
+    if (n + 1 < ylen) y[yb + n + 1] = acc[q].y;
+  }
 }
 
 // Synthesis in two parts.  synthesis_prepare() is everything that depends on f0 only: sample-rate f0 / vuv,
@@ -714,6 +752,7 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
     const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
     const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
+    const size_t o_first = take(4 * (ny / kOlaStep + 2 * nu + 4));
     unsigned char* base = nullptr;
     rc = wm_check(dev_alloc(&base, at));
     if (rc) return rc;
@@ -727,6 +766,7 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
     b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
     b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
     b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
+    b.d_pulse_first = (int*)(base + o_first);
     hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, st, F, b.d_dc_remover);
   }
   const double fp = b.p.frame_period / 1000.0;
@@ -801,7 +841,7 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   {
     hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (max_np + 255) / 256), b.n_utt), dim3(256), 0, st,
                        b.d_f_off, b.d_y_off, b.d_pulse_off, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,
-                       (PulseRec*)b.d_pulse_rec);
+                       (PulseRec*)b.d_pulse_rec, b.d_pulse_first);
   }
   b.syn_chunk = chunk;
   return wm_check(hipGetLastError());
@@ -814,7 +854,7 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
   const double fp = b.p.frame_period / 1000.0;
   const int64_t total_p = b.syn_total_p, chunk = b.syn_chunk;
   if (total_p == 0) return WM_OK;
-  const int ola_tiles = (b.max_y_len + 255) / 256;
+  const int ola_tiles = (b.max_y_len + kOlaSeg * kOlaWaves - 1) / (kOlaSeg * kOlaWaves);
   // Piece k: pulse kernel on the caller's stream into half k & 1 of the scratch, overlap-add on the second stream.
   // The overlap-adds run in list order on one stream, so every sample is summed in the order of one piece per launch
   // whatever the timing; the pulse kernel of piece k + 2 waits for the overlap-add of piece k to release its half.
@@ -855,8 +895,8 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
     {
       c.stream = so;                                       // the timing bracket records on the context's stream
       TimedScope ts2_(b.ctx, "synth_ola_kernel");
-      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(256), 0, so, b.d_y_off, b.d_pulse_off,
-                         b.d_pulse_idx, F, p0, p1, resp, d_y);
+      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(64 * kOlaWaves), 0, so, b.d_y_off,
+                         b.d_pulse_off, b.d_pulse_idx, (const int*)b.d_pulse_first, F, p0, p1, resp, d_y);
     }
     c.stream = st;
     rc = wm_check(hipEventRecord(c.ev_ola[h], so));
