@@ -30,6 +30,11 @@ const char* last_error();
 void set_error(const char* msg);
 int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0);
 void free_batch_buffers(Batch& b);
+#ifdef WM_PHASE
+int phase_read_d4c(unsigned long long* out32);
+int phase_read_cheaptrick(unsigned long long* out32);
+int phase_read_synthesis(unsigned long long* out32);
+#endif
 }  // namespace wm
 
 using namespace wm;
@@ -338,6 +343,13 @@ int WorldMi355UtteranceStatus(WorldMi355Batch* hb, const double* x, const double
   OnDevice dev_(hb->b.ctx[0]);
   return launch_utterance_status(hb->b, x, f0, sp, ap, status);
 }
+#ifdef WM_PHASE
+// debug builds only (make EXTRA=-DWM_PHASE): the shader-clock totals of the phase marks of one translation unit
+// (0 = d4c.hip, 1 = cheaptrick.hip, 2 = synthesis.hip), read and cleared
+__attribute__((visibility("default"))) int WorldMi355DebugPhases(int unit, unsigned long long* out32) {
+  return unit == 0 ? wm::phase_read_d4c(out32) : unit == 1 ? wm::phase_read_cheaptrick(out32) : wm::phase_read_synthesis(out32);
+}
+#endif
 int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
   OnDevice dev_(h->c);
   Context& c = h->c;

@@ -228,4 +228,8 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
   return wm_check(hipGetLastError());
 }
 
+#ifdef WM_PHASE
+int phase_read_cheaptrick(unsigned long long* out32) { return wm_phase_read(out32); }
+#endif
+
 }  // namespace wm

@@ -92,6 +92,48 @@ __device__ __forceinline__ void load4_a8(const double* __restrict__ p, double (&
   v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
+// ---- phase timing of a per-frame kernel (debug builds only: make EXTRA=-DWM_PHASE) ------------------------------
+// WM_PHASE_MARK(k) adds the shader clock since the previous mark to slot k of a per-wave array; WM_PHASE_FLUSH() adds
+// the array to this translation unit's wm_phase_cycles[] in device memory (WorldMi355DebugPhases(unit, out) reads and
+// clears it; tools/phase_probe.py).
+// In product builds the macros are empty.
+#ifdef WM_PHASE
+static __device__ unsigned long long wm_phase_cycles[32];     // one per translation unit (no relocatable device code)
+static inline int wm_phase_read(unsigned long long* out32) {  // host: read and clear this unit's totals
+  unsigned long long zero[32] = {};
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(wm_phase_cycles), sizeof(zero)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(wm_phase_cycles), zero, sizeof(zero)) != hipSuccess;
+}
+struct PhaseClock {
+  unsigned long long last, acc[16];
+  __device__ __forceinline__ void start() {
+    last = __builtin_readcyclecounter();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0;
+  }
+  template <int K> __device__ __forceinline__ void mark() {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[K] += now - last;
+    last = now;
+  }
+  __device__ __forceinline__ void flush(int slot0) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (acc[k]) atomicAdd(&wm_phase_cycles[slot0 + k], acc[k]);
+    }
+  }
+};
+#define WM_PHASE_DECL PhaseClock phase_clock_; phase_clock_.start();
+#define WM_PHASE_MARK(k) phase_clock_.mark<k>();
+#define WM_PHASE_FLUSH(slot0) phase_clock_.flush(slot0);
+#else
+#define WM_PHASE_DECL
+#define WM_PHASE_MARK(k)
+#define WM_PHASE_FLUSH(slot0)
+#endif
+
 // ---- wavefront collectives (64 lanes) ----------------------------------------
 // Built on DPP row shifts / row broadcasts (gfx9 family) instead of ds_bpermute shuffles: six
 // dependent VALU steps with no LDS round trip.  The six steps are a complete inclusive scan over

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
   }
   FramePipe pipe;
   pipe.init(perm, n_run, x, x_off, x_len, frame_utt, tpos, f0, rng_off);
+  WM_PHASE_DECL
   WM_FOR_EACH_PIPED(sc, pipe, n_run) {
+    WM_PHASE_MARK(0)                                                                  // the pipe's step
     const int64_t frame = sc.frame;
     const int lane = opaque_lane(lane0);
     const int fs = opaque_uniform(fs_arg), out_fft = opaque_uniform(out_fft_arg);   // nothing derived is hoisted
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       if (!RARE || fg.L <= N) d4c_centroid<N, false>(xu, xl, fg, rtab, roff + side * Lw, tw, img, lane, ce, co);
       else d4c_centroid<N, true>(xu, xl, fg, rtab, roff + side * Lw, tw, img, lane, ce, co);
     }
+    WM_PHASE_MARK(1)                                                                  // two centroids
     {
       cpx* arr2 = reinterpret_cast<cpx*>(arr);
 #pragma unroll
@@ -369,12 +372,14 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
     sc[M] = arr[H];
     wave_sync();
+    WM_PHASE_MARK(2)                                                                  // DC correction of the centroid
 
     // ---- GetSmoothedPowerSpectrum (d4c.cpp:148-164) ----
     {
       cpx v[M];
       const FrameGeom fg = frame_geom(fs, cf0, pos, 4.0);
       frame_packed<kHann, false, M>(xu, xl, fg, rtab, roff + 2 * Lw, lane, v);
+      WM_PHASE_MARK(3)                                                                // Hann frame
       rfft_forward<N>(v, img, img, tw, lane);
       double p[MB];
 #pragma unroll
@@ -392,8 +397,10 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       if (lane == 0) arr[H] = p[M];
       wave_sync();
     }
+    WM_PHASE_MARK(4)                                                                  // its transform and power
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
     linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    WM_PHASE_MARK(5)                                                                  // DC correction + smoothing
     // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
 #pragma unroll
     for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
@@ -410,6 +417,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
     gd[M] -= arr[H];
     wave_sync();
+    WM_PHASE_MARK(6)                                                                  // group delay: two smoothings
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
     const int wl = tab.window_length;
@@ -452,7 +460,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
           for (int r = 0; r < GW; ++r) v[g0 + r] = make_double2(0.0, 0.0);
         }
       }
+      WM_PHASE_MARK(7)                                                                // band window
       rfft_forward<N>(v, img, img, tw, lane);
+      WM_PHASE_MARK(8)                                                                // band transform
       double p[MB];
       double tot = 0.0;
 #pragma unroll
@@ -497,6 +507,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       for (int j = 0; j < 6; ++j)
         if (j == band) coarse[j] = c;               // static indices keep coarse[] in registers
       wave_sync();
+      WM_PHASE_MARK(9)                                                                // sort + peel + log
     }
 
     // ---- GetAperiodicity (d4c.cpp:325-333): interp1 over {0, 3000 i, fs/2} then 10^(x/20) ----
@@ -514,7 +525,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     wave_sync();
     d4c_write_row([&](int k) { return smem[k]; }, tab.nap, fs, out_fft, out_bins, lane, row);
     wave_sync();
+    WM_PHASE_MARK(10)                                                                 // output row
   }
+  WM_PHASE_FLUSH(0)
 }
 
 // The frames the two instantiations of d4c_kernel work on (both: d4c.cpp:380).  The usual one takes the frames
@@ -725,5 +738,9 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
 #undef WM_D4C_CASE
   return wm_check(hipGetLastError());
 }
+
+#ifdef WM_PHASE
+int phase_read_d4c(unsigned long long* out32) { return wm_phase_read(out32); }
+#endif
 
 }  // namespace wm

@@ -41,103 +41,161 @@ __device__ __forceinline__ cpx cis_neg2pi(double frac) {   // exp(-2*pi*i*frac)
 }
 
 // ---- in-register DFTs, natural order in and out -----------------------------
-template <int R> struct Dft;
-
-template <> struct Dft<2> {
-  __device__ static __forceinline__ void run(cpx (&v)[2]) {
-    cpx a = v[0];
-    v[0] = cadd(a, v[1]);
-    v[1] = csub(a, v[1]);
-  }
+// Decimation in time by halves, every butterfly in fused form:
+//
+//   X[q]         = E[q] + t_q O[q]            E, O: the transforms of the even / odd inputs
+//   X[q + R / 2] = E[q] - t_q O[q]            t_q = W_R^q (Dft) or w W_R^q (TwDft)
+//
+// * a constant t = (c, -s) is factored by its larger component: x +- c (y.x + tau y.y), tau = s / c a compile-time
+//   constant -- two fused multiply-adds for the bracket and one per output component: six for a butterfly where
+//   the product and the sum / difference take eight;
+// * a per-lane t (TwDft: the inter-pass twiddles w^r are folded into the butterflies, nothing is multiplied
+//   beforehand) has no tangent at hand: the sum is two chained fused multiply-adds per component and the
+//   difference is 2 x - sum (one): six as well;
+// * TwDft needs w, w^2, w^4 (, w^8) and the products w W_R^q of the last level only (q and q + R / 4 share one:
+//   W_R^(R/4) = -i) -- three to five live twiddles where a table of powers w^1 .. w^(R-1) held seven to fifteen.
+// 1024 points: 499 FP64 instructions (round 3: 612, of which 97 built powers and 112 applied them).
+template <int K16> struct W16c {                    // W_16^K = (cos, -sin)(2 pi K / 16), K = 0 .. 4 tabulated
+  static constexpr double kC[5] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173, 0.0};
+  static constexpr double c = kC[K16], s = kC[4 - K16];
 };
 
-template <> struct Dft<4> {
-  __device__ static __forceinline__ void run(cpx (&v)[4]) {
-    cpx s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
-    cpx s1 = cadd(v[1], v[3]), d1 = cmul_mi(csub(v[1], v[3]));
-    v[0] = cadd(s0, s1);
-    v[2] = csub(s0, s1);
-    v[1] = cadd(d0, d1);
-    v[3] = csub(d0, d1);
+// x, y  <-  x + t y, x - t y   with t = W_16^K16 (0 <= K16 < 8), compile-time
+template <int K16> __device__ __forceinline__ void bfly_const(cpx& x, cpx& y) {
+  if constexpr (K16 == 0) {
+    const cpx a = x;
+    x = cadd(a, y);
+    y = csub(a, y);
+  } else if constexpr (K16 == 4) {                  // t = -i: t y = (y.y, -y.x)
+    const cpx a = x, b = y;
+    x = make_double2(a.x + b.y, a.y - b.x);
+    y = make_double2(a.x - b.y, a.y + b.x);
+  } else if constexpr (K16 > 4) {                   // W^K = -i W^(K-4): t y = (u.y, -u.x), u = W^(K-4) y
+    constexpr double c = W16c<K16 - 4>::c, s = W16c<K16 - 4>::s;
+    const cpx a = x, b = y;
+    if constexpr (c >= s) {
+      constexpr double tau = s / c;
+      const double ur = __builtin_fma(tau, b.y, b.x), ui = __builtin_fma(-tau, b.x, b.y);   // u / c
+      x = make_double2(__builtin_fma(c, ui, a.x), __builtin_fma(-c, ur, a.y));
+      y = make_double2(__builtin_fma(-c, ui, a.x), __builtin_fma(c, ur, a.y));
+    } else {
+      constexpr double kap = c / s;
+      const double ur = __builtin_fma(kap, b.x, b.y), ui = __builtin_fma(kap, b.y, -b.x);   // u / s
+      x = make_double2(__builtin_fma(s, ui, a.x), __builtin_fma(-s, ur, a.y));
+      y = make_double2(__builtin_fma(-s, ui, a.x), __builtin_fma(s, ur, a.y));
+    }
+  } else {
+    constexpr double c = W16c<K16>::c, s = W16c<K16>::s;
+    const cpx a = x, b = y;
+    if constexpr (c >= s) {                         // t y = c (b.x + tau b.y, b.y - tau b.x)
+      constexpr double tau = s / c;
+      const double ur = __builtin_fma(tau, b.y, b.x), ui = __builtin_fma(-tau, b.x, b.y);
+      x = make_double2(__builtin_fma(c, ur, a.x), __builtin_fma(c, ui, a.y));
+      y = make_double2(__builtin_fma(-c, ur, a.x), __builtin_fma(-c, ui, a.y));
+    } else {                                        // t y = s (kap b.x + b.y, kap b.y - b.x)
+      constexpr double kap = c / s;
+      const double ur = __builtin_fma(kap, b.x, b.y), ui = __builtin_fma(kap, b.y, -b.x);
+      x = make_double2(__builtin_fma(s, ur, a.x), __builtin_fma(s, ui, a.y));
+      y = make_double2(__builtin_fma(-s, ur, a.x), __builtin_fma(-s, ui, a.y));
+    }
   }
-};
+}
 
-template <> struct Dft<8> {
-  __device__ static __forceinline__ void run(cpx (&v)[8]) {
-    const double h = 0.70710678118654752440;
-    cpx e[4] = {v[0], v[2], v[4], v[6]};
-    cpx o[4] = {v[1], v[3], v[5], v[7]};
-    Dft<4>::run(e);
-    Dft<4>::run(o);
-    // W8^1 = h(1-i), W8^2 = -i, W8^3 = h(-1-i)
-    cpx t1 = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
-    cpx t2 = cmul_mi(o[2]);
-    cpx t3 = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
-    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
-    v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
-    v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
-    v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+// x, y  <-  x + t y, x - t y   with a per-lane t
+__device__ __forceinline__ void bfly_tw(cpx& x, cpx& y, cpx t) {
+  const double sx = __builtin_fma(y.x, t.x, __builtin_fma(-y.y, t.y, x.x));
+  const double sy = __builtin_fma(y.x, t.y, __builtin_fma(y.y, t.x, x.y));
+  y = make_double2(__builtin_fma(2.0, x.x, -sx), __builtin_fma(2.0, x.y, -sy));
+  x = make_double2(sx, sy);
+}
+
+// w W_16^K16, K16 = 0 .. 3 (the others follow by -i)
+template <int K16> __device__ __forceinline__ cpx mul_w16(cpx w) {
+  if constexpr (K16 == 0) {
+    return w;
+  } else if constexpr (K16 == 2) {
+    constexpr double h = W16c<2>::c;
+    return make_double2(h * (w.x + w.y), h * (w.y - w.x));
+  } else {
+    constexpr double c = W16c<K16>::c, s = W16c<K16>::s;
+    return make_double2(__builtin_fma(w.x, c, w.y * s), __builtin_fma(w.y, c, -(w.x * s)));
   }
-};
+}
+__device__ __forceinline__ cpx csqr(cpx w) { return make_double2(__builtin_fma(w.x, w.x, -(w.y * w.y)), (w.x + w.x) * w.y); }
 
-template <> struct Dft<16> {
-  __device__ static __forceinline__ void run(cpx (&v)[16]) {
-    const double h = 0.70710678118654752440;
-    const double c1 = 0.92387953251128675613;   // cos(pi/8)
-    const double s1 = 0.38268343236508977173;   // sin(pi/8)
-    cpx e[8] = {v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14]};
-    cpx o[8] = {v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]};
-    Dft<8>::run(e);
-    Dft<8>::run(o);
-    // W16^k = (cos(k pi/8), -sin(k pi/8))
-    cpx t[8];
-    t[0] = o[0];
-    t[1] = cmul(o[1], make_double2(c1, -s1));
-    t[2] = make_double2(h * (o[2].x + o[2].y), h * (o[2].y - o[2].x));
-    t[3] = cmul(o[3], make_double2(s1, -c1));
-    t[4] = cmul_mi(o[4]);
-    t[5] = cmul(o[5], make_double2(-s1, -c1));
-    t[6] = make_double2(h * (o[6].y - o[6].x), -h * (o[6].x + o[6].y));
-    t[7] = cmul(o[7], make_double2(-c1, -s1));
+template <int R> struct Dft {
+  __device__ static __forceinline__ void run(cpx (&v)[R]) {
+    if constexpr (R == 2) {
+      bfly_const<0>(v[0], v[1]);
+    } else {
+      cpx e[R / 2], o[R / 2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      v[k] = cadd(e[k], t[k]);
-      v[k + 8] = csub(e[k], t[k]);
+      for (int r = 0; r < R / 2; ++r) {
+        e[r] = v[2 * r];
+        o[r] = v[2 * r + 1];
+      }
+      Dft<R / 2>::run(e);
+      Dft<R / 2>::run(o);
+      combine<0>(e, o);
+#pragma unroll
+      for (int q = 0; q < R / 2; ++q) {
+        v[q] = e[q];
+        v[q + R / 2] = o[q];
+      }
+    }
+  }
+  template <int Q> __device__ static __forceinline__ void combine(cpx (&e)[R / 2], cpx (&o)[R / 2]) {
+    if constexpr (Q < R / 2) {
+      bfly_const<Q * (16 / R)>(e[Q], o[Q]);
+      combine<Q + 1>(e, o);
     }
   }
 };
 
-// multiply a[r] by w^r, r = 1..R-1.
-// WM_FFT_ILP (default): powers from a shallow product tree (depth log2 R) -- more live registers,
-// short dependency chains; the one-wave-per-SIMD kernels are latency bound and want this.
-// Otherwise two interleaved chains stepping by w^2 (three live complex values).
+// X[q] = sum_r v[r] w^r W_R^(r q): the DFT of inputs that still lack their inter-pass twiddles w^r.
+// pw[k] = w^(2^k), k = 0 .. log2(R) - 1.
+template <int R> struct TwDft {
+  static constexpr int L = R == 2 ? 1 : (R == 4 ? 2 : (R == 8 ? 3 : 4));
+  __device__ static __forceinline__ void run(cpx (&v)[R], const cpx (&pw)[4]) { level<R>(v, pw); }
+  // level<RR>: v holds RR inputs that are every (R / RR)-th input of the whole transform; their twiddle base is
+  // w^(R / RR) = pw[log2(R / RR)]
+  template <int RR> __device__ static __forceinline__ void level(cpx (&v)[RR], const cpx (&pw)[4]) {
+    constexpr int LG = R / RR == 1 ? 0 : (R / RR == 2 ? 1 : (R / RR == 4 ? 2 : 3));
+    if constexpr (RR == 2) {
+      bfly_tw(v[0], v[1], pw[LG]);
+    } else {
+      cpx e[RR / 2], o[RR / 2];
+#pragma unroll
+      for (int r = 0; r < RR / 2; ++r) {
+        e[r] = v[2 * r];
+        o[r] = v[2 * r + 1];
+      }
+      level<RR / 2>(e, pw);
+      level<RR / 2>(o, pw);
+      comb<RR, 0>(e, o, pw[LG]);
+#pragma unroll
+      for (int q = 0; q < RR / 2; ++q) {
+        v[q] = e[q];
+        v[q + RR / 2] = o[q];
+      }
+    }
+  }
+  // t_q = w W_RR^q for q < RR / 4 (computed), t_(q + RR / 4) = -i t_q
+  template <int RR, int Q> __device__ static __forceinline__ void comb(cpx (&e)[RR / 2], cpx (&o)[RR / 2], cpx w) {
+    if constexpr (RR == 2) {
+      bfly_tw(e[0], o[0], w);
+    } else if constexpr (Q < RR / 4) {
+      const cpx t = mul_w16<Q * (16 / RR)>(w);
+      bfly_tw(e[Q], o[Q], t);
+      bfly_tw(e[Q + RR / 4], o[Q + RR / 4], make_double2(t.y, -t.x));
+      comb<RR, Q + 1>(e, o, w);
+    }
+  }
+};
+
 #ifndef WM_FFT_ILP
 #define WM_FFT_ILP 1
 #endif
-template <int R> __device__ __forceinline__ void apply_twiddle_powers(cpx (&a)[R], cpx w) {
-#if WM_FFT_ILP
-  cpx p[R];
-  p[1] = w;
-#pragma unroll
-  for (int r = 2; r < R; ++r) p[r] = (r & 1) ? cmul(p[r - 1], w) : cmul(p[r / 2], p[r / 2]);
-#pragma unroll
-  for (int r = 1; r < R; ++r) a[r] = cmul(a[r], p[r]);
-#else
-  const cpx w2 = cmul(w, w);
-  cpx odd = w, even = w2;
-  a[1] = cmul(a[1], odd);
-#pragma unroll
-  for (int r = 2; r < R; r += 2) {
-    a[r] = cmul(a[r], even);
-    if (r + 1 < R) {
-      odd = cmul(odd, w2);
-      a[r + 1] = cmul(a[r + 1], odd);
-    }
-    if (r + 2 < R) even = cmul(even, w2);
-  }
-#endif
-}
-
 template <int N> struct FftCfg;
 template <> struct FftCfg<512>  { static constexpr int R1 = 8,  R2 = 8,  R3 = 8; };
 template <> struct FftCfg<1024> { static constexpr int R1 = 16, R2 = 8,  R3 = 8; };
@@ -232,8 +290,14 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     cpx a[R2];
 #pragma unroll
     for (int r = 0; r < R2; ++r) a[r] = v[b + r * S2];
-    apply_twiddle_powers<R2>(a, tw.w2);
-    Dft<R2>::run(a);
+    {
+      cpx pw[4];
+      pw[0] = tw.w2;
+      pw[1] = csqr(pw[0]);
+      pw[2] = csqr(pw[1]);
+      pw[3] = R2 > 8 ? csqr(pw[2]) : pw[2];
+      TwDft<R2>::run(a, pw);
+    }
     const unsigned j = (unsigned)lane + 64u * b;
     const unsigned base = (j / R1) * (R1 * R2) + (j % R1);
 #pragma unroll
@@ -251,8 +315,14 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     cpx a[R3];
 #pragma unroll
     for (int r = 0; r < R3; ++r) a[r] = v[b + r * S3];
-    apply_twiddle_powers<R3>(a, tw.w3(b));
-    Dft<R3>::run(a);
+    {
+      cpx pw[4];
+      pw[0] = tw.w3(b);
+      pw[1] = csqr(pw[0]);
+      pw[2] = csqr(pw[1]);
+      pw[3] = R3 > 8 ? csqr(pw[2]) : pw[2];
+      TwDft<R3>::run(a, pw);
+    }
 #pragma unroll
     for (int r = 0; r < R3; ++r) v[b + r * S3] = a[r];
 #if !WM_FFT_ILP
@@ -286,17 +356,22 @@ __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* sp
   for (int m = 0; m < M; ++m) lds[lane + 64 * m] = v[m];     // Z, plain layout
   wave_sync();
   cpx xk[M];
-  cpx w = tw.wsplit;
+  // X[k] = (a + b) / 2 + W_2N^k (a - b) / (2 i), a = Z[k], b = conj Z[N - k]: with the half folded into the twiddle
+  // three fused multiply-adds per component.  W_2N^(k + N / 2) = -i W_2N^k: the lane's twiddles of the upper half of
+  // its elements are those of the lower half turned, so M / 2 - 1 products with constants serve M elements.
+  cpx wh[M / 2 > 0 ? M / 2 : 1];
+  wh[0] = make_double2(0.5 * tw.wsplit.x, 0.5 * tw.wsplit.y);
+#pragma unroll
+  for (int m = 1; m < M / 2; ++m) wh[m] = cmul(wh[0], cis64(m * (2048 / N)));
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;
-    cpx a = v[m];
-    cpx b = cconj(lds[(N - k) & (N - 1)]);
-    cpx e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
-    cpx d = csub(a, b);
-    cpx o = make_double2(0.5 * d.y, -0.5 * d.x);             // (a-b)/(2i)
-    xk[m] = cadd(e, cmul(w, o));
-    w = cmul(w, tw.wstep());
+    const cpx a = v[m];
+    const cpx bz = lds[(N - k) & (N - 1)];                     // b = conj(bz)
+    const cpx w = m < M / 2 ? wh[m] : make_double2(wh[m - M / 2].y, -wh[m - M / 2].x);
+    const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
+    xk[m] = make_double2(__builtin_fma(0.5, sx, __builtin_fma(w.x, dy, w.y * dx)),
+                         __builtin_fma(0.5, sy, __builtin_fma(w.y, dy, -(w.x * dx))));
   }
   cpx z0 = lds[0];
   wave_sync();
@@ -317,19 +392,23 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
   constexpr int M = N / 64;
   asm volatile("" : "+v"(lane));
   const_cast<FftTw<N>&>(tw).fence();
-  cpx w = cconj(tw.wsplit);                                  // e^{+j pi k / N}
-  const cpx wst = cconj(tw.wstep());
+  // v = (a + b) + j (a - b) conj(W_2N^k), a = X[k], b = conj X[N - k]: two chained fused multiply-adds per component;
+  // the twiddles of the upper half of a lane's elements are those of the lower half turned (see rfft_forward)
+  cpx wc[M / 2 > 0 ? M / 2 : 1];                             // conj(W_2N^k) = e^{+j pi k / N}
+  wc[0] = cconj(tw.wsplit);
+#pragma unroll
+  for (int m = 1; m < M / 2; ++m) wc[m] = cmul(wc[0], cconj(cis64(m * (2048 / N))));
   wave_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int k = lane + 64 * m;
     cpx a = spec[k];
-    cpx b = cconj(spec[N - k]);
-    if (k == 0) { a.y = 0.0; b.y = 0.0; }                    // Im(DC), Im(Nyquist) ignored
-    cpx s = cadd(a, b);                                      // 2E
-    cpx o = cmul(csub(a, b), w);                             // 2O
-    v[m] = make_double2(s.x - o.y, s.y + o.x);               // 2E + j 2O
-    w = cmul(w, wst);
+    cpx bz = spec[N - k];                                    // b = conj(bz)
+    if (m == 0 && lane == 0) { a.y = 0.0; bz.y = 0.0; }      // Im(DC), Im(Nyquist) ignored
+    const cpx w = m < M / 2 ? wc[m] : make_double2(-wc[m - M / 2].y, wc[m - M / 2].x);
+    const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
+    v[m] = make_double2(__builtin_fma(-dx, w.y, __builtin_fma(-dy, w.x, sx)),
+                        __builtin_fma(dx, w.x, __builtin_fma(-dy, w.y, sy)));
   }
   fft_backward<N>(v, lds, tw, lane);
 }

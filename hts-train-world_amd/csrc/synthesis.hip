@@ -913,4 +913,8 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
 }
 
+#ifdef WM_PHASE
+int phase_read_synthesis(unsigned long long* out32) { return wm_phase_read(out32); }
+#endif
+
 }  // namespace wm
