@@ -196,6 +196,22 @@ template <int R> struct TwDft {
 #ifndef WM_FFT_ILP
 #define WM_FFT_ILP 1
 #endif
+// Between the LDS exchanges of ONE wavefront's transform nothing needs to be waited for: a wave's DS instructions
+// execute in issue order, so a read that follows the writes of the same wave sees them, and writes that follow reads
+// do not overtake them.  What is needed is that the COMPILER keeps that order (lanes read what other lanes wrote:
+// to the compiler those are unrelated addresses).  WM_FFT_LIGHT_SYNC = 1: a compiler barrier only; 0: wave_sync(),
+// i.e. s_waitcnt lgkmcnt(0) at every exchange (all writes drained before the first read is issued).
+#ifndef WM_FFT_LIGHT_SYNC
+#define WM_FFT_LIGHT_SYNC 0
+#endif
+__device__ __forceinline__ void fft_sync() {
+#if WM_FFT_LIGHT_SYNC
+  asm volatile("" ::: "memory");
+#else
+  wave_sync();
+#endif
+}
+
 template <int N> struct FftCfg;
 template <> struct FftCfg<512>  { static constexpr int R1 = 8,  R2 = 8,  R3 = 8; };
 template <> struct FftCfg<1024> { static constexpr int R1 = 16, R2 = 8,  R3 = 8; };
@@ -265,7 +281,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
   static_assert(S1 >= 1 && S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
   static_assert(R1 * R2 * R3 == N, "radix plan");
 
-  wave_sync();
+  fft_sync();
   // ---- pass 1: radix R1, Ns = 1, no twiddles; store to out[j*R1 + r]
 #pragma unroll
   for (int b = 0; b < S1; ++b) {
@@ -280,10 +296,10 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: bounds the live registers
 #endif
   }
-  wave_sync();
+  fft_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
-  wave_sync();
+  fft_sync();
   // ---- pass 2: radix R2, Ns = R1; twiddle W_{R1 R2}^{k r}, k = j % R1 = lane % R1
 #pragma unroll
   for (int b = 0; b < S2; ++b) {
@@ -306,7 +322,7 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     __builtin_amdgcn_sched_barrier(0);
 #endif
   }
-  wave_sync();
+  fft_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
   // ---- pass 3: radix R3, Ns = N / R3; twiddle W_N^{j r}; output lands in the register layout

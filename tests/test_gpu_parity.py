@@ -42,7 +42,7 @@ def cat(rs, k):
 def fft_hook(torch, x):
     """The product's wavefront FFT (csrc/fft.hpp) on the rows of x, through tests/hooks/libfft_hook.so."""
     import ctypes as C
-    lib = C.CDLL(os.path.join(os.path.dirname(__file__), "hooks", "libfft_hook.so"))
+    lib = C.CDLL(os.environ.get("WORLD_MI355_FFT_HOOK") or os.path.join(os.path.dirname(__file__), "hooks", "libfft_hook.so"))
     count, n = x.shape
     re = torch.empty(count, n // 2 + 1, dtype=torch.float64, device="cuda")
     im, xb = torch.empty_like(re), torch.empty_like(x)
