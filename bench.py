@@ -161,15 +161,15 @@ def parse():
     ap.add_argument("--coded", action="store_true", help="sweep: the default since round 3 (kept for older command lines)")
     ap.add_argument("--rounds", type=int, default=0,
                     help="sweep: batches per rank; one round is gathered, copied and written while the next is analysed.  "
-                         "0 = auto: as many rounds as keep a rank's batch at about 35 k frames or more (a batch must "
-                         "still fill the GPU), between 4 and 16 -- the more rounds, the smaller the one round of rank 0's "
-                         "copy + write that no compute hides")
+                         "0 = auto: 2 to 4, keeping a rank's batch at 130 k frames or more -- smaller batches cost more than "
+                         "the shorter exposed round of rank 0's copy + write gains (tools/sweep_knobs.sh on one GPU: 42.8 / "
+                         "43.6 / 51.6 ms per pass at 4 / 8 / 16 rounds)")
     ap.add_argument("--writers", choices=("rank0", "all"), default="rank0",
                     help="sweep: rank0 = configs[3] as stated (gather-v, rank 0 writes everything); all = no gather, every "
                          "rank writes its own shard's files (shows what the rank-0 funnel costs)")
     ap.add_argument("--io-threads", type=int, default=0,
-                    help="sweep: file-writing threads on the writing rank (0 = one per host core of the node, 4..64; "
-                         "with --writers all the cores are shared out over the ranks)")
+                    help="sweep: file-writing threads on the writing rank (0 = two per usable host core -- the cgroup's "
+                         "share --, 4..64; with --writers all the cores are shared out over the ranks)")
     ap.add_argument("--plan-only", action="store_true",
                     help="print this rank's share of the workload as JSON and exit without touching the GPU")
     ap.add_argument("--out-dir", default=None, help="sweep: where rank 0 writes the feature files (default: a fresh temp dir, removed afterwards)")
@@ -674,7 +674,7 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     rounds = args.rounds
     if rounds <= 0:                                   # auto (see --rounds)
         per_rank = sum(sh_frames(n, fs, fp) for n in counts) / float(world)
-        rounds = int(max(4, min(16, per_rank // 35000)))
+        rounds = int(max(2, min(4, per_rank // 130000)))
     sw = sweep.ShardedSweep(ctx, fs, fp, counts, rank, world, spec_dim=50 if args.coded else 0, ap_dim=25,
                             backend=args.backend, rounds=rounds, writers=args.writers)
     mine = sw.shards[rank]
@@ -694,8 +694,8 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     if out_dir:
         names = ("lf0", "mgc", "bap") if args.coded else ("f0", "sp", "ap")
         sink = sweep.dir_sink(out_dir, names)
-    ncpu = os.cpu_count() or 8
-    io_threads = args.io_threads or max(4, min(64, ncpu if args.writers == "rank0" else ncpu // max(1, world)))
+    ncpu = pkg.sharding.usable_cpus()                 # the cgroup's share, not the host's core count
+    io_threads = args.io_threads or max(4, min(64, 2 * ncpu if args.writers == "rank0" else 2 * ncpu // max(1, world)))
     comm = env.comm_record()
 
     for _ in range(warmup):
@@ -761,7 +761,7 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
                                    "pass_wall_rank0": ms(phases["wall"]),
                                    "note": "busy times per stage (HIP events per stream; writes: time inside the native "
                                            "writer); they overlap inside pass_wall"},
-            "host_side": {"cpu_count": ncpu, "writer_threads": io_threads, "files_per_step": n_files,
+            "host_side": {"usable_cpus": ncpu, "os_cpu_count": os.cpu_count(), "writer_threads": io_threads, "files_per_step": n_files,
                           "files_per_s": round(n_files / wr, 1) if wr > 0 else None,
                           "write_gbs": round(total * per_frame_out / wr / 1e9, 2) if wr > 0 else None,
                           "to_host_gbs": round(total * per_frame_out / (phases["to_host"] / k) / 1e9, 2)
@@ -771,7 +771,7 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
                           "host_cores_assumed": ncpu, "writer_threads_assumed": io_threads,
                           "model": "max(compute/8, gather + to_host, write) + (the other two stages) / rounds, from "
                                    "this run's phases; rank 0 keeps the host side at THIS box's cores (the writes are "
-                                   "page-cache fills: they scale with the writer threads, 4..64, one per host core)"},
+                                   "page-cache fills: they scale with the writer threads, 4..64, two per usable core)"},
             "value_compute_only": round(total * k / comp_max, 1) if comp_max > 0 else None,
             "roofline": roof, "cpu_baseline": None,
         }

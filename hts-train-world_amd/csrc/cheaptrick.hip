@@ -96,7 +96,9 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
   const int n_us = *n_usual;
   const int* list = WIDE ? perm + n_us : perm;                 // usual frames first, then the wide ones
   const int64_t n_list = WIDE ? total_frames - n_us : n_us;
+  WM_PHASE_DECL
   WM_FOR_EACH_LISTED(frame, list, n_list) {
+    WM_PHASE_MARK(0)
     const int lane = opaque_lane(lane0);
     const int fs = opaque_uniform(fs_arg);
     tw.fence();
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     // ---- GetWindowedWaveform (cheaptrick.cpp:87-142), straight into the FFT operand ----
     const FrameGeom fg = frame_geom(fs, cf0, uniform_d(tpos[frame]), 3.0);
     frame_packed<kHann, true, M>(x + x_off[u], x_len[u], fg, rtab, roff, lane, v);
+    WM_PHASE_MARK(1)
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
     rfft_forward<N>(v, img, img, tw, lane);
@@ -128,10 +131,13 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       if (lane == 0) pw[H] = p[M];
       wave_sync();
     }
+    WM_PHASE_MARK(2)
     dc_correction_margin<H, kBM, WIDE ? H : kBM>(pw, cf0, fs, F, lane);
+    WM_PHASE_MARK(3)
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
     linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane);
+    WM_PHASE_MARK(4)
     {
       // the draws of all bins first (one trip to memory; a rolled loop made each bin wait for its own)
       uint32_t rv[M + 1];
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       }
     }
     wave_sync();
+    WM_PHASE_MARK(5)
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
 #pragma unroll
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       v[m] = make_double2(pw[i0 <= H ? i0 : F - i0], pw[i1 <= H ? i1 : F - i1]);
     }
     rfft_forward<N>(v, img, img, tw, lane);
+    WM_PHASE_MARK(6)
     {
       // lifters at quefrency i/fs: sin(pi f0 q)/(pi f0 q) and (1-2q1) + 2 q1 cos(2 pi f0 q);
       // angle pi*f0*i/fs advances by a rotation per 64 bins; cos(2a) = 1 - 2 sin^2(a)
@@ -178,7 +186,9 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
         g.next();
       }
     }
+    WM_PHASE_MARK(7)
     rfft_backward<N>(img, v, img, tw, lane);
+    WM_PHASE_MARK(8)
     // x[2n], x[2n+1] for n = lane + 64 m: the first H + 1 samples are the envelope's logarithm
     double* row = sp + frame * (int64_t)(H + 1);
 #pragma unroll
@@ -188,7 +198,9 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       if (i0 + 1 <= H) row[i0 + 1] = wm_exp(v[m].y);
     }
     wave_sync();
+    WM_PHASE_MARK(9)
   }
+  WM_PHASE_FLUSH(0)
 }
 
 int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp) {

@@ -12,6 +12,31 @@ from __future__ import annotations
 import numpy as np
 
 
+def usable_cpus() -> int:
+    """Host cores this process may actually use: the cgroup's CPU quota when there is one (a container on a large
+    host sees all of the host's cores in os.cpu_count()), else the affinity mask, else os.cpu_count().  Sizing a
+    thread pool by the host's 256 cores inside a 16-core share made the file writers three times slower."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:                                                    # cgroup v2: "max 100000" or "<quota> <period>"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def frame_count(n_samples: int, fs: int, frame_period: float) -> int:
     """GetSamplesForDIO (externs/WORLD_v2/src/dio.cpp:638-640)."""
     return int(1000.0 * n_samples / fs / frame_period) + 1

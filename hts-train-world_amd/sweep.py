@@ -119,7 +119,7 @@ class ShardedSweep:
         on the GPU."""
         import torch
         if io_threads is None:
-            io_threads = max(4, min(64, (os.cpu_count() or 8)))     # page-cache fills: they scale with the cores
+            io_threads = max(4, min(64, 2 * sharding.usable_cpus()))     # page-cache fills: two per usable core
         on_gpu = torch.cuda.is_available() and self.ctx is not None
         if on_gpu:
             return self._run_pipelined(sink, io_threads)
