@@ -54,6 +54,8 @@ struct Context {
   int64_t* d_pulse_info = nullptr;   // the same memory as the device sees it
   // second stream + events of launch_analyze_synthesize (created on first use)
   hipStream_t side = nullptr;
+  hipStream_t prep = nullptr;        // launch_synthesis: the f0-only kernels of the batch's second part
+  hipEvent_t ev_call = nullptr, ev_prep_b = nullptr;
   hipEvent_t ev_f0 = nullptr, ev_prep = nullptr;
   hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
   int ensure_side();                 // the second stream and its events, created on first use
@@ -192,6 +194,8 @@ struct Batch {
   int* d_pulse_tile_cnt = nullptr;   // [n_utt][tiles] pulses per search tile
   int64_t* d_pulse_off = nullptr;    // [n_utt+1]
   int* d_pulse_first = nullptr;      // first pulse at or after every 128th sample of an utterance (the overlap-add's table)
+  int* d_syn_order = nullptr;        // [2 n_utt] the identity, then the utterances by output length (shortest first)
+  std::vector<int> syn_sorted;       // host copy of the second half
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts

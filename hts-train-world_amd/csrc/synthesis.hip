@@ -15,6 +15,9 @@
 // (synthesis.cpp:341 reseed, :369 noise_size).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "batch.hpp"
 #include "common.hpp"
 #include "fastmath.hpp"
@@ -44,12 +47,15 @@ __device__ __forceinline__ double coarse_vuv(const double* __restrict__ f0, int 
 
 // Part 1 of GetTimeBase (synthesis.cpp:287-307): per-sample interpolation of the coarse f0 / vuv
 // contours and the phase increment 2 pi f0 / fs.  Fully parallel over samples.
+// (All f0-only kernels take their utterances through a list: Synthesis prepares the batch in two parts, the
+// shortest utterances first -- synthesis_prepare_part.)
 __global__ __launch_bounds__(256) void synth_inc_kernel(
-    const double* __restrict__ f0, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
-    int fs, double fp, double lowest_f0, double* __restrict__ vuv_out, double* __restrict__ inc_out) {
+    const int* __restrict__ utts, const double* __restrict__ f0, const int64_t* __restrict__ f_off,
+    const int64_t* __restrict__ y_off, int fs, double fp, double lowest_f0, double* __restrict__ vuv_out,
+    double* __restrict__ inc_out) {
   // bit-exact increments are required (see synth_timebase_kernel): no FMA contraction
 #pragma clang fp contract(off)
-  const int u = blockIdx.y;
+  const int u = utts[blockIdx.y];
   const double* f0u = f0 + f_off[u];
   const int nf = (int)(f_off[u + 1] - f_off[u]);
   const int64_t yb = y_off[u];
@@ -83,9 +89,10 @@ __global__ __launch_bounds__(256) void synth_inc_kernel(
 // one period), so the accumulated phase has to match the reference bit for bit: lane l adds
 // increments 0..l one after another (adding 0.0 on the lanes that are done is exact), and
 // fmod(total, 2 pi) is evaluated exactly as total - k * (2 pi) with a single FMA.
-__global__ __launch_bounds__(64) void synth_timebase_kernel(const int64_t* __restrict__ y_off, double* phase) {
+__global__ __launch_bounds__(64) void synth_timebase_kernel(const int* __restrict__ utts,
+                                                            const int64_t* __restrict__ y_off, double* phase) {
 #pragma clang fp contract(off)
-  const int u = blockIdx.x, lane = threadIdx.x;
+  const int u = utts[blockIdx.x], lane = threadIdx.x;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
   double carry = 0.0;
@@ -174,13 +181,13 @@ __device__ __forceinline__ double wrap_two_pi(double t) {
 constexpr int kSearchSub = 8, kSearchTile = 256 * kSearchSub;
 template <bool WRITE>
 __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
-    const int64_t* __restrict__ y_off, const double* __restrict__ phase, int fs, int tiles_max,
-    int* __restrict__ tile_cnt, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
+    const int* __restrict__ utts, const int64_t* __restrict__ y_off, const double* __restrict__ phase, int fs,
+    int tiles_max, int* __restrict__ tile_cnt, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
     int* __restrict__ pulse_cnt) {
 #pragma clang fp contract(off)
   __shared__ int wave_cnt[kSearchSub][4];
   __shared__ int red[4];
-  const int u = blockIdx.y, tile = blockIdx.x;
+  const int u = utts[blockIdx.y], tile = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
@@ -259,18 +266,21 @@ __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
   }
 }
 
-// exclusive scan of the per-utterance pulse counts; info[0] = total, info[1] = largest count (pinned host memory)
-__global__ __launch_bounds__(256) void synth_pulse_off_kernel(const int* __restrict__ cnt, int n_utt,
-                                                              int64_t* __restrict__ off, int64_t* __restrict__ info) {
+// Pulse numbers of a part of the batch: utterance utts[k] owns [off[u], off[u] + cnt[u]), numbered from `base` on in
+// list order; info[0] = the part's total, info[1] = its largest count (pinned host memory).
+__global__ __launch_bounds__(256) void synth_pulse_off_kernel(const int* __restrict__ utts, const int* __restrict__ cnt,
+                                                              int n_list, int64_t base, int64_t* __restrict__ off,
+                                                              int64_t* __restrict__ info) {
   __shared__ int64_t part[256];
   __shared__ int mx[256];
-  const int per = (n_utt + 255) / 256;
-  const int lo = threadIdx.x * per, hi = imin(n_utt, lo + per);
+  const int per = (n_list + 255) / 256;
+  const int lo = threadIdx.x * per, hi = imin(n_list, lo + per);
   int64_t sum = 0;
   int m = 0;
-  for (int u = lo; u < hi; ++u) {
-    sum += cnt[u];
-    m = imax(m, cnt[u]);
+  for (int k = lo; k < hi; ++k) {
+    const int c = cnt[utts[k]];
+    sum += c;
+    m = imax(m, c);
   }
   part[threadIdx.x] = sum;
   mx[threadIdx.x] = m;
@@ -284,14 +294,14 @@ __global__ __launch_bounds__(256) void synth_pulse_off_kernel(const int* __restr
       run += v;
       mm = imax(mm, mx[i]);
     }
-    off[n_utt] = run;
     info[0] = run;
     info[1] = mm;
     __threadfence_system();
   }
   __syncthreads();
-  int64_t run = part[threadIdx.x];
-  for (int u = lo; u < hi; ++u) {
+  int64_t run = base + part[threadIdx.x];
+  for (int k = lo; k < hi; ++k) {
+    const int u = utts[k];
     off[u] = run;
     run += cnt[u];
   }
@@ -391,12 +401,13 @@ constexpr int kOlaStep = 128;
 __host__ __device__ inline int64_t ola_table_base(int64_t yb, int u) { return yb / kOlaStep + 2 * (int64_t)u; }
 
 __global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
-    const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int64_t* __restrict__ p_off,
-    const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift, const double* __restrict__ vuv,
-    PulseRec* __restrict__ rec, int* __restrict__ first) {
-  const int u = blockIdx.y;
+    const int* __restrict__ utts, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
+    const int64_t* __restrict__ p_off, const int* __restrict__ p_cnt, const int* __restrict__ pulse_idx,
+    const double* __restrict__ pulse_shift, const double* __restrict__ vuv, PulseRec* __restrict__ rec,
+    int* __restrict__ first) {
+  const int u = utts[blockIdx.y];
   const int64_t pb = p_off[u];
-  const int np = (int)(p_off[u + 1] - pb);
+  const int np = p_cnt[u];
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
   int* fu = first + ola_table_base(yb, u);
@@ -663,21 +674,24 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
 // Round 3 gave a thread one sample of a tile of 256 and walked every pulse near the tile with 8-byte loads, four in
 // flight: 0.8 TB/s where a stream reads at 6, 15.8 ms busy per configs[4] step beside the pulse kernel.
 constexpr int kOlaQ = 4, kOlaSeg = 128 * kOlaQ, kOlaWaves = 4;
-__global__ __launch_bounds__(64 * kOlaWaves) void synth_ola_kernel(const int64_t* __restrict__ y_off,
+__global__ __launch_bounds__(64 * kOlaWaves) void synth_ola_kernel(const int* __restrict__ utts,
+                                                                   const int64_t* __restrict__ y_off,
                                                                    const int64_t* __restrict__ p_off,
+                                                                   const int* __restrict__ p_cnt,
                                                                    const int* __restrict__ pulse_idx,
                                                                    const int* __restrict__ first, int fft_size,
                                                                    int64_t p_begin, int64_t p_end,
                                                                    const double* __restrict__ resp,
                                                                    double* __restrict__ y) {
-  const int u = blockIdx.y;
+  const int u = utts[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
   const int n0 = (blockIdx.x * kOlaWaves + (threadIdx.x >> 6)) * kOlaSeg;      // wave-uniform
   const int64_t pu = p_off[u];
-  const int np = (int)(p_off[u + 1] - pu);
-  if (n0 >= ylen || np == 0) return;
+  const int np = p_cnt[u];
+  // pulses of another part of the batch (their numbers lie outside this launch's piece) or none at all
+  if (n0 >= ylen || np == 0 || pu >= p_end || pu + np <= p_begin) return;
   const int h = fft_size / 2;
   // pulses with n0 - h <= idx <= n0 + kOlaSeg + h - 2 reach into the stretch; the table brackets them (a few more on
   // the left, whose rows end before the stretch and are skipped chunk by chunk)
@@ -732,136 +746,181 @@ __global__ __launch_bounds__(64 * kOlaWaves) void synth_ola_kernel(const int64_t
   }
 }
 
-// Synthesis in two parts.  synthesis_prepare() is everything that depends on f0 only: sample-rate f0 / vuv,
-// the time base, the pulse list and its per-pulse records; it ends with the one host round trip of the path
-// (the pulse count sizes the response scratch).  synthesis_render() turns sp / ap into responses and overlap-adds
-// them.  launch_synthesis() runs them back to back on the context's stream; launch_analyze_synthesize()
-// (context.cpp) runs the first part on a side stream while CheapTrick and D4C occupy the main one.
-int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
+// Synthesis in two stages.  The PREPARE stage is everything that depends on f0 only: sample-rate f0 / vuv, the time
+// base, the pulse list and its per-pulse records; it ends with the one host round trip of the path (the pulse count
+// sizes the response scratch).  The RENDER stage turns sp / ap into responses and overlap-adds them.
+//
+// Both work on a PART of the batch: a list of utterances (Batch::d_syn_order holds the batch's utterances sorted by
+// output length; the identity order when the batch is prepared as one part).  launch_analyze_synthesize()
+// (context.cpp) prepares the whole batch as one part on a side stream while CheapTrick and D4C occupy the main one.
+// launch_synthesis() -- Synthesis alone, BASELINE.json configs[4] -- has nothing to hide the prepare stage behind
+// but its own render stage, so it splits the batch: part A, the shortest utterances making up a sixth of the output
+// samples, is prepared on the caller's stream (its phase chain is as long as ITS longest utterance, a third of the
+// batch's); while A is rendered, the rest is prepared on a third stream.  An utterance's pulses keep their order and
+// every sample its order of additions, so y does not depend on the split (tests: against the one-part form, bit for bit).
+struct SynPart {
+  const int* d_list;      // utterance numbers of the part (device)
+  int n;                  // how many
+  int max_y_len;          // longest output among them
+  int64_t p_base;         // number of the part's first pulse
+  int64_t total_p = 0;    // its pulses (after the host round trip)
+  int max_np = 0;
+};
+
+static int synthesis_arena(Batch& b) {
+  Context& c = *b.ctx;
+  const int F = b.p.fft_size;
+  if (b.d_pulse_idx) return WM_OK;
+  // one allocation for the work arrays of this batch (sections aligned to 256 bytes)
+  const size_t ny = (size_t)b.total_y, nu = (size_t)b.n_utt;
+  const size_t tiles = (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1);
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
+  const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
+  const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
+  const size_t o_first = take(4 * (ny / kOlaStep + 2 * nu + 4));
+  const size_t o_order = take(4 * 2 * nu);
+  unsigned char* base = nullptr;
+  int rc = wm_check(dev_alloc(&base, at));
+  if (rc) return rc;
+  if (!c.h_pulse_info) {            // per context: two pinned, device-visible integers
+    rc = wm_check(hipHostMalloc((void**)&c.h_pulse_info, sizeof(int64_t) * 2, hipHostMallocMapped));
+    if (!rc) rc = wm_check(hipHostGetDevicePointer((void**)&c.d_pulse_info, c.h_pulse_info, 0));
+    if (rc) { dev_free(base); return rc; }
+  }
+  b.d_syn_arena = base;
+  b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
+  b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
+  b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
+  b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
+  b.d_pulse_first = (int*)(base + o_first);
+  b.d_syn_order = (int*)(base + o_order);
+  // [0, n): the identity; [n, 2 n): the utterances by output length, shortest first (stable)
+  std::vector<int> order(2 * nu);
+  for (size_t u = 0; u < nu; ++u) order[u] = order[nu + u] = (int)u;
+  std::stable_sort(order.begin() + (long)nu, order.end(), [&](int x, int y) { return b.y_len[(size_t)x] < b.y_len[(size_t)y]; });
+  b.syn_sorted.assign(order.begin() + (long)nu, order.end());
+  rc = wm_check(hipMemcpyAsync(b.d_syn_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, c.stream));
+  rc = rc ? rc : wm_check(hipStreamSynchronize(c.stream));      // `order` is pageable and goes out of scope
+  hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, c.stream, F, b.d_dc_remover);
+  return rc;
+}
+
+// The f0-only kernels of a part, up to its pulse numbers: asynchronous on the context's stream.
+static int synthesis_prepare_launch(Batch& b, const SynPart& part, const double* d_f0) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int F = b.p.fft_size, fs = b.p.fs;
-  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
-  int rc = c.ensure_rng(b.rng_bound_synthesis());
-  if (rc) return rc;
-  if (!b.d_pulse_idx) {
-    // one allocation for the work arrays of this batch (sections aligned to 256 bytes)
-    const size_t ny = (size_t)b.total_y, nu = (size_t)b.n_utt;
-    const size_t tiles = (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1);
-    size_t at = 0;
-    auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
-    const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
-    const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
-    const size_t o_first = take(4 * (ny / kOlaStep + 2 * nu + 4));
-    unsigned char* base = nullptr;
-    rc = wm_check(dev_alloc(&base, at));
-    if (rc) return rc;
-    if (!c.h_pulse_info) {            // per context: two pinned, device-visible integers
-      rc = wm_check(hipHostMalloc((void**)&c.h_pulse_info, sizeof(int64_t) * 2, hipHostMallocMapped));
-      if (!rc) rc = wm_check(hipHostGetDevicePointer((void**)&c.d_pulse_info, c.h_pulse_info, 0));
-      if (rc) { dev_free(base); return rc; }
-    }
-    b.d_syn_arena = base;
-    b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
-    b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
-    b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
-    b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
-    b.d_pulse_first = (int*)(base + o_first);
-    hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, st, F, b.d_dc_remover);
-  }
   const double fp = b.p.frame_period / 1000.0;
   const double lowest_f0 = fs / F + 1.0;                  // integer division as in synthesis.cpp:359
-  rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
-  if (rc) return rc;
   {
-    const int tiles = imin(64, (b.max_y_len + 255) / 256);
+    const int tiles = imin(64, (part.max_y_len + 255) / 256);
     {
       TimedScope ts_(b.ctx, "synth_inc_kernel");
-      hipLaunchKernelGGL(synth_inc_kernel, dim3(tiles, b.n_utt), dim3(256), 0, st, d_f0, b.d_f_off, b.d_y_off, fs,
-                         fp, lowest_f0, b.d_vuv, b.d_phase);
+      hipLaunchKernelGGL(synth_inc_kernel, dim3(tiles, part.n), dim3(256), 0, st, part.d_list, d_f0, b.d_f_off,
+                         b.d_y_off, fs, fp, lowest_f0, b.d_vuv, b.d_phase);
     }
     TimedScope ts_(b.ctx, "synth_timebase_kernel");
-    hipLaunchKernelGGL(synth_timebase_kernel, dim3(b.n_utt), dim3(64), 0, st, b.d_y_off, b.d_phase);
+    hipLaunchKernelGGL(synth_timebase_kernel, dim3(part.n), dim3(64), 0, st, part.d_list, b.d_y_off, b.d_phase);
   }
   {
     TimedScope ts_(b.ctx, "synth_search_kernel");
-    const int tiles_max = (b.max_y_len + kSearchTile - 1) / kSearchTile + 1;
-    hipLaunchKernelGGL(synth_pulse_search_kernel<false>, dim3(tiles_max, b.n_utt), dim3(256), 0, st, b.d_y_off,
-                       b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
-    hipLaunchKernelGGL(synth_pulse_search_kernel<true>, dim3(tiles_max, b.n_utt), dim3(256), 0, st, b.d_y_off,
-                       b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift, b.d_pulse_cnt);
+    const int tiles_max = (b.max_y_len + kSearchTile - 1) / kSearchTile + 1;        // the row length of the tile counts
+    const int tiles_part = (part.max_y_len + kSearchTile - 1) / kSearchTile + 1;
+    hipLaunchKernelGGL(synth_pulse_search_kernel<false>, dim3(tiles_part, part.n), dim3(256), 0, st, part.d_list,
+                       b.d_y_off, b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift,
+                       b.d_pulse_cnt);
+    hipLaunchKernelGGL(synth_pulse_search_kernel<true>, dim3(tiles_part, part.n), dim3(256), 0, st, part.d_list,
+                       b.d_y_off, b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift,
+                       b.d_pulse_cnt);
   }
-  // Pulse offsets (exclusive scan over the utterances) stay on the device; the host needs two numbers only -- the
-  // total, which sizes the response scratch, and the largest count, which sizes a grid -- and reads them from
-  // pinned memory the kernel writes directly.  No hipMemcpy in either direction: a small copy queues on the same
-  // DMA engine as whatever bulk transfer another stream has in flight (a 1 GB feature download held this
-  // synchronisation, and with it the whole step, for 20 ms).
-  hipLaunchKernelGGL(synth_pulse_off_kernel, dim3(1), dim3(256), 0, st, (const int*)b.d_pulse_cnt, b.n_utt,
-                     b.d_pulse_off, c.d_pulse_info);
-  rc = wm_check(hipStreamSynchronize(st));                // the one host round trip of the path
-  if (rc) return rc;
-  const int64_t total_p = c.h_pulse_info[0];
-  const int max_np = (int)c.h_pulse_info[1];
-  b.syn_total_p = total_p;
-  b.syn_chunk = 0;
-  if (total_p == 0) return WM_OK;
+  // Pulse numbers stay on the device; the host needs two numbers only -- the part's total, which sizes the response
+  // scratch, and the largest count, which sizes a grid -- and reads them from pinned memory the kernel writes
+  // directly.  No hipMemcpy in either direction: a small copy queues on the same DMA engine as whatever bulk
+  // transfer another stream has in flight (a 1 GB feature download held this synchronisation, and with it the
+  // whole step, for 20 ms).
+  hipLaunchKernelGGL(synth_pulse_off_kernel, dim3(1), dim3(256), 0, st, part.d_list, (const int*)b.d_pulse_cnt, part.n,
+                     part.p_base, b.d_pulse_off, c.d_pulse_info);
+  return wm_check(hipGetLastError());
+}
+
+// After the host round trip: the part's totals are known.  `in_flight`: kernels of an earlier part may be using the
+// pulse records and the response scratch, which therefore must not move.
+static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more, bool in_flight) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int F = b.p.fft_size;
+  part.total_p = c.h_pulse_info[0];
+  part.max_np = (int)c.h_pulse_info[1];
+  if (part.total_p == 0) return WM_OK;
   // The responses of a piece of the pulse list wait in scratch memory for the overlap-add.  The scratch holds two
   // pieces: while one is added into y on the second stream the pulse kernel fills the other (synthesis_render).
   // A piece is half of the list when that fits, else what half of the scratch cap holds.  Measured (tools/syn_sweep.sh,
   // ms per pass, configs[1] | configs[4]): 1 piece 14.64 | 20.86, 2 pieces 14.64 | 20.73, 4 pieces 14.81 | 20.75,
-  // 8 pieces 15.76 | 20.62; without the second stream 14.61 | 21.24, 14.61 | 21.04, 15.01 | 21.11, 16.24 | 21.52 -- every
-  // launch of the pulse kernel has a tail, so a short list wants few pieces; the overlap-add beside the pulse kernel
-  // is worth 0.3 - 0.5 ms on a long one.  (One 4 GB piece at a time, the round-2 form, took 24.2 ms on configs[4].)
+  // 8 pieces 15.76 | 20.62 -- every launch of the pulse kernel has a tail, so a short list wants few pieces.
   int64_t cap_mb = 4096;
   if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
   int64_t chunk = (cap_mb * 1024 * 1024 / 8) / F / 2;
   if (chunk < 1) chunk = 1;
   int pieces = 2;
   if (const char* e = getenv("WORLD_MI355_SYN_PIECES")) pieces = atoi(e) > 0 ? atoi(e) : pieces;
-  const int64_t quarter = (total_p + pieces - 1) / pieces;
-  if (quarter >= 16384 && chunk > quarter) chunk = quarter;       // short lists: one piece, nothing to overlap
-  if (chunk > total_p) chunk = total_p;
-  rc = c.ensure_side();
+  const int64_t list = part.total_p > expect_more ? part.total_p : expect_more;     // the longest list still to come
+  const int64_t share = (list + pieces - 1) / pieces;
+  if (share >= 16384 && chunk > share) chunk = share;       // short lists: one piece, nothing to overlap
+  if (chunk > list) chunk = list;
+  int rc = c.ensure_side();
   if (rc) return rc;
-  rc = c.ensure_scratch((chunk < total_p ? 2 : 1) * chunk * F);
-  if (rc) return rc;
-  if (total_p > b.pulse_rec_cap) {
+  if (in_flight) {
+    // what is there stays: this part is cut into pieces of the size the scratch was laid out for
+    chunk = b.syn_chunk > 0 ? b.syn_chunk : chunk;
+  } else {
+    rc = c.ensure_scratch((chunk < list ? 2 : 1) * chunk * F);
+    if (rc) return rc;
+    b.syn_chunk = chunk;
+  }
+  const int64_t need = part.p_base + part.total_p + (in_flight ? 0 : expect_more);
+  if (need > b.pulse_rec_cap) {
+    if (in_flight) {
+      // the earlier part's kernels read the records: let them finish (they no longer need theirs afterwards)
+      rc = wm_check(hipDeviceSynchronize());
+      if (rc) return rc;
+    }
     if (b.d_pulse_rec) dev_free(b.d_pulse_rec);
     b.d_pulse_rec = nullptr;
     b.pulse_rec_cap = 0;
     if (b.d_pulse_perm) dev_free(b.d_pulse_perm);
     b.d_pulse_perm = nullptr;
-    const int64_t cap = total_p + total_p / 8 + 64;
+    const int64_t cap = need + need / 8 + 64;
     rc = wm_check(dev_alloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
     if (rc) return rc;
     rc = wm_check(dev_alloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
     if (rc) return rc;
     b.pulse_rec_cap = cap;
   }
-  {
-    hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (max_np + 255) / 256), b.n_utt), dim3(256), 0, st,
-                       b.d_f_off, b.d_y_off, b.d_pulse_off, b.d_pulse_idx, b.d_pulse_shift, b.d_vuv,
-                       (PulseRec*)b.d_pulse_rec, b.d_pulse_first);
-  }
-  b.syn_chunk = chunk;
+  hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (part.max_np + 255) / 256), part.n), dim3(256), 0, st,
+                     part.d_list, b.d_f_off, b.d_y_off, b.d_pulse_off, (const int*)b.d_pulse_cnt, b.d_pulse_idx,
+                     b.d_pulse_shift, b.d_vuv, (PulseRec*)b.d_pulse_rec, b.d_pulse_first);
   return wm_check(hipGetLastError());
 }
 
-int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y) {
+// The pulses [part.p_base, part.p_base + part.total_p): responses by the pulse kernel on the caller's stream, added
+// into y on the second stream.  `piece` counts the pieces of the whole call (the halves of the scratch alternate
+// across parts).
+static int synthesis_render_part(Batch& b, const SynPart& part, const double* d_sp, const double* d_ap, double* d_y,
+                                 int& piece) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int F = b.p.fft_size, fs = b.p.fs;
   const double fp = b.p.frame_period / 1000.0;
-  const int64_t total_p = b.syn_total_p, chunk = b.syn_chunk;
-  if (total_p == 0) return WM_OK;
-  const int ola_tiles = (b.max_y_len + kOlaSeg * kOlaWaves - 1) / (kOlaSeg * kOlaWaves);
+  const int64_t chunk = b.syn_chunk;
+  const int ola_tiles = (part.max_y_len + kOlaSeg * kOlaWaves - 1) / (kOlaSeg * kOlaWaves);
   // Piece k: pulse kernel on the caller's stream into half k & 1 of the scratch, overlap-add on the second stream.
   // The overlap-adds run in list order on one stream, so every sample is summed in the order of one piece per launch
   // whatever the timing; the pulse kernel of piece k + 2 waits for the overlap-add of piece k to release its half.
   int rc = WM_OK;
-  int piece = 0;
-  for (int64_t p0 = 0; p0 < total_p && !rc; p0 += chunk, ++piece) {
-    const int64_t p1 = p0 + chunk < total_p ? p0 + chunk : total_p;
+  const int64_t lo = part.p_base, hi = part.p_base + part.total_p;
+  for (int64_t p0 = lo; p0 < hi && !rc; p0 += chunk, ++piece) {
+    const int64_t p1 = p0 + chunk < hi ? p0 + chunk : hi;
     const int64_t np = p1 - p0;
     const int h = piece & 1;
     double* resp = c.d_scratch + (int64_t)h * chunk * F;
@@ -895,22 +954,112 @@ int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d
     {
       c.stream = so;                                       // the timing bracket records on the context's stream
       TimedScope ts2_(b.ctx, "synth_ola_kernel");
-      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, b.n_utt), dim3(64 * kOlaWaves), 0, so, b.d_y_off,
-                         b.d_pulse_off, b.d_pulse_idx, (const int*)b.d_pulse_first, F, p0, p1, resp, d_y);
+      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, part.n), dim3(64 * kOlaWaves), 0, so, part.d_list, b.d_y_off,
+                         b.d_pulse_off, (const int*)b.d_pulse_cnt, b.d_pulse_idx, (const int*)b.d_pulse_first, F, p0,
+                         p1, resp, d_y);
     }
     c.stream = st;
     rc = wm_check(hipEventRecord(c.ev_ola[h], so));
   }
   c.stream = st;
-  // y is complete, and both halves are free again, when the last overlap-add is: everything after this call on the
-  // caller's stream is ordered behind it
-  if (!rc && piece > 0) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[(piece - 1) & 1], 0));
   return rc ? rc : wm_check(hipGetLastError());
 }
 
+// y is complete, and both halves of the scratch are free again, when the last overlap-add is: everything after the
+// call on the caller's stream is ordered behind it
+static int synthesis_join(Batch& b, int pieces) {
+  Context& c = *b.ctx;
+  if (pieces == 0) return WM_OK;
+  return wm_check(hipStreamWaitEvent(c.stream, c.ev_ola[(pieces - 1) & 1], 0));
+}
+
+// ---- the whole batch as one part (launch_analyze_synthesize: prepare on a side stream, render on the main one) ----
+int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
+  Context& c = *b.ctx;
+  const int F = b.p.fft_size;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
+  int rc = c.ensure_rng(b.rng_bound_synthesis());
+  rc = rc ? rc : synthesis_arena(b);
+  rc = rc ? rc : wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, c.stream));
+  if (rc) return rc;
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  rc = synthesis_prepare_launch(b, part, d_f0);
+  rc = rc ? rc : wm_check(hipStreamSynchronize(c.stream));      // the one host round trip of the path
+  b.syn_chunk = 0;
+  rc = rc ? rc : synthesis_prepare_finish(b, part, 0, false);
+  b.syn_total_p = part.total_p;
+  return rc;
+}
+
+int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y) {
+  if (b.syn_total_p == 0) return WM_OK;
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  part.total_p = b.syn_total_p;
+  int piece = 0;
+  int rc = synthesis_render_part(b, part, d_sp, d_ap, d_y, piece);
+  return rc ? rc : synthesis_join(b, piece);
+}
+
+// ---- Synthesis alone: the batch in two parts (see the top of this section) ----
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y) {
-  int rc = synthesis_prepare(b, d_f0, d_y);
-  return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
+  Context& c = *b.ctx;
+  static const int split_env = getenv("WORLD_MI355_SYN_SPLIT") ? atoi(getenv("WORLD_MI355_SYN_SPLIT")) : 3;
+  // worth it from a few hundred thousand output samples per part on: below, the parts do not fill the machine
+  if (!split_env || b.n_utt < 16 || b.total_y < (int64_t)4 << 20) {
+    int rc = synthesis_prepare(b, d_f0, d_y);
+    return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
+  }
+  const int F = b.p.fft_size;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
+  int rc = c.ensure_rng(b.rng_bound_synthesis());
+  rc = rc ? rc : synthesis_arena(b);
+  rc = rc ? rc : c.ensure_side();
+  if (!rc && !c.prep) {
+    // the highest priority there is: its workgroups are few and latency-bound, and they only get the slots the
+    // pulse kernel's workgroups leave as they retire
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    rc = wm_check(hipStreamCreateWithPriority(&c.prep, hipStreamNonBlocking, prio_hi));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_call, hipEventDisableTiming));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&c.ev_prep_b, hipEventDisableTiming));
+  }
+  if (rc) return rc;
+  hipStream_t st = c.stream;
+  // part A: the shortest utterances up to a sixth of the output samples
+  int n_a = 0;
+  int64_t acc = 0;
+  const int denom = split_env >= 2 ? split_env : 3;
+  while (n_a < b.n_utt - 1 && acc < b.total_y / denom) acc += b.y_len[(size_t)b.syn_sorted[(size_t)n_a++]];
+  const int* sorted = b.d_syn_order + b.n_utt;
+  SynPart pa{sorted, n_a, b.y_len[(size_t)b.syn_sorted[(size_t)n_a - 1]], 0};
+  SynPart pb{sorted + n_a, b.n_utt - n_a, b.max_y_len, 0};
+  rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_call, st));          // the caller's f0 is ready from here on
+  rc = rc ? rc : synthesis_prepare_launch(b, pa, d_f0);
+  rc = rc ? rc : wm_check(hipStreamSynchronize(st));               // host round trip of part A
+  if (rc) return rc;
+  b.syn_chunk = 0;
+  const int64_t guess_b = (int64_t)((double)c.h_pulse_info[0] * (double)(b.total_y - acc) / (double)(acc > 0 ? acc : 1) * 1.25) + 1024;
+  rc = synthesis_prepare_finish(b, pa, guess_b, false);
+  if (rc) return rc;
+  // part B's f0-only kernels on the third stream, beside part A's render stage
+  pb.p_base = pa.total_p;
+  rc = wm_check(hipStreamWaitEvent(c.prep, c.ev_call, 0));
+  c.stream = c.prep;
+  rc = rc ? rc : synthesis_prepare_launch(b, pb, d_f0);
+  c.stream = st;
+  int piece = 0;
+  if (!rc && pa.total_p > 0) rc = synthesis_render_part(b, pa, d_sp, d_ap, d_y, piece);
+  rc = rc ? rc : wm_check(hipStreamSynchronize(c.prep));           // host round trip of part B (A's render is queued)
+  if (rc) return rc;
+  c.stream = c.prep;
+  rc = synthesis_prepare_finish(b, pb, 0, pa.total_p > 0);
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_prep_b, c.prep));
+  c.stream = st;
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(st, c.ev_prep_b, 0));
+  if (!rc && pb.total_p > 0) rc = synthesis_render_part(b, pb, d_sp, d_ap, d_y, piece);
+  b.syn_total_p = pa.total_p + pb.total_p;
+  return rc ? rc : synthesis_join(b, piece);
 }
 
 #ifdef WM_PHASE
