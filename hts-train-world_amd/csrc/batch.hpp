@@ -216,6 +216,8 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
 int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);
+int synthesis_begin(Batch& b, const double* d_f0, double* d_y);      // the f0-only kernels, queued
+int synthesis_prepare_wait(Batch& b);                                 // their host round trip
 int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y);
 int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
                               double* d_y);

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <vector>
@@ -499,8 +500,20 @@ Workspace g_ws;
 
 hipStream_t ws_stream() { return default_context()->c.stream; }
 
-void h2d(double* dst, const double* staged, size_t n) {
-  if (n && hipMemcpyAsync(dst, staged, sizeof(double) * n, hipMemcpyHostToDevice, ws_stream()) != hipSuccess)
+// the upload stream of Synthesis(): its sp / ap rows travel beside the f0-only kernels, not behind them
+hipStream_t g_up_stream = nullptr;
+hipEvent_t g_up_done = nullptr;
+hipStream_t up_stream() {
+  if (!g_up_stream) {
+    if (hipStreamCreateWithFlags(&g_up_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_up_done, hipEventDisableTiming) != hipSuccess)
+      die("upload stream", WM_ERR_HIP);
+  }
+  return g_up_stream;
+}
+
+void h2d(double* dst, const double* staged, size_t n, hipStream_t st = nullptr) {
+  if (n && hipMemcpyAsync(dst, staged, sizeof(double) * n, hipMemcpyHostToDevice, st ? st : ws_stream()) != hipSuccess)
     die("H2D", WM_ERR_HIP);
 }
 // contiguous host array -> device slot through a staging region of this call (asynchronous: see Workspace::stage)
@@ -520,12 +533,12 @@ double* put_x(const double* x, size_t n) {
   g_ws.x_valid = true;
   return d;
 }
-double* put_rows(Slot s, const double* const* rows, int n_rows, int width) {
+double* put_rows(Slot s, const double* const* rows, int n_rows, int width, hipStream_t stream = nullptr) {
   const size_t n = (size_t)n_rows * width;
   double* d = g_ws.device(s, n);
   double* st = g_ws.stage(n);
   for (int i = 0; i < n_rows; ++i) memcpy(st + (size_t)i * width, rows[i], sizeof(double) * width);
-  h2d(d, st, n);
+  h2d(d, st, n, stream);
   return d;
 }
 // device -> a staging region (after the kernels on the stream); the host copy happens in finish()
@@ -547,6 +560,37 @@ void get_rows(const double* d, double** rows, int n_rows, int width) {
 void run_or_die(const char* where, int rc) {
   if (rc) die(where, rc);
 }
+
+// WORLD_MI355_TRACE=1: where the wall time of a drop-in call goes, to stderr (host staging / launches + kernels / the
+// way back); synchronises after every stage, so the totals are somewhat above the untraced call's
+struct CallTrace {
+  bool on;
+  double t0, last;
+  const char* name;
+  char line[256];
+  int at = 0;
+  static double now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
+  explicit CallTrace(const char* n) : name(n) {
+    static const bool enabled = getenv("WORLD_MI355_TRACE") && atoi(getenv("WORLD_MI355_TRACE")) != 0;
+    on = enabled;
+    if (on) t0 = last = now();
+    line[0] = 0;
+  }
+  void mark(const char* what, bool sync = false) {
+    if (!on) return;
+    if (sync) (void)hipStreamSynchronize(ws_stream());
+    const double t = now();
+    at += snprintf(line + at, sizeof(line) - (size_t)at, " %s %.3f", what, t - last);
+    last = t;
+  }
+  ~CallTrace() {
+    if (on) fprintf(stderr, "[world_mi355] %s:%s | total %.3f ms\n", name, line, now() - t0);
+  }
+};
 
 }  // namespace
 
@@ -572,15 +616,21 @@ void Dio(const double* x, int x_length, int fs, const DioOption* option, double*
   p.channels_in_octave = option->channels_in_octave; p.speed = option->speed;
   p.allowed_range = option->allowed_range;
   p.fft_size = 1024;   // unused by DIO
+  CallTrace tr("Dio");
   WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
+  tr.mark("batch");
   const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
   double* dx = put_x(x, (size_t)x_length);
+  tr.mark("stage");
   double* dt = g_ws.device(kT, nf);
   double* df = g_ws.device(kF0, nf);
   run_or_die("Dio", WorldMi355Dio(b, dx, dt, df));
+  tr.mark("launch");
+  tr.mark("kernels", true);
   get(dt, temporal_positions, nf);
   get(df, f0, nf);
   g_ws.finish();
+  tr.mark("back");
 }
 
 int GetSamplesForHarvest(int fs, int x_length, double frame_period) {  // harvest.cpp:1219-1221
@@ -644,14 +694,20 @@ void CheapTrick(const double* x, int x_length, int fs, const double* temporal_po
   p.q1 = option->q1;
   p.fft_size = option->fft_size;
   const int w = option->fft_size / 2 + 1;
+  CallTrace tr("CheapTrick");
   WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+  tr.mark("batch");
   double* dx = put_x(x, (size_t)x_length);
   double* dt = put(kT, temporal_positions, (size_t)f0_length);
   double* df = put(kF0, f0, (size_t)f0_length);
+  tr.mark("stage");
   double* ds = g_ws.device(kSp, (size_t)f0_length * w);
   run_or_die("CheapTrick", WorldMi355CheapTrick(b, dx, dt, df, ds));
+  tr.mark("launch");
+  tr.mark("kernels", true);
   get_rows(ds, spectrogram, f0_length, w);
   g_ws.finish();
+  tr.mark("back");
 }
 
 void InitializeD4COption(D4COption* option) { option->threshold = 0.85; }   // d4c.cpp:399-401
@@ -667,10 +723,14 @@ void D4C(const double* x, int x_length, int fs, const double* temporal_positions
   double* dx = put_x(x, (size_t)x_length);
   double* dt = put(kT, temporal_positions, (size_t)f0_length);
   double* df = put(kF0, f0, (size_t)f0_length);
+  CallTrace tr("D4C");
   double* da = g_ws.device(kAp, (size_t)f0_length * w);
   run_or_die("D4C", WorldMi355D4C(b, dx, dt, df, da));
+  tr.mark("launch");
+  tr.mark("kernels", true);
   get_rows(da, aperiodicity, f0_length, w);
   g_ws.finish();
+  tr.mark("back");
 }
 
 // ---- world/codec.h --------------------------------------------------------------------------------
@@ -749,14 +809,42 @@ void Synthesis(const double* f0, int f0_length, const double* const* spectrogram
   WorldMi355DefaultParams(fs, frame_period, &p);
   p.fft_size = fft_size;
   const int w = fft_size / 2 + 1;
+  CallTrace tr("Synthesis");
   WorldMi355Batch* b = g_ws.batch(p, -1, f0_length, y_length);
+  tr.mark("batch");
+  // f0 first, and the f0-only stage of Synthesis behind it (time base, pulse search: a latency chain as long as the
+  // utterance); the rows of sp / ap are gathered into pinned memory and sent while that runs
   double* df = put(kF0, f0, (size_t)f0_length);
-  double* ds = put_rows(kSp, spectrogram, f0_length, w);
-  double* da = put_rows(kAp, aperiodicity, f0_length, w);
   double* dy = g_ws.device(kY, (size_t)y_length);
-  run_or_die("Synthesis", WorldMi355Synthesis(b, df, ds, da, dy));
+  {
+    OnDevice dev_(b->b.ctx[0]);
+    run_or_die("Synthesis", synthesis_begin(b->b, df, dy));
+  }
+  tr.mark("begin");
+  // (the device and pinned buffers are sized before anything of this call is in flight on the upload stream: growing
+  // them synchronises the context's stream only)
+  const size_t cells = (size_t)f0_length * w;
+  (void)g_ws.device(kSp, cells);
+  (void)g_ws.device(kAp, cells);
+  (void)g_ws.stage(2 * cells + 16);
+  g_ws.stage_at -= (2 * cells + 16 + 7) & ~(size_t)7;               // reserved, not taken
+  hipStream_t up = up_stream();
+  double* ds = put_rows(kSp, spectrogram, f0_length, w, up);
+  double* da = put_rows(kAp, aperiodicity, f0_length, w, up);
+  if (hipEventRecord(g_up_done, up) != hipSuccess) die("upload", WM_ERR_HIP);
+  tr.mark("stage");
+  {
+    OnDevice dev_(b->b.ctx[0]);
+    run_or_die("Synthesis", synthesis_prepare_wait(b->b));
+    tr.mark("wait");
+    if (hipStreamWaitEvent(ws_stream(), g_up_done, 0) != hipSuccess) die("upload", WM_ERR_HIP);
+    run_or_die("Synthesis", synthesis_render(b->b, ds, da, dy));
+  }
+  tr.mark("launch");
+  tr.mark("kernels", true);
   get(dy, y, (size_t)y_length);
   g_ws.finish();
+  tr.mark("back");
 }
 
 }  // extern "C"

@@ -974,7 +974,10 @@ static int synthesis_join(Batch& b, int pieces) {
 }
 
 // ---- the whole batch as one part (launch_analyze_synthesize: prepare on a side stream, render on the main one) ----
-int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
+// synthesis_begin() queues the f0-only kernels and returns; synthesis_prepare_wait() is the host round trip behind
+// them.  Between the two the host is free: the drop-in Synthesis() gathers the caller's `double**` rows of sp / ap
+// into pinned memory there, i.e. while the phase chain of the utterance runs (capi.cpp).
+int synthesis_begin(Batch& b, const double* d_f0, double* d_y) {
   Context& c = *b.ctx;
   const int F = b.p.fft_size;
   if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
@@ -983,12 +986,20 @@ int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
   rc = rc ? rc : wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, c.stream));
   if (rc) return rc;
   SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
-  rc = synthesis_prepare_launch(b, part, d_f0);
-  rc = rc ? rc : wm_check(hipStreamSynchronize(c.stream));      // the one host round trip of the path
+  return synthesis_prepare_launch(b, part, d_f0);
+}
+int synthesis_prepare_wait(Batch& b) {
+  Context& c = *b.ctx;
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  int rc = wm_check(hipStreamSynchronize(c.stream));            // the one host round trip of the path
   b.syn_chunk = 0;
   rc = rc ? rc : synthesis_prepare_finish(b, part, 0, false);
   b.syn_total_p = part.total_p;
   return rc;
+}
+int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
+  int rc = synthesis_begin(b, d_f0, d_y);
+  return rc ? rc : synthesis_prepare_wait(b);
 }
 
 int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y) {
