@@ -376,6 +376,112 @@ __device__ __forceinline__ void minimum_phase(const double* ls, cpx* img, const 
   wave_sync();
 }
 
+// The PHASES of the minimum-phase spectra of two log spectra at once (a voiced pulse needs both: the periodic and the
+// aperiodic part, synthesis.cpp:105-138 and :38-68).
+//
+// GetMinimumPhaseSpectrum (common.cpp:182-220) takes the transform of the mirrored (real, even) log spectrum -- the
+// cepstrum C, real -- folds it (c_j = 2 C_j for 0 < j < H, c_0 = C_0, c_H = C_H, 0 above) and transforms again:
+// S_k = sum_j c_j e^(-i pi j k / H).  Its real part is F times the log spectrum it started from (the fold undoes the
+// mirror), so the amplitude exp(Re S_k / F) is the square root of the spectrum value, which the caller has; only
+//     Im S_k = -2 sum_{0<j<H} C_j sin(pi j k / H)
+// needs the transforms: a cosine transform of the log spectrum, then a sine transform of the result.  Both are real
+// and linear, so ONE complex sequence w = lp + i la carries both spectra through them, and the symmetry does the
+// rest: the even (odd) extension of w to F = 2 H points has an H-point transform of its even samples E and of its
+// odd samples O = e^(i pi j / H) R with E_(-j) = +-E_j, R_(-j) = +-R_j, so the ONE complex H-point transform Z of
+// z_n = w_2n + i w_2n+1 separates into both from Z_j and Z_(H-j):
+//     R_j = -(Z_j -+ Z_(H-j)) / (2 sin(pi j / H)),   E_j = Z_j - i e^(i pi j / H) R_j,   transform_j = E_j + R_j.
+// Two complex transforms of N points and two partner exchanges replace four real transforms of 2 N points with their
+// splits (4 x 490 -> 2 x ~520 vector instructions at N = 512), and the exp() of the amplitude goes.  The division by
+// the sine amplifies rounding at low j by up to H / pi: 1e-13 of the cepstrum's scale, 6e-14 rad in the phases
+// (tools/minphase_pair_proto.py), far below the 1e-8 at which y is compared.
+// lsp / lsa: LDS, [0 .. H] each, may lie inside the FFT image (they are read before its first exchange).
+// On exit php[m] / pha[m] = Im S_k / F for k = lane + 64 m; the phase of bin H is 0.
+template <int N>
+__device__ __forceinline__ void minimum_phase_pair(const double* lsp, const double* lsa, cpx* img, const FftTw<N>& tw,
+                                                   int lane, double (&php)[N / 64], double (&pha)[N / 64]) {
+  constexpr int M = N / 64, F = 2 * N, H = N;
+  static_assert(M >= 8 && M % 8 == 0, "the constant factors below are eighths of a half turn");
+  lane = opaque_lane(lane);
+  cpx v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
+    const int a0 = i0 <= H ? i0 : F - i0, a1 = i1 <= H ? i1 : F - i1;             // the even extension
+    const double p0 = lsp[a0], q0 = lsa[a0], p1 = lsp[a1], q1 = lsa[a1];
+    v[m] = make_double2(p0 - q1, q0 + p1);                                           // w_2n + i w_2n+1
+  }
+  fft_forward<N>(v, img, tw, lane);
+  // e^(i pi j / H), j = lane + 64 m -- the lane's base turned by 32 m / M sixty-fourths of a turn -- and 1 / (2 sin):
+  // rebuilt where they are used (a product with a constant, a reciprocal with one Newton step) instead of kept in
+  // 4 M registers across the transforms
+  auto turn = [&](int m, cpx e0, cpx& e, double& inv) {
+    const int k64 = 32 * m / M;
+    e = k64 % 16 == 0 ? e0 : cmul(e0, cconj(cis64(k64 % 16)));
+    if (k64 / 16 == 1) e = make_double2(-e.y, e.x);
+    const double r0 = __builtin_amdgcn_rcp(e.y);
+    const double r1 = __builtin_fma(__builtin_fma(-e.y, r0, 1.0), r0, r0);           // 1 / sin to 1e-16 relative
+    inv = (m == 0 && lane == 0) ? 0.0 : 0.5 * r1;                                     // j = 0: nothing to separate
+  };
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M; ++m) img[lane + 64 * m] = v[m];                            // Z, plain layout
+  wave_sync();
+  {
+    const cpx e0 = cconj(make_double2(opaque_d(tw.wsplit.x), opaque_d(tw.wsplit.y)));   // W_2N^(-lane)
+    cpx zp[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) zp[m] = img[(N - (lane + 64 * m)) & (N - 1)];
+    wave_sync();                                                                     // partners read: the image may go
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      cpx e;
+      double inv;
+      turn(m, e0, e, inv);
+      const cpx R = make_double2((zp[m].x - v[m].x) * inv, (zp[m].y - v[m].y) * inv);   // -(Z_j - Z_(H-j)) / (2 sin)
+      // i e^(i th) R = (-(e.x R.y + e.y R.x), e.x R.x - e.y R.y);  A = Z - that + R;  g = 2 A
+      const double ax = v[m].x + __builtin_fma(e.x, R.y, e.y * R.x) + R.x;
+      const double ay = v[m].y - __builtin_fma(e.x, R.x, -(e.y * R.y)) + R.y;
+      const cpx g = (m == 0 && lane == 0) ? make_double2(0.0, 0.0) : make_double2(2.0 * ax, 2.0 * ay);
+      img[lane + 64 * m] = g;                                                         // folded cepstra, plain; g_0 = 0
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0) img[H] = make_double2(0.0, 0.0);                                   // g_H = 0
+  }
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
+    const cpx c0 = img[i0 <= H ? i0 : F - i0], c1 = img[i1 <= H ? i1 : F - i1];
+    const double s0 = i0 <= H ? 1.0 : -1.0, s1 = i1 <= H ? 1.0 : -1.0;              // the odd extension
+    v[m] = make_double2(s0 * c0.x - s1 * c1.y, s0 * c0.y + s1 * c1.x);
+  }
+  fft_forward<N>(v, img, tw, lane);
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M; ++m) img[lane + 64 * m] = v[m];
+  wave_sync();
+  {
+    const cpx e0 = cconj(make_double2(opaque_d(tw.wsplit.x), opaque_d(tw.wsplit.y)));
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int k = lane + 64 * m;
+      const cpx zp = img[(N - k) & (N - 1)];
+      cpx e;
+      double inv;
+      turn(m, e0, e, inv);
+      const cpx R = make_double2(-(zp.x + v[m].x) * inv, -(zp.y + v[m].y) * inv);     // -(Z_k + Z_(H-k)) / (2 sin)
+      const double gx = v[m].x + __builtin_fma(e.x, R.y, e.y * R.x) + R.x;
+      const double gy = v[m].y - __builtin_fma(e.x, R.x, -(e.y * R.y)) + R.y;
+      // transform of the odd extension = -2 i sum c sin = 2 X_a - 2 i X_p with Im S = -X: Im S_p = Im G / 2, Im S_a = -Re G / 2
+      const bool zero = m == 0 && lane == 0;
+      php[m] = zero ? 0.0 : gy * (0.5 / F);
+      pha[m] = zero ? 0.0 : -gx * (0.5 / F);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  wave_sync();
+}
+
 // Everything a pulse needs that is not spectral data, gathered by a fully parallel kernel so that
 // the per-pulse kernel starts with ONE (scalar) load instead of a binary search over the pulse
 // offsets followed by four levels of dependent loads.
@@ -501,6 +607,8 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
     const bool periodic = !(cvuv <= 0.5 || rat0 > 0.999);
 #pragma unroll
     for (int m = 0; m < (LEAN ? 1 : M); ++m) xp[m] = 0.0;
+    // A voiced pulse needs two minimum-phase spectra (periodic and aperiodic part): their phases come from ONE pair
+    // of complex transforms (minimum_phase_pair), their amplitudes are the square roots of the spectra themselves
     if (periodic) {
       wave_sync();
       auto log_periodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
@@ -511,16 +619,55 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
         }
         if (lane == 0) ls[H] = wm_log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
       };
+      cpx mp[MB];
       if constexpr (LEAN) {
-        double env[MB], rat[MB];
-        spectral(env, rat);
-        log_periodic(env, rat);
+        double* ls2 = ls + H + 2;                                   // the aperiodic log spectrum beside the periodic one
+        {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int k = m < M ? lane + 64 * m : H;
+            const double lp = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+            const double la = wm_log(env[m] * rat[m]) / 2.0;        // cvuv > 0.5 here (synthesis.cpp:53-56)
+            if (m < M || lane == 0) {
+              ls[k] = lp;
+              ls2[k] = la;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        wave_sync();
+        {
+          double php[M], pha[M];
+          minimum_phase_pair<N>(ls, ls2, img, tw, lane, php, pha);
+          // the aperiodic part's phases wait in the first half of the response row (free until the response is
+          // written; every lane re-reads its own), the periodic part's in the slots of the spectrum they become
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            out[lane + 64 * m] = pha[m];
+            mp[m] = make_double2(0.0, php[m]);
+          }
+          mp[M] = make_double2(0.0, 0.0);                             // bin H: real
+        }
+        {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+#pragma unroll
+          for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * (1.0 - rat[m]) + kSafe);
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          double sn = 0.0, cs = 1.0;
+          if (m < M) sincospi(mp[m].y * (1.0 / kPi), &sn, &cs);
+          mp[m] = make_double2(mp[m].x * cs, mp[m].x * sn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
         log_periodic(env_keep, rat_keep);
+        wave_sync();
+        minimum_phase<N>(ls, img, tw, lane, mp);
       }
-      wave_sync();
-      cpx mp[MB];
-      minimum_phase<N>(ls, img, tw, lane, mp);
       const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
       // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
       // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
@@ -569,27 +716,50 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
 
     // ---- GetAperiodicResponse (:38-68) ----
     wave_sync();
-    {
-      auto log_aperiodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
+    cpx mp[MB];
+    if (LEAN && periodic) {
+      // phases from the pair above (parked in the response row); amplitude sqrt(env * rat) (cvuv > 0.5 on a periodic pulse)
+      {
+        const int lp_ = opaque_lane(lane);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const int k = m < M ? lane + 64 * m : H;
-          const double val = wm_log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
-          if (m < M || lane == 0) ls[k] = val;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if constexpr (LEAN) {
+        for (int m = 0; m < M; ++m) mp[m] = make_double2(0.0, out[lp_ + 64 * m]);
+        mp[M] = make_double2(0.0, 0.0);
+      }
+      {
         double env[MB], rat[MB];
         spectral(env, rat);
-        log_aperiodic(env, rat);
-      } else {
-        log_aperiodic(env_keep, rat_keep);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * rat[m]);
       }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        double sn = 0.0, cs = 1.0;
+        if (m < M) sincospi(mp[m].y * (1.0 / kPi), &sn, &cs);
+        mp[m] = make_double2(mp[m].x * cs, mp[m].x * sn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      {
+        auto log_aperiodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int k = m < M ? lane + 64 * m : H;
+            const double val = wm_log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
+            if (m < M || lane == 0) ls[k] = val;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        if constexpr (LEAN) {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+          log_aperiodic(env, rat);
+        } else {
+          log_aperiodic(env_keep, rat_keep);
+        }
+      }
+      wave_sync();
+      minimum_phase<N>(ls, img, tw, lane, mp);
     }
-    wave_sync();
-    cpx mp[MB];
-    minimum_phase<N>(ls, img, tw, lane, mp);
     // GetNoiseSpectrum (:19-33)
     cpx v[M];
     {
