@@ -37,8 +37,13 @@ MATCH = {"analysis_synthesis": is_usual_d4c,
 
 # a kernel that runs exactly once per pass of the workload: its launches count the passes of a profiled run, so that a
 # pass that launches the dominant kernel several times (Synthesis in pieces, D4C in chunks) is still one pass
-PASS_MARK = {"analysis_synthesis": "synth_timebase_kernel", "synthesis": "synth_timebase_kernel",
+PASS_MARK = {"analysis_synthesis": "stonemask_kernel", "synthesis": "synth_timebase_kernel",
              "harvest": "hv_contour_kernel"}
+
+
+# launches of the mark per pass: Synthesis alone prepares a batch in two parts (synthesis.hip: launch_synthesis), each
+# with its own time-base launch
+MARKS_PER_PASS = {"synthesis": 2}
 
 
 def total(dirname, counter, match=is_usual_d4c, mark=None):
@@ -65,6 +70,10 @@ def main():
     fkb, fl, name, fp = total(fdir, "FETCH_SIZE", MATCH[workload], PASS_MARK[workload])
     wkb, wl, _, wp = total(wdir, "WRITE_SIZE", MATCH[workload], PASS_MARK[workload])
     assert fl and fl == wl and fp and fp == wp, (fl, wl, fp, wp)
+    per = MARKS_PER_PASS.get(workload, 1)
+    assert fp % per == 0, (fp, per)
+    fp //= per
+    wp //= per
     kname = (name or "d4c_kernel").split("(")[0]
     if "d4cb_" in kname:
         kname = "d4cb_centroid_kernel + d4cb_spectrum_kernel + d4cb_band_kernel (the D4C scope at fft 4096)"
