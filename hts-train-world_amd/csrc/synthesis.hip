@@ -550,6 +550,10 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
   // (32), and the log spectrum shares the LDS image of the transform that consumes it (8 KB: 9 workgroups per CU
   // instead of 6).  One wave per SIMD had nothing to hide the LDS round trips of its transforms behind.
   constexpr bool LEAN = F == 2048 || F == 1024;
+  // PAIRED: the two minimum-phase spectra of a voiced pulse through one pair of complex transforms
+  // (minimum_phase_pair).  At fft 2048 the pair's registers cost four spilled ones at two waves per SIMD and the
+  // kernel is 1 % slower with it than without (A/B at 48 kHz: 10.08 against 9.95 ms), so only fft 1024 takes it.
+  constexpr bool PAIRED = F == 1024;
   __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + (LEAN ? 0 : H + 2)];
   cpx* img = reinterpret_cast<cpx*>(smem);
   double* ls = LEAN ? smem : smem + 2 * FftLds<N>::kElems;
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
         if (lane == 0) ls[H] = wm_log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
       };
       cpx mp[MB];
-      if constexpr (LEAN) {
+      if constexpr (PAIRED) {
         double* ls2 = ls + H + 2;                                   // the aperiodic log spectrum beside the periodic one
         {
           double env[MB], rat[MB];
@@ -664,7 +668,13 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
-        log_periodic(env_keep, rat_keep);
+        if constexpr (LEAN) {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+          log_periodic(env, rat);
+        } else {
+          log_periodic(env_keep, rat_keep);
+        }
         wave_sync();
         minimum_phase<N>(ls, img, tw, lane, mp);
       }
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
     // ---- GetAperiodicResponse (:38-68) ----
     wave_sync();
     cpx mp[MB];
-    if (LEAN && periodic) {
+    if (PAIRED && periodic) {
       // phases from the pair above (parked in the response row); amplitude sqrt(env * rat) (cvuv > 0.5 on a periodic pulse)
       {
         const int lp_ = opaque_lane(lane);
