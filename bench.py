@@ -557,7 +557,7 @@ def host_inclusive(env, ctx, xs, fs, fp, coded=None):
     x16 = pl.to_int16(np.concatenate(xs))
     for xb in pipe.x_pinned:                        # the waveforms wait in pinned memory, as decoded wav payloads would
         xb.numpy()[:] = x16
-    steps = max(2, args.steps)
+    steps = max(8, args.steps)                      # a pipeline: its fill and drain are amortised over the steps
     for _ in range(2):
         pipe.result(pipe.submit())
     env.barrier()

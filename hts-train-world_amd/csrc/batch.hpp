@@ -225,6 +225,8 @@ int launch_utterance_status(Batch& b, const double* d_x, const double* d_f0, con
                             int* d_status);
 int launch_vibrato(Batch& b, const float* d_lf0, const int* seg_utt_off, const int* seg_start, const int* seg_end,
                    const double* seg_pitch, float* d_vib, float* d_lf0_out, int* n_too_long);
+int launch_pcm16_to_samples(Batch& b, const int16_t* d_pcm, double* d_x);
+int launch_samples_to_pcm16(Batch& b, const double* d_y, int16_t* d_pcm);
 int codec_num_aperiodicities(int fs);
 int launch_code_spectral_envelope(Batch& b, const double* d_sp, int ndim, double* d_coded);
 int launch_decode_spectral_envelope(Batch& b, const double* d_coded, int ndim, double* d_sp);

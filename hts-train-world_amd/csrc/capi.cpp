@@ -315,6 +315,14 @@ void WorldMi355HtkHeader(int n_frames, int sampling_rate, int frame_shift_sample
   memcpy(out12 + 8, &c, 2);
   memcpy(out12 + 10, &d, 2);
 }
+int WorldMi355SamplesFromPcm16(WorldMi355Batch* b, const int16_t* pcm, double* x) {
+  OnDevice dev_(b->b.ctx[0]);
+  return wm::launch_pcm16_to_samples(b->b, pcm, x);
+}
+int WorldMi355SamplesToPcm16(WorldMi355Batch* b, const double* y, int16_t* pcm) {
+  OnDevice dev_(b->b.ctx[0]);
+  return wm::launch_samples_to_pcm16(b->b, y, pcm);
+}
 int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0) {
   OnDevice dev_(b->b.ctx[0]);
   return wm::launch_harvest(b->b, x, t, f0);

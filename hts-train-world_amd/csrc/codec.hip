@@ -245,6 +245,36 @@ __global__ __launch_bounds__(256) void codec_lf0_kernel(const double* __restrict
   if (i < n) lf0[i] = (float)(f0[i] != 0 ? log(f0[i]) : 0.0);
 }
 
+// The sample formats on either side of the path: wavread's x = s / 2^15 for 16-bit files (test/audioio.cpp:236-249)
+// and wavwrite's s = clamp(int(y * 32767)) with the cast truncating towards zero (:160-167).  One pass each over the
+// batch's samples (the host pipeline did them as two and four elementwise passes).  A NaN writes 0.
+__global__ __launch_bounds__(256) void pcm16_to_samples_kernel(const int16_t* __restrict__ pcm, int64_t n,
+                                                               double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    x[i] = (double)pcm[i] * (1.0 / 32768.0);                      // exact: a power of two
+}
+__global__ __launch_bounds__(256) void samples_to_pcm16_kernel(const double* __restrict__ y, int64_t n,
+                                                               int16_t* __restrict__ pcm) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = trunc(y[i] * 32767.0);
+    pcm[i] = (int16_t)(v != v ? 0.0 : fmin(32767.0, fmax(-32768.0, v)));
+  }
+}
+int launch_pcm16_to_samples(Batch& b, const int16_t* d_pcm, double* d_x) {
+  if (b.total_x <= 0) return WM_OK;
+  const int64_t blocks = (b.total_x + 1023) / 1024;
+  hipLaunchKernelGGL(pcm16_to_samples_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, b.ctx->stream,
+                     d_pcm, b.total_x, d_x);
+  return wm_check(hipGetLastError());
+}
+int launch_samples_to_pcm16(Batch& b, const double* d_y, int16_t* d_pcm) {
+  if (b.total_y <= 0) return WM_OK;
+  const int64_t blocks = (b.total_y + 1023) / 1024;
+  hipLaunchKernelGGL(samples_to_pcm16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, b.ctx->stream,
+                     d_y, b.total_y, d_pcm);
+  return wm_check(hipGetLastError());
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 static double to_mel(double f) { return kCodecM0 * log(f / kCodecF0 + 1.0); }         // codec.cpp:59-61
 static double from_mel(double m) { return kCodecF0 * (exp(m / kCodecM0) - 1.0); }     // codec.cpp:66-68

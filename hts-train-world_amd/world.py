@@ -73,6 +73,8 @@ def load_library():
     L.WorldMi355CheapTrick.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355D4C.argtypes = [vp, vp, vp, vp, vp]
     L.WorldMi355Synthesis.argtypes = [vp, vp, vp, vp, vp]
+    L.WorldMi355SamplesFromPcm16.argtypes = [vp, vp, vp]
+    L.WorldMi355SamplesToPcm16.argtypes = [vp, vp, vp]
     L.WorldMi355Analyze.argtypes = [vp, vp, vp, vp, vp, vp]
     L.WorldMi355AnalyzeSynthesize.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.WorldMi355UtteranceStatus.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -209,6 +211,23 @@ class WorldBatch:
         ap = out if out is not None else self._new(self.total_frames, self.bins)
         _check(load_library().WorldMi355D4C(self.handle, self._p(x), self._p(t), self._p(f0), self._p(ap)), "D4C")
         return ap
+
+    def samples_from_pcm16(self, pcm, out=None):
+        """int16 cuda tensor [total_samples] (the wav payload) -> float64 samples s / 32768 (wavread)."""
+        assert pcm.is_cuda and pcm.is_contiguous() and str(pcm.dtype) == "torch.int16" and pcm.numel() == self.total_samples
+        x = out if out is not None else self._new(self.total_samples)
+        _check(load_library().WorldMi355SamplesFromPcm16(self.handle, C.c_void_p(pcm.data_ptr()), self._p(x)),
+               "SamplesFromPcm16")
+        return x
+
+    def samples_to_pcm16(self, y, out=None):
+        """float64 y [total_out] -> int16 as wavwrite stores it: clamp(int(y * 32767)), truncating towards zero."""
+        import torch
+        pcm = out if out is not None else torch.empty(self.total_out, dtype=torch.int16, device="cuda")
+        assert pcm.is_cuda and pcm.is_contiguous() and pcm.numel() == self.total_out
+        _check(load_library().WorldMi355SamplesToPcm16(self.handle, self._p(y), C.c_void_p(pcm.data_ptr())),
+               "SamplesToPcm16")
+        return pcm
 
     def analyze(self, x, out=None):
         """Dio -> StoneMask -> CheapTrick -> D4C (test/analysis.cpp:243-390)."""

@@ -107,6 +107,13 @@ int WorldMi355Synthesis(WorldMi355Batch* b, const double* f0, const double* sp, 
                         double* y);
 int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0);
 
+/* The sample formats of the callers (test/audioio.cpp), over the batch's concatenated samples, DEVICE pointers:
+ *   x[i] = pcm[i] / 32768          wavread of a 16-bit file (:236-249); total samples of the batch
+ *   pcm[i] = clamp(int(y[i] * 32767), -32768, 32767), the cast truncating towards zero: wavwrite (:160-167);
+ *            total output samples of the batch.  A NaN sample writes 0 (the reference's cast is undefined there). */
+int WorldMi355SamplesFromPcm16(WorldMi355Batch* b, const int16_t* pcm, double* x);
+int WorldMi355SamplesToPcm16(WorldMi355Batch* b, const double* y, int16_t* pcm);
+
 /* Dio -> StoneMask -> CheapTrick -> D4C, as test/analysis.cpp:243-390 chains them. */
 int WorldMi355Analyze(WorldMi355Batch* b, const double* x, double* t, double* f0, double* sp,
                       double* ap);

@@ -929,6 +929,26 @@ def test_synthesis_in_response_chunks(gpu, monkeypatch):
     b.close()
 
 
+def test_pcm16_conversions(gpu):
+    """wavread's s / 32768 and wavwrite's clamp(int(y * 32767)) (test/audioio.cpp:236-249, :160-167) over a batch."""
+    torch, W, ctx = gpu
+    lens = [1000, 37, 4096 + 3]
+    b = W.WorldBatch(ctx, W.default_params(16000, 5.0), x_lengths=lens)
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32768, size=sum(lens), dtype=np.int16)
+    pcm[:4] = [-32768, 32767, 0, -1]
+    x = b.samples_from_pcm16(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(x, pcm.astype(np.float64) / 32768.0)
+    y = rng.uniform(-1.3, 1.3, size=int(b.total_out))
+    y[:8] = [0.0, -0.0, 1.0, -1.0, 32767.5 / 32767.0, -32768.9 / 32767.0, 0.99999, np.nan]
+    got = b.samples_to_pcm16(torch.from_numpy(y).cuda()).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        want = np.clip(np.trunc(y * 32767.0), -32768, 32767)
+    want[np.isnan(want)] = 0
+    np.testing.assert_array_equal(got, want.astype(np.int16))
+    b.close()
+
+
 def test_host_pipeline_gives_the_device_results(gpu, pkg):
     """hts-train-world_amd/pipeline.py: int16 in, float32 features and int16 resynthesis out, three streams, two
     slots -- the same numbers as the resident API converted afterwards, whatever the overlap, step after step."""
