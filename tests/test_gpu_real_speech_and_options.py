@@ -224,3 +224,37 @@ def test_option_sweep_in_a_mixed_batch(gpu, oracle):
         if F == 512:
             assert below > 0                                               # the default-f0 branch is taken
         b.close()
+
+
+@pytest.mark.parametrize("name", REAL)
+def test_real_speech_front_end_options(gpu, oracle, name):
+    """The F0 front ends away from their defaults on the reference's own inputs, against the oracle (pinned to the
+    compiled reference on the same grid by tests/test_oracle_vs_ref.py): Dio with decimation (speed 2, 4: the
+    thresholded contour logic behind a decimated signal), 1 and 10 ms hops, a narrower search range, more channels
+    per octave; Harvest with other floors / ceilings and a 1 ms hop; each followed by StoneMask."""
+    torch, W, ctx = gpu
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = g["x_i16"].astype(np.float64) / 32768.0
+    fs = int(g["fs"])
+    xc = torch.from_numpy(x).cuda()
+    for kw in (dict(speed=2), dict(speed=4), dict(frame_period=1.0), dict(frame_period=10.0),
+               dict(f0_floor=50.0, f0_ceil=500.0), dict(channels_in_octave=4.0), dict(allowed_range=0.05)):
+        fp = kw.get("frame_period", 5.0)
+        p = W.default_params(fs, fp, **{k: v for k, v in kw.items() if k != "frame_period"})
+        b = W.WorldBatch(ctx, p, x_lengths=[len(x)])
+        t, f0 = b.dio(xc)
+        to, fo = oracle.dio(x, fs, **dict(kw, frame_period=fp))
+        np.testing.assert_array_equal(t.cpu().numpy(), to)
+        same_voicing(f0.cpu().numpy(), fo)
+        np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+        sm = b.stonemask(xc, t, f0).cpu().numpy()
+        np.testing.assert_allclose(sm, oracle.stonemask(x, fs, to, fo), atol=F0_TOL, rtol=0)
+        b.close()
+    for fp, lo, hi in ((5.0, 50.0, 500.0), (5.0, 100.0, 1000.0), (1.0, 71.0, 800.0)):
+        b = W.WorldBatch(ctx, W.default_params(fs, fp, f0_floor=lo, f0_ceil=hi), x_lengths=[len(x)])
+        t, f0 = b.harvest(xc)
+        to, fo = oracle.harvest(x, fs, fp, lo, hi)
+        np.testing.assert_array_equal(t.cpu().numpy(), to)
+        same_voicing(f0.cpu().numpy(), fo)
+        np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
+        b.close()

@@ -179,3 +179,26 @@ def test_reference_wavs(oracle, reference):
         th, ho = oracle.harvest(x, fs)
         assert ((hr > 0) == (ho > 0)).all()
         np.testing.assert_allclose(ho, hr, atol=1e-8, rtol=0)
+
+
+def test_reference_wavs_front_end_options(oracle, reference):
+    """Dio / Harvest away from their defaults on the reference's own inputs (the grid that
+    tests/test_gpu_real_speech_and_options.py::test_real_speech_front_end_options runs on the HIP path)."""
+    import os
+    from conftest import GOLDEN
+    for name in ("real_arctic_a0001", "real_vaiueo2d"):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        x = g["x_i16"].astype(np.float64) / 32768.0
+        fs = int(g["fs"])
+        for kw in (dict(speed=2), dict(speed=4), dict(frame_period=1.0), dict(frame_period=10.0),
+                   dict(f0_floor=50.0, f0_ceil=500.0), dict(channels_in_octave=4.0), dict(allowed_range=0.05)):
+            tr, fr = reference.dio(x, fs, **kw)
+            to, fo = oracle.dio(x, fs, **kw)
+            np.testing.assert_array_equal(tr, to)
+            assert ((fr > 0) == (fo > 0)).all(), kw
+            np.testing.assert_allclose(fo, fr, atol=1e-6, rtol=0)
+        for fp, lo, hi in ((5.0, 50.0, 500.0), (5.0, 100.0, 1000.0), (1.0, 71.0, 800.0)):
+            tr, fr = reference.harvest(x, fs, fp, lo, hi)
+            to, fo = oracle.harvest(x, fs, fp, lo, hi)
+            assert ((fr > 0) == (fo > 0)).all(), (fp, lo, hi)
+            np.testing.assert_allclose(fo, fr, atol=1e-8, rtol=0)
