@@ -40,6 +40,10 @@ int phase_read_synthesis(unsigned long long* out32);
 
 using namespace wm;
 
+// the drop-in entry points' failure handler (WorldMi355SetErrorHandler; see die() below)
+static WorldMi355ErrorHandler g_on_error = nullptr;
+static void* g_on_error_user = nullptr;
+
 struct WorldMi355Context { Context c; };
 struct WorldMi355Batch { Batch b; };
 
@@ -359,6 +363,10 @@ __attribute__((visibility("default"))) int WorldMi355DebugPhases(int unit, unsig
   return unit == 0 ? wm::phase_read_d4c(out32) : unit == 1 ? wm::phase_read_cheaptrick(out32) : wm::phase_read_synthesis(out32);
 }
 #endif
+void WorldMi355SetErrorHandler(WorldMi355ErrorHandler handler, void* user) {
+  g_on_error = handler;
+  g_on_error_user = user;
+}
 int WorldMi355TimingEnable(WorldMi355Context* h, int on) {
   OnDevice dev_(h->c);
   Context& c = h->c;
@@ -393,7 +401,16 @@ namespace {
 std::mutex g_mu;
 WorldMi355Context* g_ctx = nullptr;
 
+// A failure inside a drop-in entry point (no device, a HIP error, an unsupported size): the reference's functions
+// return void, so by default it ends in a message on stderr and abort(), like the reference's own bad_alloc.  A host
+// that would rather lose one utterance than the process installs a handler (WorldMi355SetErrorHandler): the failure
+// then unwinds to the entry point, which calls the handler and returns with its outputs unspecified.
+struct DropInError {
+  const char* where;
+  int code;
+};
 [[noreturn]] void die(const char* where, int rc) {
+  if (g_on_error) throw DropInError{where, rc};
   fprintf(stderr, "libworld_mi355: %s failed (code %d): %s\n", where, rc, WorldMi355LastError());
   abort();
 }
@@ -505,6 +522,14 @@ struct Workspace {
   }
 };
 Workspace g_ws;
+
+void drop_in_failed(const DropInError& e) {
+  (void)hipDeviceSynchronize();               // nothing of the failed call may still write into the staging buffers
+  g_ws.pending.clear();
+  g_ws.stage_at = 0;
+  g_ws.x_valid = false;
+  if (g_on_error) g_on_error(e.where, e.code, WorldMi355LastError(), g_on_error_user);
+}
 
 hipStream_t ws_stream() { return default_context()->c.stream; }
 
@@ -618,27 +643,31 @@ void InitializeDioOption(DioOption* option) {                           // dio.c
 void Dio(const double* x, int x_length, int fs, const DioOption* option, double* temporal_positions,
          double* f0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, option->frame_period, &p);
-  p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
-  p.channels_in_octave = option->channels_in_octave; p.speed = option->speed;
-  p.allowed_range = option->allowed_range;
-  p.fft_size = 1024;   // unused by DIO
-  CallTrace tr("Dio");
-  WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
-  tr.mark("batch");
-  const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
-  double* dx = put_x(x, (size_t)x_length);
-  tr.mark("stage");
-  double* dt = g_ws.device(kT, nf);
-  double* df = g_ws.device(kF0, nf);
-  run_or_die("Dio", WorldMi355Dio(b, dx, dt, df));
-  tr.mark("launch");
-  tr.mark("kernels", true);
-  get(dt, temporal_positions, nf);
-  get(df, f0, nf);
-  g_ws.finish();
-  tr.mark("back");
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, option->frame_period, &p);
+    p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
+    p.channels_in_octave = option->channels_in_octave; p.speed = option->speed;
+    p.allowed_range = option->allowed_range;
+    p.fft_size = 1024;   // unused by DIO
+    CallTrace tr("Dio");
+    WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
+    tr.mark("batch");
+    const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
+    double* dx = put_x(x, (size_t)x_length);
+    tr.mark("stage");
+    double* dt = g_ws.device(kT, nf);
+    double* df = g_ws.device(kF0, nf);
+    run_or_die("Dio", WorldMi355Dio(b, dx, dt, df));
+    tr.mark("launch");
+    tr.mark("kernels", true);
+    get(dt, temporal_positions, nf);
+    get(df, f0, nf);
+    g_ws.finish();
+    tr.mark("back");
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 int GetSamplesForHarvest(int fs, int x_length, double frame_period) {  // harvest.cpp:1219-1221
@@ -652,35 +681,43 @@ void InitializeHarvestOption(HarvestOption* option) {                   // harve
 void Harvest(const double* x, int x_length, int fs, const HarvestOption* option,
              double* temporal_positions, double* f0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, option->frame_period, &p);
-  p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
-  p.fft_size = 1024;   // unused by Harvest
-  WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
-  const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
-  double* dx = put_x(x, (size_t)x_length);
-  double* dt = g_ws.device(kT, nf);
-  double* df = g_ws.device(kF0, nf);
-  run_or_die("Harvest", WorldMi355Harvest(b, dx, dt, df));
-  get(dt, temporal_positions, nf);
-  get(df, f0, nf);
-  g_ws.finish();
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, option->frame_period, &p);
+    p.f0_floor = option->f0_floor; p.f0_ceil = option->f0_ceil;
+    p.fft_size = 1024;   // unused by Harvest
+    WorldMi355Batch* b = g_ws.batch(p, x_length, -1, -1);
+    const size_t nf = (size_t)WorldMi355BatchTotalFrames(b);
+    double* dx = put_x(x, (size_t)x_length);
+    double* dt = g_ws.device(kT, nf);
+    double* df = g_ws.device(kF0, nf);
+    run_or_die("Harvest", WorldMi355Harvest(b, dx, dt, df));
+    get(dt, temporal_positions, nf);
+    get(df, f0, nf);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 void StoneMask(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
                int f0_length, double* refined_f0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, 5.0, &p);
-  p.fft_size = 1024;   // unused by StoneMask
-  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
-  double* dx = put_x(x, (size_t)x_length);
-  double* dt = put(kT, temporal_positions, (size_t)f0_length);
-  double* df = put(kF0, f0, (size_t)f0_length);
-  double* dr = g_ws.device(kOut, (size_t)f0_length);
-  run_or_die("StoneMask", WorldMi355StoneMask(b, dx, dt, df, dr));
-  get(dr, refined_f0, (size_t)f0_length);
-  g_ws.finish();
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, 5.0, &p);
+    p.fft_size = 1024;   // unused by StoneMask
+    WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+    double* dx = put_x(x, (size_t)x_length);
+    double* dt = put(kT, temporal_positions, (size_t)f0_length);
+    double* df = put(kF0, f0, (size_t)f0_length);
+    double* dr = g_ws.device(kOut, (size_t)f0_length);
+    run_or_die("StoneMask", WorldMi355StoneMask(b, dx, dt, df, dr));
+    get(dr, refined_f0, (size_t)f0_length);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 int GetFFTSizeForCheapTrick(int fs, const CheapTrickOption* option) {   // cheaptrick.cpp:191-194
@@ -697,48 +734,56 @@ void InitializeCheapTrickOption(int fs, CheapTrickOption* option) {      // chea
 void CheapTrick(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
                 int f0_length, const CheapTrickOption* option, double** spectrogram) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, 5.0, &p);
-  p.q1 = option->q1;
-  p.fft_size = option->fft_size;
-  const int w = option->fft_size / 2 + 1;
-  CallTrace tr("CheapTrick");
-  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
-  tr.mark("batch");
-  double* dx = put_x(x, (size_t)x_length);
-  double* dt = put(kT, temporal_positions, (size_t)f0_length);
-  double* df = put(kF0, f0, (size_t)f0_length);
-  tr.mark("stage");
-  double* ds = g_ws.device(kSp, (size_t)f0_length * w);
-  run_or_die("CheapTrick", WorldMi355CheapTrick(b, dx, dt, df, ds));
-  tr.mark("launch");
-  tr.mark("kernels", true);
-  get_rows(ds, spectrogram, f0_length, w);
-  g_ws.finish();
-  tr.mark("back");
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, 5.0, &p);
+    p.q1 = option->q1;
+    p.fft_size = option->fft_size;
+    const int w = option->fft_size / 2 + 1;
+    CallTrace tr("CheapTrick");
+    WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+    tr.mark("batch");
+    double* dx = put_x(x, (size_t)x_length);
+    double* dt = put(kT, temporal_positions, (size_t)f0_length);
+    double* df = put(kF0, f0, (size_t)f0_length);
+    tr.mark("stage");
+    double* ds = g_ws.device(kSp, (size_t)f0_length * w);
+    run_or_die("CheapTrick", WorldMi355CheapTrick(b, dx, dt, df, ds));
+    tr.mark("launch");
+    tr.mark("kernels", true);
+    get_rows(ds, spectrogram, f0_length, w);
+    g_ws.finish();
+    tr.mark("back");
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 void InitializeD4COption(D4COption* option) { option->threshold = 0.85; }   // d4c.cpp:399-401
 void D4C(const double* x, int x_length, int fs, const double* temporal_positions, const double* f0,
          int f0_length, int fft_size, const D4COption* option, double** aperiodicity) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, 5.0, &p);
-  p.fft_size = fft_size;
-  p.d4c_threshold = option->threshold;
-  const int w = fft_size / 2 + 1;
-  WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
-  double* dx = put_x(x, (size_t)x_length);
-  double* dt = put(kT, temporal_positions, (size_t)f0_length);
-  double* df = put(kF0, f0, (size_t)f0_length);
-  CallTrace tr("D4C");
-  double* da = g_ws.device(kAp, (size_t)f0_length * w);
-  run_or_die("D4C", WorldMi355D4C(b, dx, dt, df, da));
-  tr.mark("launch");
-  tr.mark("kernels", true);
-  get_rows(da, aperiodicity, f0_length, w);
-  g_ws.finish();
-  tr.mark("back");
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, 5.0, &p);
+    p.fft_size = fft_size;
+    p.d4c_threshold = option->threshold;
+    const int w = fft_size / 2 + 1;
+    WorldMi355Batch* b = g_ws.batch(p, x_length, f0_length, -1);
+    double* dx = put_x(x, (size_t)x_length);
+    double* dt = put(kT, temporal_positions, (size_t)f0_length);
+    double* df = put(kF0, f0, (size_t)f0_length);
+    CallTrace tr("D4C");
+    double* da = g_ws.device(kAp, (size_t)f0_length * w);
+    run_or_die("D4C", WorldMi355D4C(b, dx, dt, df, da));
+    tr.mark("launch");
+    tr.mark("kernels", true);
+    get_rows(da, aperiodicity, f0_length, w);
+    g_ws.finish();
+    tr.mark("back");
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 // ---- world/codec.h --------------------------------------------------------------------------------
@@ -757,39 +802,51 @@ static WorldMi355Batch* codec_batch(int fs, int fft_size, int f0_length) {   // 
 void CodeSpectralEnvelope(const double* const* spectrogram, int f0_length, int fs, int fft_size,
                           int number_of_dimensions, double** coded_spectral_envelope) {
   std::lock_guard<std::mutex> lock(g_mu);
-  const int w = fft_size / 2 + 1;
-  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
-  double* ds = put_rows(kSp, spectrogram, f0_length, w);
-  double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_dimensions);
-  run_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(b, ds, number_of_dimensions, dc));
-  get_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
-  g_ws.finish();
+  try {
+    const int w = fft_size / 2 + 1;
+    WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+    double* ds = put_rows(kSp, spectrogram, f0_length, w);
+    double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_dimensions);
+    run_or_die("CodeSpectralEnvelope", WorldMi355CodeSpectralEnvelope(b, ds, number_of_dimensions, dc));
+    get_rows(dc, coded_spectral_envelope, f0_length, number_of_dimensions);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 void DecodeSpectralEnvelope(const double* const* coded_spectral_envelope, int f0_length, int fs, int fft_size,
                             int number_of_dimensions, double** spectrogram) {
   std::lock_guard<std::mutex> lock(g_mu);
-  const int w = fft_size / 2 + 1;
-  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
-  double* dc = put_rows(kCoded, coded_spectral_envelope, f0_length, number_of_dimensions);
-  double* ds = g_ws.device(kSp, (size_t)f0_length * w);
-  run_or_die("DecodeSpectralEnvelope", WorldMi355DecodeSpectralEnvelope(b, dc, number_of_dimensions, ds));
-  get_rows(ds, spectrogram, f0_length, w);
-  g_ws.finish();
+  try {
+    const int w = fft_size / 2 + 1;
+    WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+    double* dc = put_rows(kCoded, coded_spectral_envelope, f0_length, number_of_dimensions);
+    double* ds = g_ws.device(kSp, (size_t)f0_length * w);
+    run_or_die("DecodeSpectralEnvelope", WorldMi355DecodeSpectralEnvelope(b, dc, number_of_dimensions, ds));
+    get_rows(ds, spectrogram, f0_length, w);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, int fft_size,
                       int number_of_aperiodicities, double** coded_aperiodicity) {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (number_of_aperiodicities != codec_num_aperiodicities(fs))
-    die("CodeAperiodicity: number_of_aperiodicities must be GetNumberOfAperiodicities(fs)", WM_ERR_BAD_ARG);
-  const int w = fft_size / 2 + 1;
-  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
-  double* da = put_rows(kAp, aperiodicity, f0_length, w);
-  double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_aperiodicities);
-  run_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(b, da, dc));
-  get_rows(dc, coded_aperiodicity, f0_length, number_of_aperiodicities);
-  g_ws.finish();
+  try {
+    if (number_of_aperiodicities != codec_num_aperiodicities(fs))
+      die("CodeAperiodicity: number_of_aperiodicities must be GetNumberOfAperiodicities(fs)", WM_ERR_BAD_ARG);
+    const int w = fft_size / 2 + 1;
+    WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+    double* da = put_rows(kAp, aperiodicity, f0_length, w);
+    double* dc = g_ws.device(kCoded, (size_t)f0_length * number_of_aperiodicities);
+    run_or_die("CodeAperiodicity", WorldMi355CodeAperiodicity(b, da, dc));
+    get_rows(dc, coded_aperiodicity, f0_length, number_of_aperiodicities);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 // Positional meaning of the reference's DEFINITION (codec.cpp:237-238): the 4th argument is the number
@@ -797,62 +854,70 @@ void CodeAperiodicity(const double* const* aperiodicity, int f0_length, int fs, 
 void DecodeAperiodicity(const double* const* coded_aperiodicity, int f0_length, int fs, int arg4_number_of_aperiodicities,
                         int arg5_fft_size, double** aperiodicity) {
   std::lock_guard<std::mutex> lock(g_mu);
-  const int nap = arg4_number_of_aperiodicities, fft_size = arg5_fft_size;
-  if (nap != codec_num_aperiodicities(fs))
-    die("DecodeAperiodicity: 4th argument must be GetNumberOfAperiodicities(fs) (codec.cpp:237-238)", WM_ERR_BAD_ARG);
-  const int w = fft_size / 2 + 1;
-  WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
-  double* dc = put_rows(kCoded, coded_aperiodicity, f0_length, nap);
-  double* da = g_ws.device(kAp, (size_t)f0_length * w);
-  run_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(b, dc, da));
-  get_rows(da, aperiodicity, f0_length, w);
-  g_ws.finish();
+  try {
+    const int nap = arg4_number_of_aperiodicities, fft_size = arg5_fft_size;
+    if (nap != codec_num_aperiodicities(fs))
+      die("DecodeAperiodicity: 4th argument must be GetNumberOfAperiodicities(fs) (codec.cpp:237-238)", WM_ERR_BAD_ARG);
+    const int w = fft_size / 2 + 1;
+    WorldMi355Batch* b = codec_batch(fs, fft_size, f0_length);
+    double* dc = put_rows(kCoded, coded_aperiodicity, f0_length, nap);
+    double* da = g_ws.device(kAp, (size_t)f0_length * w);
+    run_or_die("DecodeAperiodicity", WorldMi355DecodeAperiodicity(b, dc, da));
+    get_rows(da, aperiodicity, f0_length, w);
+    g_ws.finish();
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
+  }
 }
 
 void Synthesis(const double* f0, int f0_length, const double* const* spectrogram,
                const double* const* aperiodicity, int fft_size, double frame_period, int fs, int y_length,
                double* y) {
   std::lock_guard<std::mutex> lock(g_mu);
-  WorldMi355Params p;
-  WorldMi355DefaultParams(fs, frame_period, &p);
-  p.fft_size = fft_size;
-  const int w = fft_size / 2 + 1;
-  CallTrace tr("Synthesis");
-  WorldMi355Batch* b = g_ws.batch(p, -1, f0_length, y_length);
-  tr.mark("batch");
-  // f0 first, and the f0-only stage of Synthesis behind it (time base, pulse search: a latency chain as long as the
-  // utterance); the rows of sp / ap are gathered into pinned memory and sent while that runs
-  double* df = put(kF0, f0, (size_t)f0_length);
-  double* dy = g_ws.device(kY, (size_t)y_length);
-  {
-    OnDevice dev_(b->b.ctx[0]);
-    run_or_die("Synthesis", synthesis_begin(b->b, df, dy));
+  try {
+    WorldMi355Params p;
+    WorldMi355DefaultParams(fs, frame_period, &p);
+    p.fft_size = fft_size;
+    const int w = fft_size / 2 + 1;
+    CallTrace tr("Synthesis");
+    WorldMi355Batch* b = g_ws.batch(p, -1, f0_length, y_length);
+    tr.mark("batch");
+    // f0 first, and the f0-only stage of Synthesis behind it (time base, pulse search: a latency chain as long as the
+    // utterance); the rows of sp / ap are gathered into pinned memory and sent while that runs
+    double* df = put(kF0, f0, (size_t)f0_length);
+    double* dy = g_ws.device(kY, (size_t)y_length);
+    {
+      OnDevice dev_(b->b.ctx[0]);
+      run_or_die("Synthesis", synthesis_begin(b->b, df, dy));
+    }
+    tr.mark("begin");
+    // (the device and pinned buffers are sized before anything of this call is in flight on the upload stream: growing
+    // them synchronises the context's stream only)
+    const size_t cells = (size_t)f0_length * w;
+    (void)g_ws.device(kSp, cells);
+    (void)g_ws.device(kAp, cells);
+    (void)g_ws.stage(2 * cells + 16);
+    g_ws.stage_at -= (2 * cells + 16 + 7) & ~(size_t)7;               // reserved, not taken
+    hipStream_t up = up_stream();
+    double* ds = put_rows(kSp, spectrogram, f0_length, w, up);
+    double* da = put_rows(kAp, aperiodicity, f0_length, w, up);
+    if (hipEventRecord(g_up_done, up) != hipSuccess) die("upload", WM_ERR_HIP);
+    tr.mark("stage");
+    {
+      OnDevice dev_(b->b.ctx[0]);
+      run_or_die("Synthesis", synthesis_prepare_wait(b->b));
+      tr.mark("wait");
+      if (hipStreamWaitEvent(ws_stream(), g_up_done, 0) != hipSuccess) die("upload", WM_ERR_HIP);
+      run_or_die("Synthesis", synthesis_render(b->b, ds, da, dy));
+    }
+    tr.mark("launch");
+    tr.mark("kernels", true);
+    get(dy, y, (size_t)y_length);
+    g_ws.finish();
+    tr.mark("back");
+  } catch (const DropInError& e_) {
+    drop_in_failed(e_);
   }
-  tr.mark("begin");
-  // (the device and pinned buffers are sized before anything of this call is in flight on the upload stream: growing
-  // them synchronises the context's stream only)
-  const size_t cells = (size_t)f0_length * w;
-  (void)g_ws.device(kSp, cells);
-  (void)g_ws.device(kAp, cells);
-  (void)g_ws.stage(2 * cells + 16);
-  g_ws.stage_at -= (2 * cells + 16 + 7) & ~(size_t)7;               // reserved, not taken
-  hipStream_t up = up_stream();
-  double* ds = put_rows(kSp, spectrogram, f0_length, w, up);
-  double* da = put_rows(kAp, aperiodicity, f0_length, w, up);
-  if (hipEventRecord(g_up_done, up) != hipSuccess) die("upload", WM_ERR_HIP);
-  tr.mark("stage");
-  {
-    OnDevice dev_(b->b.ctx[0]);
-    run_or_die("Synthesis", synthesis_prepare_wait(b->b));
-    tr.mark("wait");
-    if (hipStreamWaitEvent(ws_stream(), g_up_done, 0) != hipSuccess) die("upload", WM_ERR_HIP);
-    run_or_die("Synthesis", synthesis_render(b->b, ds, da, dy));
-  }
-  tr.mark("launch");
-  tr.mark("kernels", true);
-  get(dy, y, (size_t)y_length);
-  g_ws.finish();
-  tr.mark("back");
 }
 
 }  // extern "C"

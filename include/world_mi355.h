@@ -68,6 +68,15 @@ typedef struct {
  * floor 71, ceil 800, 2 ch/oct, speed 1, range 0.1, q1 -0.15, threshold 0 (NOT 0.85). */
 void WorldMi355DefaultParams(int fs, double frame_period, WorldMi355Params* p);
 
+/* The entry points of WORLD's own API (include/world/*.h) return void: a failure inside them (no HIP device, a HIP
+ * error, an unsupported size) prints a message and calls abort(), as the reference aborts on bad_alloc.  A host that
+ * would rather lose one utterance than the process installs a handler: it is called INSTEAD of abort() with the name
+ * of the step that failed, a WM_ERR_* code and WorldMi355LastError()'s text, and the entry point then returns to its
+ * caller with its outputs unspecified.  NULL restores abort().  The functions of this header return codes and never
+ * call the handler. */
+typedef void (*WorldMi355ErrorHandler)(const char* where, int code, const char* message, void* user);
+void WorldMi355SetErrorHandler(WorldMi355ErrorHandler handler, void* user);
+
 /* device < 0: current device.  stream == NULL: the legacy default stream (stream 0). */
 int WorldMi355CreateContext(int device, void* hip_stream, WorldMi355Context** out);
 void WorldMi355DestroyContext(WorldMi355Context* ctx);

@@ -104,3 +104,35 @@ def test_library_exports_only_its_abi():
     declared = declared_symbols()
     assert exported == {n for n in declared if not n.startswith("WM_")}, sorted(exported ^ declared)[:20]
     assert len([n for n in exported if not n.startswith("WorldMi355")]) == 19      # WORLD's own names
+
+
+def test_drop_in_error_handler_instead_of_abort(pkg):
+    """Without a handler a failing drop-in call aborts the process (the reference's functions return void); with
+    WorldMi355SetErrorHandler the failure is reported and the call returns.  On a box without a GPU every drop-in call
+    fails with WM_ERR_NO_DEVICE, which is what this exercises (in a child process: the abort path kills it)."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the call succeeds")
+    code = r'''
+import ctypes as C, importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("hts-train-world_amd")
+L = pkg.capi._lib()
+seen = []
+H = C.CFUNCTYPE(None, C.c_char_p, C.c_int, C.c_char_p, C.c_void_p)
+def on_error(where, code, msg, user):
+    seen.append((where.decode(), code, msg.decode()))
+cb = H(on_error)
+if sys.argv[1] == "handler":
+    L.WorldMi355SetErrorHandler(cb, None)
+x = np.zeros(1600)
+t, f0 = pkg.capi.dio(x, 16000)
+print("returned", seen)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code, "handler"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "returned [('CreateContext', 4," in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, "-c", code, "abort"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "libworld_mi355: CreateContext failed (code 4)" in r.stderr

@@ -913,6 +913,29 @@ def test_errors_are_reported_not_swallowed(gpu):
 
 
 @pytest.mark.gpu
+def test_drop_in_failure_goes_to_the_handler(gpu, pkg, oracle):
+    """WorldMi355SetErrorHandler: a drop-in call that fails (CheapTrick at an fft_size the kernels do not have) calls
+    the handler instead of abort(), returns, and the next call works as if nothing had happened."""
+    import ctypes as C
+    capi = pkg.capi
+    L = capi._lib()
+    seen = []
+    H = C.CFUNCTYPE(None, C.c_char_p, C.c_int, C.c_char_p, C.c_void_p)
+    cb = H(lambda where, code, msg, user: seen.append((where.decode(), code)))
+    L.WorldMi355SetErrorHandler(cb, None)
+    try:
+        x = sd.make_utterance(90, 16000, duration=0.4)
+        t, f0 = capi.dio(x, 16000)
+        capi.cheaptrick(x, 16000, t, f0, fft_size=256)
+        assert seen == [("CheapTrick", 3)]                              # WM_ERR_UNSUPPORTED_FFT
+        sp = capi.cheaptrick(x, 16000, t, f0)
+        sp_close(sp, oracle.cheaptrick(x, 16000, t, f0))
+        assert len(seen) == 1
+    finally:
+        L.WorldMi355SetErrorHandler(None, None)
+
+
+@pytest.mark.gpu
 def test_synthesis_in_response_chunks(gpu, monkeypatch):
     """The per-pulse responses go through a scratch buffer of bounded size; a batch whose pulses do not fit is
     rendered chunk by chunk.  Same bits whatever the chunk size."""

@@ -32,3 +32,25 @@ def test_oracle_suites_under_asan_ubsan():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert "passed" in r.stdout and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+
+
+def test_host_file_writer_under_asan_ubsan(tmp_path):
+    """The one host-only translation unit of the product (csrc/fileio.cpp: the native writer of the sweep's feature
+    files, plain threads) built by g++ with AddressSanitizer + UndefinedBehaviorSanitizer around a harness
+    (tests/hostsan/fileio_harness.cpp): many files from several threads, empty files, more threads than files, bad
+    arguments, a path that cannot be created."""
+    if not _runtime("libasan.so") or not _runtime("libubsan.so"):
+        pytest.skip("gcc sanitizer runtimes not installed")
+    exe = tmp_path / "fileio_harness"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "hostsan", "fileio_harness.cpp"),
+                           os.path.join(ROOT, "hts-train-world_amd", "csrc", "fileio.cpp"), "-o", str(exe)])
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    r = subprocess.run([str(exe), str(out_dir)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="abort_on_error=1:halt_on_error=1",
+                                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
+    assert r.returncode == 0 and "fileio ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
