@@ -43,6 +43,33 @@ def batches(order, frames, limit):
         yield cur
 
 
+def tapered_batches(order, frames, rounds, limit, ratio=0.65):
+    """`order` cut into `rounds` consecutive groups whose frame counts fall off geometrically (ratio per round), each
+    within `limit`.  A pass is a pipeline -- round k + 1 is analysed while round k travels to the host and round k - 1
+    is written -- so what no compute hides is the LAST round's transfer and file writes: the smaller that round, the
+    shorter the tail (equal rounds: a quarter of the pass's copy + write time exposed at four rounds; tapered: a
+    tenth).  Too small a round does not fill the GPU, hence the gentle ratio."""
+    total = sum(frames[i] for i in order)
+    w = [ratio ** k for k in range(rounds)]
+    cum, acc = [], 0.0
+    for x in w:
+        acc += x
+        cum.append(total * acc / sum(w))
+    groups, cur, tot, done, k = [], [], 0, 0, 0
+    for i in order:
+        if cur and (tot + frames[i] > limit or (k < rounds - 1 and done + tot >= cum[k])):
+            groups.append(cur)
+            done += tot
+            cur, tot = [], 0
+            while k < rounds - 1 and done >= cum[k]:
+                k += 1
+        cur.append(i)
+        tot += frames[i]
+    if cur:
+        groups.append(cur)
+    return groups
+
+
 class ShardedSweep:
     """One corpus, one sampling rate, `world` ranks.  Every rank builds the same plan; `load()` puts this rank's
     waveforms into HBM; `run()` is one pass: analyse, gather to rank 0, write."""
@@ -60,12 +87,14 @@ class ShardedSweep:
         self.frames = [sharding.frame_count(n, self.fs, self.fp) for n in self.samples]
         self.shards = sharding.lpt_shards(self.frames, world)
         self.writers = writers
+        # batch plan of EVERY rank (rank 0 needs the layout of what it receives): longest first inside a shard; with
+        # several rounds the rounds taper off (tapered_batches)
+        by_len = lambda s: sorted(s, key=lambda i: (-self.frames[i], i))
         if rounds > 1:
-            busiest = max(sum(self.frames[i] for i in s) for s in self.shards)
-            max_batch_frames = min(max_batch_frames, max(1, -(-busiest // rounds)))
-        # batch plan of EVERY rank (rank 0 needs the layout of what it receives): longest first inside a shard
-        self.plan = [list(batches(sorted(s, key=lambda i: (-self.frames[i], i)), self.frames, max_batch_frames))
-                     for s in self.shards]
+            ratio = float(os.environ.get("WORLD_MI355_SWEEP_TAPER", "0.65"))
+            self.plan = [tapered_batches(by_len(s), self.frames, rounds, max_batch_frames, ratio) for s in self.shards]
+        else:
+            self.plan = [list(batches(by_len(s), self.frames, max_batch_frames)) for s in self.shards]
         self.rounds = max((len(p) for p in self.plan), default=0)
         self.params = W.default_params(self.fs, self.fp)
         self.loaded = []                 # [(WorldBatch, x on device)] for this rank's batches
