@@ -56,7 +56,7 @@ struct Context {
   hipStream_t side = nullptr;
   hipStream_t prep = nullptr;        // launch_synthesis: the f0-only kernels of the batch's second part
   hipEvent_t ev_call = nullptr, ev_prep_b = nullptr;
-  hipEvent_t ev_f0 = nullptr, ev_prep = nullptr;
+  hipEvent_t ev_f0 = nullptr, ev_prep = nullptr, ev_d4c = nullptr;
   hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
   int ensure_side();                 // the second stream and its events, created on first use
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
@@ -145,6 +145,11 @@ struct Batch {
   int* d_perm2 = nullptr;            // [total_f] D4C: frames that need the wide-margin kernel first
   int* d_part_cnt = nullptr;         // [total_f / 1024 + 2]
   int* d_part_n = nullptr;           // [4] number of listed frames
+  // D4C's own offsets and lists: its preparation may run beside CheapTrick (d4c_prepare, d4c.hip)
+  int* d_rng_off_d4c = nullptr;      // [total_f]
+  int* d_perm_d4c = nullptr;         // [total_f]
+  int* d_part_cnt_d4c = nullptr;     // [total_f / 1024 + 2]
+  int* d_part_n_d4c = nullptr;       // [4]
   void* d_sm_twid = nullptr;         // StoneMask's DFT twiddle table (stonemask.hip)
   // D4C tables
   double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
@@ -214,6 +219,9 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
                      double f0_lower = 0.0);
 int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_sp);
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
+int launch_analyze(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap);
+int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_f0);
+int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
 int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);
 int synthesis_begin(Batch& b, const double* d_f0, double* d_y);      // the f0-only kernels, queued

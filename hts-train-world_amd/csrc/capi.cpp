@@ -125,6 +125,7 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
   if (c.ev_f0) hipEventDestroy(c.ev_f0);
   if (c.ev_prep) hipEventDestroy(c.ev_prep);
+  if (c.ev_d4c) hipEventDestroy(c.ev_d4c);
   for (int h = 0; h < 2; ++h) {
     if (c.ev_pulse[h]) hipEventDestroy(c.ev_pulse[h]);
     if (c.ev_ola[h]) hipEventDestroy(c.ev_ola[h]);
@@ -205,6 +206,7 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
   const size_t init_bytes = at;
   const size_t o_rng = take(4 * nf), o_rng2 = take(4 * nf), o_ap0 = take(8 * nf), o_f0t = take(8 * nf);
   const size_t o_perm = take(4 * nf), o_pcnt = take(4 * (nf / 1024 + 2)), o_pn = take(4 * 4);
+  const size_t o_rng_d = take(4 * nf), o_perm_d = take(4 * nf), o_pcnt_d = take(4 * (nf / 1024 + 2)), o_pn_d = take(4 * 4);
   std::vector<unsigned char> img(init_bytes, 0);
   memcpy(&img[o_xoff], b.x_off.data(), 8 * n1);
   memcpy(&img[o_foff], b.f_off.data(), 8 * n1);
@@ -232,6 +234,8 @@ int WorldMi355CreateBatch(WorldMi355Context* h, const WorldMi355Params* params, 
   b.d_rng_off = (int*)(base + o_rng); b.d_rng_off2 = (int*)(base + o_rng2);
   b.d_ap0 = (double*)(base + o_ap0); b.d_f0_tmp = (double*)(base + o_f0t);
   b.d_perm = (int*)(base + o_perm); b.d_part_cnt = (int*)(base + o_pcnt); b.d_part_n = (int*)(base + o_pn);
+  b.d_rng_off_d4c = (int*)(base + o_rng_d); b.d_perm_d4c = (int*)(base + o_perm_d);
+  b.d_part_cnt_d4c = (int*)(base + o_pcnt_d); b.d_part_n_d4c = (int*)(base + o_pn_d);
   *out = hb;
   return WM_OK;
 }
@@ -334,12 +338,7 @@ int WorldMi355Harvest(WorldMi355Batch* b, const double* x, double* t, double* f0
 int WorldMi355Analyze(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
                       double* ap) {
   OnDevice dev_(hb->b.ctx[0]);
-  Batch& b = hb->b;
-  int rc = launch_dio(b, x, t, b.d_f0_tmp);
-  rc = rc ? rc : launch_stonemask(b, x, t, b.d_f0_tmp, f0, b.p.f0_floor);
-  rc = rc ? rc : launch_cheaptrick(b, x, t, f0, sp);
-  rc = rc ? rc : launch_d4c(b, x, t, f0, ap);
-  return rc;
+  return launch_analyze(hb->b, x, t, f0, sp, ap);
 }
 int WorldMi355AnalyzeSynthesize(WorldMi355Batch* hb, const double* x, double* t, double* f0, double* sp,
                                 double* ap, double* y) {

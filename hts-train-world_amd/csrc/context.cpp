@@ -227,11 +227,40 @@ int Context::ensure_side() {
   int rc = wm_check(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_f0, hipEventDisableTiming));
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
+  rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_d4c, hipEventDisableTiming));
   for (int h = 0; h < 2 && !rc; ++h) {
     rc = wm_check(hipEventCreateWithFlags(&ev_pulse[h], hipEventDisableTiming));
     rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_ola[h], hipEventDisableTiming));
   }
   return rc;
+}
+
+// Dio -> StoneMask -> CheapTrick -> D4C as one call: D4C's preparation runs on the second stream beside CheapTrick
+// once the batch has its D4C tables (the first use allocates them, in the plain order).
+int launch_analyze(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap) {
+  Context& c = *b.ctx;
+  int rc = launch_dio(b, d_x, d_t, b.d_f0_tmp);
+  rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0, b.p.f0_floor);
+  if (rc) return rc;
+  if (!b.d_d4c_window) {
+    rc = launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
+    return rc ? rc : launch_d4c(b, d_x, d_t, d_f0, d_ap);
+  }
+  int64_t need = b.rng_bound_cheaptrick();                 // the randn table must not move under two streams
+  if (b.rng_bound_d4c() > need) need = b.rng_bound_d4c();
+  rc = c.ensure_side();
+  rc = rc ? rc : c.ensure_rng(need);
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_f0, c.stream));
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(c.side, c.ev_f0, 0));
+  if (rc) return rc;
+  hipStream_t main_stream = c.stream;
+  c.stream = c.side;
+  rc = d4c_prepare(b, d_x, d_t, d_f0);
+  if (!rc) rc = wm_check(hipEventRecord(c.ev_d4c, c.side));
+  c.stream = main_stream;
+  rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(main_stream, c.ev_d4c, 0));
+  return rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
 }
 
 // Analysis followed by Synthesis of the same features (BASELINE.json's metric), as one call.  Identical
@@ -262,13 +291,21 @@ int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* 
   rc = rc ? rc : launch_dio(b, d_x, d_t, b.d_f0_tmp);
   rc = rc ? rc : launch_stonemask(b, d_x, d_t, b.d_f0_tmp, d_f0, b.p.f0_floor);
   rc = rc ? rc : wm_check(hipEventRecord(c.ev_f0, c.stream));
-  rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
-  rc = rc ? rc : launch_d4c(b, d_x, d_t, d_f0, d_ap);
   if (rc) return rc;
   hipStream_t main_stream = c.stream;
+  // second stream, from f0 on: D4C's preparation (offsets, LoveTrain, frame lists), then Synthesis's
   rc = wm_check(hipStreamWaitEvent(c.side, c.ev_f0, 0));
   if (!rc) {
     c.stream = c.side;                       // the launchers take the context's stream
+    rc = d4c_prepare(b, d_x, d_t, d_f0);
+    if (!rc) rc = wm_check(hipEventRecord(c.ev_d4c, c.side));
+    c.stream = main_stream;
+  }
+  rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(main_stream, c.ev_d4c, 0));
+  rc = rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
+  if (!rc) {
+    c.stream = c.side;
     rc = synthesis_prepare(b, d_f0, d_y);
     if (!rc) rc = wm_check(hipEventRecord(c.ev_prep, c.side));
     c.stream = main_stream;

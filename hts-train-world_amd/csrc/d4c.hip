@@ -318,11 +318,14 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
   cpx* img = reinterpret_cast<cpx*>(smem);    // FFT image (aliases it)
 
   const int lane0 = threadIdx.x;
+  const int n_run = *n_listed;
+  // the usual case of the RARE launch is an empty list: leave before the twiddle tables are built (the launch took
+  // 64 us of every pass of configs[1] doing that and nothing else)
+  if (RARE && n_run == 0) return;
   FftTw<N> tw;
   tw.init(lane0);
   const int out_bins = out_fft_arg / 2 + 1;
 
-  const int n_run = *n_listed;
   if (!RARE) {
     WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
       double* row = ap + frame * (int64_t)out_bins;
@@ -597,15 +600,15 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   double* COARSE = GD + (size_t)chunk * G::kRow;
   double* WS = COARSE + (size_t)tf * 8;
   const int fs = b.p.fs;
-  const int* perm = (const int*)b.d_perm;
-  const int* nl = (const int*)b.d_part_n;
+  const int* perm = (const int*)b.d_perm_d4c;
+  const int* nl = (const int*)b.d_part_n_d4c;
   for (int64_t begin = 0; begin < tf; begin += chunk) {
     const int64_t left = tf - begin < chunk ? tf - begin : chunk;
     const int capc = (int)(left < (int64_t)c.frame_grid ? left : (int64_t)c.frame_grid);
     hipLaunchKernelGGL(d4cb_centroid_kernel<FD>, dim3(imin(capc, g1)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (int)begin, (int)chunk, WS, C);
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off_d4c, c.d_rng, fs, perm, nl, (int)begin, (int)chunk, WS, C);
     hipLaunchKernelGGL(d4cb_spectrum_kernel<FD>, dim3(imin(capc, g2)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                       b.d_frame_utt, d_t, d_f0, b.d_rng_off, c.d_rng, fs, perm, nl, (int)begin, (int)chunk,
+                       b.d_frame_utt, d_t, d_f0, b.d_rng_off_d4c, c.d_rng, fs, perm, nl, (int)begin, (int)chunk,
                        (const double*)C, GD);
     const int64_t tasks = left * tab.nap;
     const int cap3 = (int)(tasks < (int64_t)c.frame_grid * 4 ? tasks : (int64_t)c.frame_grid * 4);
@@ -622,13 +625,30 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   if constexpr (FD <= 4096) {
     const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
     hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab,
-                       b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);
+                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab,
+                       b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);
   }
   return wm_check(hipGetLastError());
 }
 
-int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+// D4C in two steps.  d4c_prepare(): everything that needs f0 (and the waveform, for the LoveTrain ratio) but no
+// result of CheapTrick -- the randn offsets, the LoveTrain stage and the three frame lists -- on the context's stream.
+// d4c_run(): the transforms.  launch_analyze_synthesize() puts the first on its second stream beside CheapTrick (ten
+// short dependent launches, 0.1 ms of an otherwise idle machine between CheapTrick and the D4C kernel); the lists and
+// offsets are D4C's own arrays (`*_d4c`), so nothing of CheapTrick's is touched.
+static int d4c_tables(Batch& b, D4CTables& tab) {
+  const int fs = b.p.fs;
+  const int FD = d4c_fft_size(fs);
+  tab.nuttall = b.d_d4c_window;
+  tab.window_length = (int)(kFreqInterval * FD / fs) * 2 + 1;
+  double lim = fs / 2.0 - kFreqInterval;
+  tab.nap = (int)((kUpperLimit < lim ? kUpperLimit : lim) / kFreqInterval);
+  // no band at all below 12 kHz (fs / 2 - 3000 < 3000): the reference then interpolates between its two end knots only
+  if (tab.nap < 0 || tab.nap > 6) return WM_ERR_UNSUPPORTED;
+  return WM_OK;
+}
+
+int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_f0) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
   const int fs = b.p.fs;
@@ -659,24 +679,20 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
     b.d_d4c_window = dw;
   }
   D4CTables tab;
-  tab.nuttall = b.d_d4c_window;
-  tab.window_length = wl;
-  double lim = fs / 2.0 - kFreqInterval;
-  tab.nap = (int)((kUpperLimit < lim ? kUpperLimit : lim) / kFreqInterval);
-  // no band at all below 12 kHz (fs / 2 - 3000 < 3000): the reference then interpolates between its two end knots only
-  if (tab.nap < 0 || tab.nap > 6) return WM_ERR_UNSUPPORTED;
+  rc = d4c_tables(b, tab);
+  if (rc) return rc;
 
   const int64_t tf = b.total_f;
   const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   hipLaunchKernelGGL(d4c_offsets_kernel<0>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)nullptr,
                      b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off2);
-  launch_partition(st, VoicedPred{d_f0}, (int)tf, b.d_part_cnt, b.d_perm, b.d_part_n);
+  launch_partition(st, VoicedPred{d_f0}, (int)tf, b.d_part_cnt_d4c, b.d_perm_d4c, b.d_part_n_d4c);
 #define WM_LT_CASE(FF)                                                                                     \
   case FF: {                                                                                               \
     const int per_ = persistent_grid(c, d4c_lovetrain_kernel<FF>, 64, (int64_t)1 << 40);            \
     hipLaunchKernelGGL(d4c_lovetrain_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,  \
                        b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf,                \
-                       (const int*)b.d_perm, (const int*)b.d_part_n, b.d_ap0);                             \
+                       (const int*)b.d_perm_d4c, (const int*)b.d_part_n_d4c, b.d_ap0);                             \
   } break;
   {
     TimedScope ts_(b.ctx, "d4c_lovetrain_kernel");
@@ -692,33 +708,46 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
         case 8192: {
           const int per_ = persistent_grid(c, d4cb_lovetrain_kernel<8192>, 64, (int64_t)1 << 40);
           hipLaunchKernelGGL(d4cb_lovetrain_kernel<8192>, dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                             b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, (const int*)b.d_perm,
-                             (const int*)b.d_part_n, b.d_ap0);
+                             b.d_frame_utt, d_t, d_f0, b.d_rng_off2, c.d_rng, fs, tf, (const int*)b.d_perm_d4c,
+                             (const int*)b.d_part_n_d4c, b.d_ap0);
         } break;
       }
     }
   }
 #undef WM_LT_CASE
   hipLaunchKernelGGL(d4c_offsets_kernel<1>, dim3(b.n_utt), dim3(256), 0, st, d_f0, (const double*)b.d_ap0,
-                     b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off);
-  launch_partition(st, D4cRunUsualPred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt, b.d_perm,
-                   b.d_part_n);
+                     b.d_f_off, fs, b.p.d4c_threshold, b.d_utt_total, b.d_rng_off_d4c);
+  launch_partition(st, D4cRunUsualPred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt_d4c, b.d_perm_d4c,
+                   b.d_part_n_d4c);
   // the rare frames (f0 >= fs / 16, or a window longer than FD / 2 samples) are listed separately for the
   // wide-margin, long-frame instantiation; an empty list costs that launch a few microseconds
-  launch_partition(st, D4cRunRarePred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt, b.d_perm2,
-                   b.d_part_n + 1);
+  launch_partition(st, D4cRunRarePred{d_f0, b.d_ap0, b.p.d4c_threshold, FD, fs}, (int)tf, b.d_part_cnt_d4c, b.d_perm2,
+                   b.d_part_n_d4c + 1);
+  return wm_check(hipGetLastError());
+}
+
+int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int fs = b.p.fs;
+  const int FD = d4c_fft_size(fs);
+  D4CTables tab;
+  int rc = d4c_tables(b, tab);
+  if (rc) return rc;
+  const int64_t tf = b.total_f;
+  const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
 #define WM_D4C_CASE(FF, WV)                                                                               \
   case FF: {                                                                                              \
     const int per_ = persistent_grid(c, d4c_kernel<FF, WV, false>, 64, (int64_t)1 << 40);          \
     hipLaunchKernelGGL((d4c_kernel<FF, WV, false>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x,         \
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
-                       b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
-                       (const int*)b.d_perm, (const int*)b.d_part_n, d_ap);                               \
+                       b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
+                       (const int*)b.d_perm_d4c, (const int*)b.d_part_n_d4c, d_ap);                               \
     const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
     hipLaunchKernelGGL((d4c_kernel<FF, 1, true>), dim3(imin(grid, per2_)), dim3(64), 0, st, d_x,          \
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
-                       b.d_rng_off, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
-                       (const int*)b.d_perm2, (const int*)(b.d_part_n + 1), d_ap);                        \
+                       b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
+                       (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);                        \
   } break;
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
@@ -737,6 +766,11 @@ int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f
   }
 #undef WM_D4C_CASE
   return wm_check(hipGetLastError());
+}
+
+int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  int rc = d4c_prepare(b, d_x, d_t, d_f0);
+  return rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
 }
 
 #ifdef WM_PHASE

@@ -222,9 +222,8 @@ __device__ __forceinline__ void zc_scan_tiles(int* __restrict__ tile_cnt, int nt
 }
 
 // Move a signal's staged events to their places in the ordered lists, by one workgroup: its scanned offsets (4 * (ntiles + 1) ints, layout [tile][kind]) go to
-// LDS once (`lds_off`, kZcCompactTiles + 1 tiles at most; longer signals search the offsets in memory), then every
-// thread takes places of the ordered lists, finds the tile a place belongs to by bisection of the offsets and
-// fetches the event from that tile's slot.  One workgroup per (tile, signal) -- a handful of events each, 1.6 M
+// LDS once (`lds_off`, kZcCompactTiles + 1 tiles at most; longer signals read the offsets from memory), then every
+// wavefront takes tiles and copies each tile's run of events to its place in the ordered list.  One workgroup per (tile, signal) -- a handful of events each, 1.6 M
 // workgroups on configs[2] -- cost more in dispatch than the copies themselves.
 constexpr int kZcCompactTiles = 1023;
 __device__ __forceinline__ void zc_compact_signal(const double* __restrict__ slot, int64_t slot_cap, int ntiles,
@@ -235,18 +234,19 @@ __device__ __forceinline__ void zc_compact_signal(const double* __restrict__ slo
     for (int i = threadIdx.x; i < 4 * (ntiles + 1); i += blockDim.x) lds_off[i] = off[i];
   __syncthreads();
   const int* o4 = staged ? lds_off : off;
+  // A wavefront per tile and kind: the tile's events are consecutive in its slot and consecutive in the list, so a
+  // tile is two offset reads and a run of coalesced copies.  (Round 3 gave a thread a PLACE of the list and found its
+  // tile by bisection of the offsets: ten dependent LDS reads per event, 80 % of the kernel's cycles waiting.)
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
 #pragma unroll 1
   for (int ty = 0; ty < 4; ++ty) {
-    const int total = imin(o4[4 * ntiles + ty], cap);
     const double* src = slot + (int64_t)ty * slot_cap;
     double* dst = ev + (int64_t)ty * cap;
-    for (int o = threadIdx.x; o < total; o += blockDim.x) {
-      int lo = 0, hi = ntiles;                                    // last tile whose offset is <= o
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (o4[4 * mid + ty] <= o) lo = mid; else hi = mid;
-      }
-      dst[o] = src[(int64_t)lo * kZcSlot + (o - o4[4 * lo + ty])];
+    for (int tile = wv; tile < ntiles; tile += nw) {
+      const int b = o4[4 * tile + ty];
+      const int e = imin(o4[4 * (tile + 1) + ty], cap);
+      const double* st = src + (int64_t)tile * kZcSlot;
+      for (int j = b + lane; j < e; j += 64) dst[j] = st[j - b];
     }
   }
 }
