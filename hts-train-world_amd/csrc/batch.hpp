@@ -54,9 +54,10 @@ struct Context {
   int64_t* d_pulse_info = nullptr;   // the same memory as the device sees it
   // second stream + events of launch_analyze_synthesize (created on first use)
   hipStream_t side = nullptr;
+  hipStream_t aux = nullptr;         // D4C's RARE launch (d4c_rare)
   hipStream_t prep = nullptr;        // launch_synthesis: the f0-only kernels of the batch's second part
   hipEvent_t ev_call = nullptr, ev_prep_b = nullptr;
-  hipEvent_t ev_f0 = nullptr, ev_prep = nullptr, ev_d4c = nullptr;
+  hipEvent_t ev_f0 = nullptr, ev_prep = nullptr, ev_d4c = nullptr, ev_rare = nullptr;
   hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
   int ensure_side();                 // the second stream and its events, created on first use
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
@@ -221,6 +222,7 @@ int launch_cheaptrick(Batch& b, const double* d_x, const double* d_t, const doub
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_analyze(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap);
 int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_f0);
+int d4c_rare(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
 int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);

@@ -126,6 +126,8 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.ev_f0) hipEventDestroy(c.ev_f0);
   if (c.ev_prep) hipEventDestroy(c.ev_prep);
   if (c.ev_d4c) hipEventDestroy(c.ev_d4c);
+  if (c.ev_rare) hipEventDestroy(c.ev_rare);
+  if (c.aux) { hipStreamSynchronize(c.aux); hipStreamDestroy(c.aux); }
   for (int h = 0; h < 2; ++h) {
     if (c.ev_pulse[h]) hipEventDestroy(c.ev_pulse[h]);
     if (c.ev_ola[h]) hipEventDestroy(c.ev_ola[h]);

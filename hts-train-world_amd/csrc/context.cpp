@@ -228,11 +228,37 @@ int Context::ensure_side() {
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_f0, hipEventDisableTiming));
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming));
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_d4c, hipEventDisableTiming));
+  rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_rare, hipEventDisableTiming));
+  rc = rc ? rc : wm_check(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
   for (int h = 0; h < 2 && !rc; ++h) {
     rc = wm_check(hipEventCreateWithFlags(&ev_pulse[h], hipEventDisableTiming));
     rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_ola[h], hipEventDisableTiming));
   }
   return rc;
+}
+
+// D4C around CheapTrick in the one-call forms, after ev_f0 has been recorded on the caller's stream and the second
+// stream waits for it: the preparation on the second stream, the RARE launch on the third (its waves wait for whole
+// SIMDs, i.e. for CheapTrick to drain, and would hold up whatever came behind them on a shared stream); d4c_after()
+// queues the usual kernel behind the preparation and makes the caller's stream wait for the RARE launch.
+static int d4c_beside(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  Context& c = *b.ctx;
+  hipStream_t main_stream = c.stream;
+  c.stream = c.side;
+  int rc = d4c_prepare(b, d_x, d_t, d_f0);
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_d4c, c.side));
+  rc = rc ? rc : wm_check(hipStreamWaitEvent(c.aux, c.ev_d4c, 0));
+  c.stream = c.aux;
+  rc = rc ? rc : d4c_rare(b, d_x, d_t, d_f0, d_ap);
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_rare, c.aux));
+  c.stream = main_stream;
+  return rc;
+}
+static int d4c_after(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  Context& c = *b.ctx;
+  int rc = wm_check(hipStreamWaitEvent(c.stream, c.ev_d4c, 0));
+  rc = rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
+  return rc ? rc : wm_check(hipStreamWaitEvent(c.stream, c.ev_rare, 0));
 }
 
 // Dio -> StoneMask -> CheapTrick -> D4C as one call: D4C's preparation runs on the second stream beside CheapTrick
@@ -253,14 +279,9 @@ int launch_analyze(Batch& b, const double* d_x, double* d_t, double* d_f0, doubl
   rc = rc ? rc : wm_check(hipEventRecord(c.ev_f0, c.stream));
   rc = rc ? rc : wm_check(hipStreamWaitEvent(c.side, c.ev_f0, 0));
   if (rc) return rc;
-  hipStream_t main_stream = c.stream;
-  c.stream = c.side;
-  rc = d4c_prepare(b, d_x, d_t, d_f0);
-  if (!rc) rc = wm_check(hipEventRecord(c.ev_d4c, c.side));
-  c.stream = main_stream;
+  rc = d4c_beside(b, d_x, d_t, d_f0, d_ap);
   rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
-  rc = rc ? rc : wm_check(hipStreamWaitEvent(main_stream, c.ev_d4c, 0));
-  return rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
+  return rc ? rc : d4c_after(b, d_x, d_t, d_f0, d_ap);
 }
 
 // Analysis followed by Synthesis of the same features (BASELINE.json's metric), as one call.  Identical
@@ -295,15 +316,9 @@ int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* 
   hipStream_t main_stream = c.stream;
   // second stream, from f0 on: D4C's preparation (offsets, LoveTrain, frame lists), then Synthesis's
   rc = wm_check(hipStreamWaitEvent(c.side, c.ev_f0, 0));
-  if (!rc) {
-    c.stream = c.side;                       // the launchers take the context's stream
-    rc = d4c_prepare(b, d_x, d_t, d_f0);
-    if (!rc) rc = wm_check(hipEventRecord(c.ev_d4c, c.side));
-    c.stream = main_stream;
-  }
+  rc = rc ? rc : d4c_beside(b, d_x, d_t, d_f0, d_ap);
   rc = rc ? rc : launch_cheaptrick(b, d_x, d_t, d_f0, d_sp);
-  rc = rc ? rc : wm_check(hipStreamWaitEvent(main_stream, c.ev_d4c, 0));
-  rc = rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
+  rc = rc ? rc : d4c_after(b, d_x, d_t, d_f0, d_ap);
   if (!rc) {
     c.stream = c.side;
     rc = synthesis_prepare(b, d_f0, d_y);

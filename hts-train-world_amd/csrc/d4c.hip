@@ -295,6 +295,39 @@ __device__ __forceinline__ void d4c_write_row(Knot kv, int nap, int fs, int out_
   }
 }
 
+// The frames the two instantiations of d4c_kernel work on (both: d4c.cpp:380).  The usual one takes the frames
+// whose smoothing mirror fits FD / 16 bins (f0 < fs / 16) AND whose 4-period window fits FD / 2 samples (f0 above
+// ~4 fs / FD): every frame behind Dio / Harvest + StoneMask at their default 71-800 Hz range from 12.8 kHz up.
+// The RARE one takes the rest of what the reference defines.
+__host__ __device__ inline bool d4c_is_usual(double cf0, int fd, int fs) {
+  // fd 4096 (d4c_big.hpp) takes any window length; the one-kernel form only windows of at most fd / 2 samples
+  return d4c_mirror_bins(cf0, fd, fs) <= fd / 16 && (fd >= 4096 || 2 * matlab_round(2.0 * fs / cf0) + 1 <= fd / 2);
+}
+struct D4cRunUsualPred {
+  const double* f0;
+  const double* ap0;
+  double threshold;
+  int fd, fs;
+  __device__ bool operator()(int i) const {
+    const double v = f0[i];
+    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
+    return d4c_is_usual(v > kFloorF0D4C ? v : kFloorF0D4C, fd, fs);
+  }
+};
+struct D4cRunRarePred {
+  const double* f0;
+  const double* ap0;
+  double threshold;
+  int fd, fs;
+  __device__ bool operator()(int i) const {
+    const double v = f0[i];
+    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
+    const double cf0 = v > kFloorF0D4C ? v : kFloorF0D4C;
+    // beyond fd / 2 mirror bins the reference reads past its spectrum (common.cpp:62-68, :85-92): default row stays
+    return !d4c_is_usual(cf0, fd, fs) && d4c_mirror_bins(cf0, fd, fs) <= fd / 2;
+  }
+};
+
 // FD = fft_size_d4c.  Rows of `ap` have out_bins = fft_size/2+1 entries (CheapTrick's size).
 // One wavefront per frame (fft.hpp): registers + one LDS region that is FFT image, spectrum with margins and
 // selection scratch in turn.  RARE = false: the frames d4c_is_usual() accepts (short window, narrow mirror), at
@@ -327,7 +360,9 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
   const int out_bins = out_fft_arg / 2 + 1;
 
   if (!RARE) {
+    const D4cRunRarePred rare{f0, ap0, threshold, FD, fs_arg};
     WM_FOR_EACH_LISTED(frame, perm + n_run, total_frames - n_run) {   // d4c.cpp:318-323, :380
+      if (rare((int)frame)) continue;                                  // the RARE launch owns that row (it may run first)
       double* row = ap + frame * (int64_t)out_bins;
       for (int i = lane0; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
     }
@@ -533,44 +568,15 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
   WM_PHASE_FLUSH(0)
 }
 
-// The frames the two instantiations of d4c_kernel work on (both: d4c.cpp:380).  The usual one takes the frames
-// whose smoothing mirror fits FD / 16 bins (f0 < fs / 16) AND whose 4-period window fits FD / 2 samples (f0 above
-// ~4 fs / FD): every frame behind Dio / Harvest + StoneMask at their default 71-800 Hz range from 12.8 kHz up.
-// The RARE one takes the rest of what the reference defines.
-__host__ __device__ inline bool d4c_is_usual(double cf0, int fd, int fs) {
-  // fd 4096 (d4c_big.hpp) takes any window length; the one-kernel form only windows of at most fd / 2 samples
-  return d4c_mirror_bins(cf0, fd, fs) <= fd / 16 && (fd >= 4096 || 2 * matlab_round(2.0 * fs / cf0) + 1 <= fd / 2);
-}
-struct D4cRunUsualPred {
-  const double* f0;
-  const double* ap0;
-  double threshold;
-  int fd, fs;
-  __device__ bool operator()(int i) const {
-    const double v = f0[i];
-    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
-    return d4c_is_usual(v > kFloorF0D4C ? v : kFloorF0D4C, fd, fs);
-  }
-};
-struct D4cRunRarePred {
-  const double* f0;
-  const double* ap0;
-  double threshold;
-  int fd, fs;
-  __device__ bool operator()(int i) const {
-    const double v = f0[i];
-    if (v == 0.0 || ap0[i] <= threshold) return false;       // d4c.cpp:380 as written: a NaN ratio does not skip
-    const double cf0 = v > kFloorF0D4C ? v : kFloorF0D4C;
-    // beyond fd / 2 mirror bins the reference reads past its spectrum (common.cpp:62-68, :85-92): default row stays
-    return !d4c_is_usual(cf0, fd, fs) && d4c_mirror_bins(cf0, fd, fs) <= fd / 2;
-  }
-};
-
 }  // namespace wm
 #include "d4c_big.hpp"
 namespace wm {
 
 // fft_size_d4c = 4096 / 8192: the four-kernel form of d4c_big.hpp for the usual frames
+// Grid of the RARE launch: one round of resident workgroups, not `oversub` rounds -- its list is empty at the default
+// f0 range, and 6 144 workgroups of 33 KB LDS took 64 us to come and go (1 024: 12 us).
+static inline int rare_grid(const Context& c, int persistent) { return imax(1, persistent / imax(1, c.oversub)); }
+
 template <int FD>
 static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const double* d_f0, D4CTables tab,
                           double* d_ap) {
@@ -618,22 +624,15 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   const int cap = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
   const int64_t blocks = (tf + 3) / 4;
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
-                     b.p.fft_size, tf, perm, nl, (const double*)COARSE, d_ap);
-  // the rare frames afterwards, over the default rows the output kernel has written for them.  At 8192 there is no
-  // one-kernel form (its transform would be 4096 complex points on one wavefront): frames with f0 >= fs / 16 (6 kHz at
-  // 96 kHz) keep the default row there.
-  if constexpr (FD <= 4096) {
-    const int g4 = persistent_grid(c, d4c_kernel<FD, 1, true>, 64, (int64_t)1 << 40);
-    hipLaunchKernelGGL((d4c_kernel<FD, 1, true>), dim3(imin(cap, g4)), dim3(64), 0, st, d_x, b.d_x_off, b.d_x_len,
-                       b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab,
-                       b.p.fft_size, tf, (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);
-  }
+                     b.p.fft_size, tf, perm, nl,
+                     D4cRunRarePred{d_f0, (const double*)b.d_ap0, b.p.d4c_threshold, FD <= 4096 ? FD : 0, fs},
+                     (const double*)COARSE, d_ap);
   return wm_check(hipGetLastError());
 }
 
-// D4C in two steps.  d4c_prepare(): everything that needs f0 (and the waveform, for the LoveTrain ratio) but no
+// D4C in three steps.  d4c_prepare(): everything that needs f0 (and the waveform, for the LoveTrain ratio) but no
 // result of CheapTrick -- the randn offsets, the LoveTrain stage and the three frame lists -- on the context's stream.
-// d4c_run(): the transforms.  launch_analyze_synthesize() puts the first on its second stream beside CheapTrick (ten
+// d4c_rare(): the RARE instantiation over its list (normally empty).  d4c_run(): the transforms of the usual frames.  launch_analyze_synthesize() puts the first on its second stream beside CheapTrick (ten
 // short dependent launches, 0.1 ms of an otherwise idle machine between CheapTrick and the D4C kernel); the lists and
 // offsets are D4C's own arrays (`*_d4c`), so nothing of CheapTrick's is touched.
 static int d4c_tables(Batch& b, D4CTables& tab) {
@@ -726,6 +725,39 @@ int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_
   return wm_check(hipGetLastError());
 }
 
+int d4c_rare(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int fs = b.p.fs;
+  const int FD = d4c_fft_size(fs);
+  D4CTables tab;
+  int rc = d4c_tables(b, tab);
+  if (rc) return rc;
+  const int64_t tf = b.total_f;
+  const int grid = (int)(tf < (int64_t)c.frame_grid ? tf : (int64_t)c.frame_grid);
+  // The RARE launch on its own: its rows are its own (the other kernels leave them alone), so it needs nothing of
+  // d4c_run() but the lists -- and behind the usual kernel it cost 62 us of every pass with its list empty (the default
+  // f0 range), for a kernel whose every wave leaves at its fourth instruction.  Its waves need a SIMD to themselves:
+  // beside another kernel the launch sits until that one drains, so the one-call forms give it a stream of its own.  At 8192 there is no one-kernel form (its
+  // transform would be 4096 complex points on one wavefront): frames with f0 >= fs / 16 (6 kHz at 96 kHz) keep the
+  // default row there.
+#define WM_D4C_RARE(FF)                                                                                   \
+  case FF: {                                                                                              \
+    const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
+    hipLaunchKernelGGL((d4c_kernel<FF, 1, true>), dim3(imin(grid, rare_grid(c, per2_))), dim3(64), 0, st, d_x, \
+                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
+                       b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,            \
+                       (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);                    \
+  } break;
+  switch (FD) {
+    WM_D4C_RARE(1024)
+    WM_D4C_RARE(2048)
+    WM_D4C_RARE(4096)
+  }
+#undef WM_D4C_RARE
+  return wm_check(hipGetLastError());
+}
+
 int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
@@ -743,11 +775,6 @@ int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, 
                        b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
                        b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
                        (const int*)b.d_perm_d4c, (const int*)b.d_part_n_d4c, d_ap);                               \
-    const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
-    hipLaunchKernelGGL((d4c_kernel<FF, 1, true>), dim3(imin(grid, per2_)), dim3(64), 0, st, d_x,          \
-                       b.d_x_off, b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0,            \
-                       b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
-                       (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);                        \
   } break;
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
@@ -770,6 +797,7 @@ int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, 
 
 int launch_d4c(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap) {
   int rc = d4c_prepare(b, d_x, d_t, d_f0);
+  rc = rc ? rc : d4c_rare(b, d_x, d_t, d_f0, d_ap);
   return rc ? rc : d4c_run(b, d_x, d_t, d_f0, d_ap);
 }
 

@@ -24,7 +24,8 @@
 //   d4cb_band_kernel       GetCoarseAperiodicity (:192-223), one wavefront per (frame, band): the same even / odd
 //                          real transform of the windowed slice, the power spectrum's 2049 values sorted per lane,
 //                          the largest peeled (peel_largest, peel.hpp).  Output: COARSE[frame][band].
-//   d4cb_output_kernel     GetAperiodicity (:325-333) for the listed frames, the default row for all others.
+//   d4cb_output_kernel     GetAperiodicity (:325-333) for the listed frames, the default row for all others but the
+//                          RARE launch's.
 //
 // What these kernels were bound by, in the order it was found (MI355X, 256 utterances at 48 kHz, 272 794 frames;
 // rocprofv3 SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY per wave): memory round trips, not arithmetic.  A load that sits in a
@@ -608,9 +609,11 @@ __global__ __launch_bounds__(64, FL > 4096 ? 1 : 2) void d4cb_lovetrain_kernel(
 
 // ap rows: interpolation of the coarse values (GetAperiodicity, d4c.cpp:325-333) for the listed frames, the
 // default 1 - 1e-12 for all others (:318-323).  One wavefront per frame, four per workgroup.
+// `rare`: the frames of the RARE launch (d4c_kernel<FD, 1, true>, which may run before this kernel) keep what it
+// wrote; rare.fd == 0 when there is no such launch (fft 8192: those frames get the default row).
 __global__ __launch_bounds__(256) void d4cb_output_kernel(int fs, D4CTables tab, int out_fft, int64_t total_frames,
                                                           const int* __restrict__ perm,
-                                                          const int* __restrict__ n_listed,
+                                                          const int* __restrict__ n_listed, D4cRunRarePred rare,
                                                           const double* __restrict__ COARSE, double* __restrict__ ap) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (int64_t)gridDim.x * 4;
@@ -620,6 +623,7 @@ __global__ __launch_bounds__(256) void d4cb_output_kernel(int fs, D4CTables tab,
     const int frame = perm[k];
     double* row = ap + frame * (int64_t)out_bins;
     if (k >= n_run) {
+      if (rare.fd != 0 && rare(frame)) continue;
       for (int i = lane; i < out_bins; i += 64) row[i] = 1.0 - kSafe;
       continue;
     }

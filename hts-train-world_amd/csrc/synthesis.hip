@@ -1080,6 +1080,15 @@ static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more
   hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (part.max_np + 255) / 256), part.n), dim3(256), 0, st,
                      part.d_list, b.d_f_off, b.d_y_off, b.d_pulse_off, (const int*)b.d_pulse_cnt, b.d_pulse_idx,
                      b.d_pulse_shift, b.d_vuv, (PulseRec*)b.d_pulse_rec, b.d_pulse_first);
+  // The voiced-first order of every piece of the list, here rather than in front of each pulse kernel: two short
+  // dependent launches per piece that sat between D4C and the first pulse kernel and between the pieces.  A piece's
+  // order lives at its own place of the array (perm + p0); the block counts are scratch of one launch pair.
+  const int64_t piece = b.syn_chunk, p_end = part.p_base + part.total_p;
+  for (int64_t p0 = part.p_base; p0 < p_end; p0 += piece) {
+    const int64_t np = p_end - p0 < piece ? p_end - p0 : piece;
+    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
+                     b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm + p0, b.d_pulse_perm + b.pulse_rec_cap);
+  }
   return wm_check(hipGetLastError());
 }
 
@@ -1107,14 +1116,12 @@ static int synthesis_render_part(Batch& b, const SynPart& part, const double* d_
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
     if (piece >= 2) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[h], 0));
     if (rc) break;
-    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
-                     b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm, b.d_pulse_perm + b.pulse_rec_cap);
 #define WM_SY_CASE(FF)                                                                                          \
   case FF: {                                                                                                    \
     const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
     hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
                        (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
-                       (const int*)b.d_pulse_perm, resp);                                                       \
+                       (const int*)b.d_pulse_perm + p0, resp);                                                  \
   } break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
