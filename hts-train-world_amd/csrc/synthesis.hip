@@ -484,8 +484,9 @@ __global__ __launch_bounds__(256) void synth_first_kernel(const int* __restrict_
 }
 
 // The response of one pulse (GetOneFrameSegment, synthesis.cpp:183-221) by one wavefront: 7 (voiced) or 4 (unvoiced)
-// real transforms of F points in LDS / registers.  emit(j, a, b) receives response[j], response[j + 1] (fftshifted
-// positions, j even, every pair once; lane l delivers the pairs 2 (l + 64 m)); `out` is a row of F doubles of the
+// real transforms of F points in LDS / registers.  emit(m, j, a, b) receives response[j], response[j + 1] (fftshifted
+// positions, j even, every pair once; m < F / 128 is the compile-time number of the pair within the lane, which
+// delivers the pairs 2 (lane + 64 m)); `out` is a row of F doubles of the
 // wavefront's own where intermediate results wait (LEAN).
 template <int F> struct PulseCfg {
   static constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
@@ -507,7 +508,11 @@ template <int F, class Emit>
 __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, const double* __restrict__ ap,
                                                const PulseRec& r, const double* __restrict__ dcr,
                                                const uint32_t* __restrict__ rtab, int fs, double fp,
-                                               const FftTw<F / 2>& tw, double* smem, double* out, int lane0, Emit emit) {
+                                               const FftTw<F / 2>& tw, double* smem, double* out, int lane0, Emit emit
+#ifdef WM_PHASE
+                                               , PhaseClock& phase_clock_
+#endif
+                                               ) {
   constexpr int N = PulseCfg<F>::N, M = PulseCfg<F>::M, H = PulseCfg<F>::H, MB = PulseCfg<F>::MB;
   constexpr bool LEAN = PulseCfg<F>::LEAN, PAIRED = PulseCfg<F>::PAIRED;
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -589,7 +594,9 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
       wave_sync();
       {
         double php[M], pha[M];
+        WM_PHASE_MARK(1)
         minimum_phase_pair<N>(ls, ls2, img, tw, lane, php, pha);
+        WM_PHASE_MARK(2)
         // the aperiodic part's phases wait in the first half of the response row (free until the response is
         // written; every lane re-reads its own), the periodic part's in the slots of the spectrum they become
 #pragma unroll
@@ -623,6 +630,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
       wave_sync();
       minimum_phase<N>(ls, img, tw, lane, mp);
     }
+    WM_PHASE_MARK(3)
     const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
     // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
     // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
@@ -651,6 +659,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
       __builtin_amdgcn_sched_barrier(0);
     }
     cpx v[M];
+    WM_PHASE_MARK(4)
     rfft_backward<N>(img, v, img, tw, lane);
     // fftshift + RemoveDCComponent (:73-82, :135-137): dc = sum of the shifted second half = x[0..H)
 #pragma unroll
@@ -671,6 +680,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
 
   // ---- GetAperiodicResponse (:38-68) ----
   wave_sync();
+  WM_PHASE_MARK(5)
   cpx mp[MB];
   if (PAIRED && periodic) {
     // phases from the pair above (parked in the response row); amplitude sqrt(env * rat) (cvuv > 0.5 on a periodic pulse)
@@ -716,6 +726,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
     minimum_phase<N>(ls, img, tw, lane, mp);
   }
   // GetNoiseSpectrum (:19-33)
+  WM_PHASE_MARK(6)
   cpx v[M];
   {
     // LEAN: the draws are fetched here (their addresses hang on a fenced lane), not ahead of the transforms above
@@ -739,6 +750,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
     }
   }
   rfft_forward<N>(v, img, img, tw, lane);
+  WM_PHASE_MARK(7)
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
     const int k = m < M ? lane + 64 * m : H;
@@ -748,6 +760,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
   }
   rfft_backward<N>(img, v, img, tw, lane);
 
+  WM_PHASE_MARK(8)
   // ---- response = (periodic * sqrt(noise_size) + aperiodic) / fft_size (:211-215), fftshifted ----
   const double sq = sqrt((double)noise_size);
   cpx xq[LEAN ? M / 2 : 1];
@@ -770,17 +783,18 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
       const double p1 = periodic ? x1 - dc * dr.y : 0.0;
       r0 = (p0 * sq + v[m].x) / F;
       r1 = (p1 * sq + v[m].y) / F;
-      emit(i0 + H, r0, r1);
+      emit(m, i0 + H, r0, r1);
     } else {                                        // i >= H ->  j = i - H (first half, periodic overwritten)
       const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 - H);
       const double p0 = periodic ? -dc * dr.x : 0.0;
       const double p1 = periodic ? -dc * dr.y : 0.0;
       r0 = (p0 * sq + v[m].x) / F;
       r1 = (p1 * sq + v[m].y) / F;
-      emit(i0 - H, r0, r1);
+      emit(m, i0 - H, r0, r1);
     }
   }
   wave_sync();
+  WM_PHASE_MARK(9)
 }
 
 // ---- rendering by runs ----
@@ -823,11 +837,13 @@ __global__ __launch_bounds__(64, PulseCfg<F>::kWaves) void synth_run_kernel(
   FftTw<N> tw;
   tw.init(lane0);
   double* out = park + (int64_t)blockIdx.x * F;                     // this wavefront's row for intermediates
+  WM_PHASE_DECL
   for (;;) {
     int k = 0;
     if (lane0 == 0) k = atomicAdd(next, 1);
     k = __builtin_amdgcn_readfirstlane(k) + k_begin;
     if (k >= k_end) break;                                          // every wavefront gets here: the counter only grows
+    WM_PHASE_MARK(10)
     const int g = run_list[k];
     const int u = run_utt[g];
     const int r = g - run_off[u];
@@ -858,13 +874,38 @@ __global__ __launch_bounds__(64, PulseCfg<F>::kWaves) void synth_run_kernel(
       // response[j] belongs to sample idx - F/2 + 1 + j (synthesis.cpp:378-383), the strip starts at sample
       // r S - F/2 + 1: position idx - r S + j
       double* at = strip + (rec.idx - r * kRunS);
-      pulse_response<F>(sp, ap, rec, dcr, rtab, fs, fp, tw, smem, out, lane0, [&](int j, double a, double b2) {
-        // read, add, write: hardware FP64 atomics without return (global_atomic_add_f64) made the kernel 12 % slower
-        at[j] += a;
-        at[j + 1] += b2;
-      });
+      WM_PHASE_MARK(0)
+      // The pairs of the response wait in registers until all are there; then the strip's values are fetched together,
+      // added to and written back.  (Adding inside emit() made every pair its own trip to L2 -- the compiler keeps a
+      // load behind the store before it -- and the end of a pulse 20 % of its time.)
+      constexpr int MP = F / 128;
+      double ra[MP], rb[MP];
+      int rj[MP];
+      pulse_response<F>(sp, ap, rec, dcr, rtab, fs, fp, tw, smem, out, lane0, [&](int m, int j, double a, double b2) {
+        ra[m] = a;
+        rb[m] = b2;
+        rj[m] = j;
+      }
+#ifdef WM_PHASE
+      , phase_clock_
+#endif
+      );
+      {
+        double2_a8 cur[MP];
+#pragma unroll
+        for (int m = 0; m < MP; ++m) cur[m] = *reinterpret_cast<const double2_a8*>(at + rj[m]);
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+          cur[m].x += ra[m];
+          cur[m].y += rb[m];
+        }
+#pragma unroll
+        for (int m = 0; m < MP; ++m) *reinterpret_cast<double2_a8*>(at + rj[m]) = cur[m];
+      }
+      WM_PHASE_MARK(11)
     }
   }
+  WM_PHASE_FLUSH(0)
 }
 
 // y[n] = the sum of the strips that cover sample n, in run order (every sample of the part's utterances is written:
