@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     WM_PHASE_MARK(1)
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
-    rfft_forward<N>(v, img, img, tw, lane);
+    rfft_forward_nz<N>(v, img, img, tw, lane, (fg.L + 127) >> 7);     // the window reaches that many packed registers
     {
       double p[M + 1];
 #pragma unroll

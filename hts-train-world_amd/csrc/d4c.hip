@@ -199,6 +199,7 @@ __device__ __forceinline__ void d4c_centroid(const double* __restrict__ xu, int 
   const double s = (double)(1 << (31 - __clz(fg.hw | 1)));
   double x[QX];
   double pwr;
+  const int nzc = (fg.L + 63) >> 6;                 // registers of the operand the window reaches (not LONG: L <= N)
   frame_strided<kBlackman, QX, !LONG>(xu, xl, fg, rtab, ro, lane, x, pwr);
   // normalisation to unit energy (d4c.cpp:96-100) and the 1 / (2 s) of the identity above, on the result
   const double scale = uniform_d(1.0 / (2.0 * s * pwr));
@@ -210,7 +211,8 @@ __device__ __forceinline__ void d4c_centroid(const double* __restrict__ xu, int 
     if constexpr (!LONG) v[m] = make_double2(s * x[m], r * x[m]);
     else v[m] = make_double2(s * (x[m] + x[m + M]), r * x[m] + (r + N) * x[m + M]);
   }
-  fft_forward<N>(v, img, tw, lane);
+  if constexpr (LONG) fft_forward<N>(v, img, tw, lane);
+  else fft_forward_nz<N>(v, img, tw, lane, nzc);
   wave_sync();
 #pragma unroll
   for (int m = M / 2; m < M; ++m) img[lane + 64 * m] = v[m];       // the partners E[N - j] of j < N / 2
@@ -241,7 +243,8 @@ __device__ __forceinline__ void d4c_centroid(const double* __restrict__ xu, int 
     }
     w = cmul(w, tw.wstep());                                        // W_FD^64
   }
-  fft_forward<N>(v, img, tw, lane);
+  if constexpr (LONG) fft_forward<N>(v, img, tw, lane);
+  else fft_forward_nz<N>(v, img, tw, lane, nzc);
   wave_sync();
 #pragma unroll
   for (int m = M / 2; m < M; ++m) img[lane + 64 * m] = v[m];
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       const FrameGeom fg = frame_geom(fs, cf0, pos, 4.0);
       frame_packed<kHann, false, M>(xu, xl, fg, rtab, roff + 2 * Lw, lane, v);
       WM_PHASE_MARK(3)                                                                // Hann frame
-      rfft_forward<N>(v, img, img, tw, lane);
+      rfft_forward_nz<N>(v, img, img, tw, lane, RARE ? M : (fg.L + 127) >> 7);
       double p[MB];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
         }
       }
       WM_PHASE_MARK(7)                                                                // band window
-      rfft_forward<N>(v, img, img, tw, lane);
+      rfft_forward_nz<N>(v, img, img, tw, lane, (wl + 127) >> 7);
       WM_PHASE_MARK(8)                                                                // band transform
       double p[MB];
       double tot = 0.0;

@@ -152,6 +152,40 @@ template <int R> struct Dft {
   }
 };
 
+// The same with only the first NZ inputs possibly non-zero (the analysis frames are a few hundred samples in a
+// transform of one or two thousand: most of what the first pass reads is padding).  By halves as above: the even inputs
+// have ceil(NZ / 2) leading non-zeros, the odd ones NZ / 2; a sub-transform of one non-zero input is that input at every
+// output, of none it is zero; the combining butterflies stay (their operands are dense).  Radix 16: 32 butterflies
+// become 28 / 24 / 20 / 16 / 8 / 0 for NZ = 12 / 8 / 6 / 4 / 2 / 1.  v[r], r >= NZ, is not read.
+template <int R, int NZ> struct DftNz {
+  __device__ static __forceinline__ void run(cpx (&v)[R]) {
+    if constexpr (NZ >= R) {
+      Dft<R>::run(v);
+    } else if constexpr (NZ <= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[r] = make_double2(0.0, 0.0);
+    } else if constexpr (NZ == 1) {
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[r] = v[0];
+    } else {
+      cpx e[R / 2], o[R / 2];
+#pragma unroll
+      for (int r = 0; r < R / 2; ++r) {
+        e[r] = v[2 * r];
+        o[r] = v[2 * r + 1];
+      }
+      DftNz<R / 2, (NZ + 1) / 2>::run(e);
+      DftNz<R / 2, NZ / 2>::run(o);
+      Dft<R>::template combine<0>(e, o);
+#pragma unroll
+      for (int q = 0; q < R / 2; ++q) {
+        v[q] = e[q];
+        v[q + R / 2] = o[q];
+      }
+    }
+  }
+};
+
 // X[q] = sum_r v[r] w^r W_R^(r q): the DFT of inputs that still lack their inter-pass twiddles w^r.
 // pw[k] = w^(2^k), k = 0 .. log2(R) - 1.
 template <int R> struct TwDft {
@@ -266,29 +300,43 @@ template <int N> struct FftTw {
 // a full index computation per element instead of one base plus immediate offsets
 template <int N> __device__ __forceinline__ unsigned fft_pad(unsigned i) { return i + i / (unsigned)FftCfg<N>::R1; }
 
-// Forward complex FFT (e^{-j}).  v[m] holds element lane + 64 m on entry and on
-// exit.  `lds` must provide FftLds<N>::kElems cpx.  Caller guarantees no other
-// use of `lds` is in flight (ends with registers only; starts with a barrier).
-template <int N>
-__device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
-  constexpr int M = N / 64;
-  // per-call fences: every transform derives its own LDS addresses and twiddle powers (a few
-  // integer ops / FMAs) instead of sharing hoisted copies that the register allocator then spills
-  asm volatile("" : "+v"(lane));
-  const_cast<FftTw<N>&>(tw).fence();
-  constexpr int R1 = FftCfg<N>::R1, R2 = FftCfg<N>::R2, R3 = FftCfg<N>::R3;
-  constexpr int S1 = M / R1, S2 = M / R2, S3 = M / R3;
-  static_assert(S1 >= 1 && S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
-  static_assert(R1 * R2 * R3 == N, "radix plan");
+// pass 1 of a transform whose inputs are zero from element 64 NZM on: butterfly b (of S1) holds the inputs
+// b + r S1, of which the first ceil((NZM - b) / S1) may be non-zero.  b is a loop counter (a constant once unrolled):
+// the switch folds.
+template <int R1, int S1, int NZM> __device__ __forceinline__ void fft_pass1_pruned(cpx (&a)[R1], int b) {
+  static_assert(S1 <= 2, "radix plans here have one or two first-pass butterflies per lane");
+  constexpr int NZ0 = (NZM + S1 - 1) / S1 < R1 ? (NZM + S1 - 1) / S1 : R1;                     // b = 0
+  constexpr int NZ1 = NZM - 1 <= 0 ? 0 : ((NZM - 1 + S1 - 1) / S1 < R1 ? (NZM - 1 + S1 - 1) / S1 : R1);   // b = 1
+  if (b == 0) DftNz<R1, NZ0>::run(a);
+  else DftNz<R1, NZ1>::run(a);
+}
 
+// The three passes of the forward complex FFT (e^{-j}) of one wavefront.  v[m] holds element lane + 64 m on entry
+// and on exit; `lds` must provide FftLds<N>::kElems cpx.  Caller guarantees no other use of `lds` is in flight (ends
+// with registers only; starts with a barrier).
+// fft_pass1<N, NZM>: the first pass, registers -> LDS image.  NZM: only v[0 .. NZM) may be non-zero on entry (elements
+// below 64 NZM); the others are not read.  Everything the pass produces is in LDS when it ends, so the variants of a
+// run-time choice (fft_forward_nz) meet with no register live across them.
+template <int N, int NZM>
+__device__ __forceinline__ void fft_pass1(const cpx (&v)[N / 64], cpx* lds, int lane) {
+  constexpr int M = N / 64;
+  constexpr int R1 = FftCfg<N>::R1;
+  constexpr int S1 = M / R1;
+  static_assert(S1 >= 1, "radix plan does not fit 64 lanes");
   fft_sync();
   // ---- pass 1: radix R1, Ns = 1, no twiddles; store to out[j*R1 + r]
 #pragma unroll
   for (int b = 0; b < S1; ++b) {
     cpx a[R1];
+    if constexpr (NZM >= M) {
 #pragma unroll
-    for (int r = 0; r < R1; ++r) a[r] = v[b + r * S1];
-    Dft<R1>::run(a);
+      for (int r = 0; r < R1; ++r) a[r] = v[b + r * S1];
+      Dft<R1>::run(a);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R1; ++r) a[r] = b + r * S1 < NZM ? v[b + r * S1] : make_double2(0.0, 0.0);
+      fft_pass1_pruned<R1, S1, NZM>(a, b);
+    }
     const unsigned j = (unsigned)lane + 64u * b;
 #pragma unroll
     for (int r = 0; r < R1; ++r) lds[fft_pad<N>(j * R1 + r)] = a[r];
@@ -296,6 +344,16 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
     __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: bounds the live registers
 #endif
   }
+}
+
+// passes 2 and 3: LDS image -> registers
+template <int N>
+__device__ __forceinline__ void fft_finish(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  constexpr int M = N / 64;
+  constexpr int R1 = FftCfg<N>::R1, R2 = FftCfg<N>::R2, R3 = FftCfg<N>::R3;
+  constexpr int S2 = M / R2, S3 = M / R3;
+  static_assert(S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
+  static_assert(R1 * R2 * R3 == N, "radix plan");
   fft_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
@@ -347,6 +405,34 @@ __device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const Ff
   }
 }
 
+template <int N, int NZM = N / 64>
+__device__ __forceinline__ void fft_forward(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  // per-call fences: every transform derives its own LDS addresses and twiddle powers (a few
+  // integer ops / FMAs) instead of sharing hoisted copies that the register allocator then spills
+  asm volatile("" : "+v"(lane));
+  const_cast<FftTw<N>&>(tw).fence();
+  fft_pass1<N, NZM>(v, lds, lane);
+  fft_finish<N>(v, lds, tw, lane);
+}
+
+// fft_forward with the number of leading registers that may be non-zero known at run time (wave-uniform `nz`: the
+// window of an analysis frame): the first pass comes in four sizes.
+template <int N>
+__device__ __forceinline__ void fft_forward_nz(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane, int nz) {
+  constexpr int M = N / 64;
+  if constexpr (N < 512) {                               // 256 points ride on the 512-point plan (end of the file)
+    fft_forward<N>(v, lds, tw, lane);
+  } else {
+    asm volatile("" : "+v"(lane));
+    const_cast<FftTw<N>&>(tw).fence();
+    if (8 * nz <= M) fft_pass1<N, M / 8>(v, lds, lane);
+    else if (4 * nz <= M) fft_pass1<N, M / 4>(v, lds, lane);
+    else if (2 * nz <= M) fft_pass1<N, M / 2>(v, lds, lane);
+    else fft_pass1<N, M>(v, lds, lane);
+    fft_finish<N>(v, lds, tw, lane);
+  }
+}
+
 // Unnormalised inverse complex FFT (e^{+j}) via conj . forward . conj.
 template <int N>
 __device__ __forceinline__ void fft_backward(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
@@ -361,11 +447,27 @@ __device__ __forceinline__ void fft_backward(cpx (&v)[N / 64], cpx* lds, const F
 // r2c: on entry v[m] = (x[2n], x[2n+1]), n = lane + 64 m.  On exit the half
 // spectrum X[0..N] is in `spec` (LDS, N+1 cpx, plain layout): spec may alias the
 // FFT image (it is only written after the last exchange).
+// The split after the complex transform (shared by rfft_forward and rfft_forward_nz).
 template <int N>
+__device__ __forceinline__ void rfft_split(cpx (&v)[N / 64], cpx* lds, cpx* spec, const FftTw<N>& tw, int lane);
+
+template <int N, int NZM = N / 64>
 __device__ __forceinline__ void rfft_forward(cpx (&v)[N / 64], cpx* lds, cpx* spec, const FftTw<N>& tw,
                                              int lane) {
+  fft_forward<N, NZM>(v, lds, tw, lane);
+  rfft_split<N>(v, lds, spec, tw, lane);
+}
+// nz: the packed registers v[0 .. nz) may be non-zero (wave-uniform)
+template <int N>
+__device__ __forceinline__ void rfft_forward_nz(cpx (&v)[N / 64], cpx* lds, cpx* spec, const FftTw<N>& tw, int lane,
+                                                int nz) {
+  fft_forward_nz<N>(v, lds, tw, lane, nz);
+  rfft_split<N>(v, lds, spec, tw, lane);
+}
+
+template <int N>
+__device__ __forceinline__ void rfft_split(cpx (&v)[N / 64], cpx* lds, cpx* spec, const FftTw<N>& tw, int lane) {
   constexpr int M = N / 64;
-  fft_forward<N>(v, lds, tw, lane);
   asm volatile("" : "+v"(lane));
   wave_sync();
 #pragma unroll

@@ -749,7 +749,7 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
       if (i0 + 1 < noise_size) v[m].y -= avg;
     }
   }
-  rfft_forward<N>(v, img, img, tw, lane);
+  rfft_forward_nz<N>(v, img, img, tw, lane, (noise_size + 127) >> 7);   // the draws up to the next pulse, zeros behind
   WM_PHASE_MARK(7)
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
