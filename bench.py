@@ -44,8 +44,8 @@ def byte_model(fs, fp_ms, fft_size):
       analysis  : hop samples*8 + t 8 + f0 8 + sp bins*8 + ap bins*8   (8864 at 16 kHz / 5 ms / fft 1024)
       synthesis : f0 8 + sp + ap + hop samples*8                       (8856)
       d4c_kernel: its hop new samples + t + f0 + ap0 in, one ap row out (4768)
-      pulse     : synth_run_kernel (timed as "synth_pulse_kernel"): f0 + one sp row + one ap row in per frame (the
-                  strips of its runs are intermediates, y is the combine kernel's)   (8216)"""
+      pulse     : synth_pulse_kernel: f0 + one sp row + one ap row in per frame (its responses are intermediates,
+                  y is the overlap-add kernel's)                       (8216)"""
     hop = fs * fp_ms / 1000.0
     bins = fft_size // 2 + 1
     analysis = hop * 8 + 16 + 2 * bins * 8
@@ -981,9 +981,8 @@ def synthesis_bench(env, ctx, xs, feats, fs, fp, steps, warmup, prewarm, cpu=Tru
         # aperiodic part; counted as 7 (voiced) / 4 (unvoiced) real FFTs of F points, about 5.8 per frame
         flops = frames * 5.8 * 2.5 * F * math.log2(F)
         roof = kernel_roofline("synthesis", "synth_pulse_kernel",
-                               "synth_run_kernel: VALU-issue bound (7 / 4 transforms per voiced / unvoiced pulse, the logarithms, "
-                               "square roots and sines of the minimum-phase spectra); it must read f0 and one sp and ap row "
-                               "per frame, the strips of its runs are intermediates",
+                               "FP64-FFT bound (7 / 4 transforms per voiced / unvoiced pulse); the kernel must read f0 and one "
+                               "sp and ap row per frame, its per-pulse responses are intermediates",
                                kms, steps, frames, bm["pulse"], fs, flops_per_launch=flops)
         roof["pipeline"] = {"bytes_per_frame": bm["synthesis"],
                             "achieved_gbs": round(value / env.world * bm["synthesis"] / 1e9, 3),

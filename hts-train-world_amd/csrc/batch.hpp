@@ -50,12 +50,15 @@ struct Context {
   int64_t scratch_cap = 0;           // in doubles
   int ensure_rng(int64_t count);     // grow + (re)generate, returns error code
   int ensure_scratch(int64_t doubles);
+  int64_t* h_pulse_info = nullptr;   // pinned, mapped: {total pulses, largest per-utterance count} of the last Synthesis
+  int64_t* d_pulse_info = nullptr;   // the same memory as the device sees it
   // second stream + events of launch_analyze_synthesize (created on first use)
   hipStream_t side = nullptr;
   hipStream_t aux = nullptr;         // D4C's RARE launch (d4c_rare)
   hipStream_t prep = nullptr;        // launch_synthesis: the f0-only kernels of the batch's second part
   hipEvent_t ev_call = nullptr, ev_prep_b = nullptr;
   hipEvent_t ev_f0 = nullptr, ev_prep = nullptr, ev_d4c = nullptr, ev_rare = nullptr;
+  hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
   int ensure_side();                 // the second stream and its events, created on first use
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
   bool timing = false;
@@ -195,20 +198,15 @@ struct Batch {
   double* d_phase = nullptr;         // [total_y] scratch (increments / wrapped phase)
   int* d_pulse_cnt = nullptr;        // [n_utt]
   int* d_pulse_tile_cnt = nullptr;   // [n_utt][tiles] pulses per search tile
-  int* d_pulse_first = nullptr;      // first pulse at or after every 128th sample of an utterance (the runs' pulse ranges)
+  int64_t* d_pulse_off = nullptr;    // [n_utt+1]
+  int* d_pulse_first = nullptr;      // first pulse at or after every 128th sample of an utterance (the overlap-add's table)
   int* d_syn_order = nullptr;        // [2 n_utt] the identity, then the utterances by output length (shortest first)
-  std::vector<int> syn_order;        // host copy
-  // the runs of Synthesis (synthesis.hip): utterance u owns the runs run_off[u] .. run_off[u + 1]
-  int run_s = 512;                   // samples of an utterance per run
-  std::vector<int> run_off;          // [n_utt + 1]
-  std::vector<int> run_first;        // [2 n_utt + 1] first position of the i-th utterance's runs in either order of runs
-  int* d_run_off = nullptr;          // [n_utt + 1]
-  int* d_run_utt = nullptr;          // [runs] utterance of a run
-  int* d_run_list = nullptr;         // [2 runs] the runs utterance by utterance in the identity order, then by output length
-  int* d_run_pos = nullptr;          // [2 runs] position of a run in either list
-  int* d_run_cnt = nullptr;          // [runs] pulses of the run in a launch's slot
-  int* d_run_next = nullptr;         // the run kernel's work counter
+  std::vector<int> syn_sorted;       // host copy of the second half
+  void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
+  int64_t pulse_rec_cap = 0;
+  int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
   double* d_dc_remover = nullptr;    // [fft_size]
+  int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per piece (half of the response scratch)
   bool syn_warm = false;                    // launch_analyze_synthesize has run once on this batch
 
   int64_t rng_bound_cheaptrick() const;
@@ -228,7 +226,8 @@ int d4c_rare(Batch& b, const double* d_x, const double* d_t, const double* d_f0,
 int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, double* d_ap);
 int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const double* d_ap, double* d_y);
 int synthesis_prepare(Batch& b, const double* d_f0, double* d_y);
-int synthesis_begin(Batch& b, const double* d_f0, double* d_y);      // the f0-only kernels, queued (no host round trip)
+int synthesis_begin(Batch& b, const double* d_f0, double* d_y);      // the f0-only kernels, queued
+int synthesis_prepare_wait(Batch& b);                                 // their host round trip
 int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y);
 int launch_analyze_synthesize(Batch& b, const double* d_x, double* d_t, double* d_f0, double* d_sp, double* d_ap,
                               double* d_y);

@@ -120,6 +120,7 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   c.timing_clear();
   if (c.d_rng) wm::dev_free(c.d_rng);
   if (c.d_scratch) wm::dev_free(c.d_scratch);
+  if (c.h_pulse_info) hipHostFree(c.h_pulse_info);
   if (c.own_stream) hipStreamDestroy(c.stream);
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
   if (c.ev_f0) hipEventDestroy(c.ev_f0);
@@ -127,6 +128,10 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.ev_d4c) hipEventDestroy(c.ev_d4c);
   if (c.ev_rare) hipEventDestroy(c.ev_rare);
   if (c.aux) { hipStreamSynchronize(c.aux); hipStreamDestroy(c.aux); }
+  for (int h = 0; h < 2; ++h) {
+    if (c.ev_pulse[h]) hipEventDestroy(c.ev_pulse[h]);
+    if (c.ev_ola[h]) hipEventDestroy(c.ev_ola[h]);
+  }
   delete h;
 }
 
@@ -901,6 +906,8 @@ void Synthesis(const double* f0, int f0_length, const double* const* spectrogram
     tr.mark("stage");
     {
       OnDevice dev_(b->b.ctx[0]);
+      run_or_die("Synthesis", synthesis_prepare_wait(b->b));
+      tr.mark("wait");
       if (hipStreamWaitEvent(ws_stream(), g_up_done, 0) != hipSuccess) die("upload", WM_ERR_HIP);
       run_or_die("Synthesis", synthesis_render(b->b, ds, da, dy));
     }

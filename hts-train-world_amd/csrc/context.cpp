@@ -230,6 +230,10 @@ int Context::ensure_side() {
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_d4c, hipEventDisableTiming));
   rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_rare, hipEventDisableTiming));
   rc = rc ? rc : wm_check(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+  for (int h = 0; h < 2 && !rc; ++h) {
+    rc = wm_check(hipEventCreateWithFlags(&ev_pulse[h], hipEventDisableTiming));
+    rc = rc ? rc : wm_check(hipEventCreateWithFlags(&ev_ola[h], hipEventDisableTiming));
+  }
   return rc;
 }
 
@@ -356,7 +360,7 @@ void free_batch_buffers(Batch& b) {
                   b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_H, b.d_dio_edges, b.d_dio_ylen, b.d_dio_y, b.d_dio_tmp,
                   b.d_dio_yoff, b.d_dio_toff, b.d_dio_mean, b.d_dio_mean_part, b.d_dio_z,
                   b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_slot_off, b.d_dio_cand,
-                  b.d_dio_score, b.d_syn_arena};
+                  b.d_dio_score, b.d_syn_arena, b.d_pulse_rec, b.d_pulse_perm};
   for (void* p : ptrs)
     if (p) dev_free(p);
   if (b.dio_host) dio_free_host(b.dio_host);

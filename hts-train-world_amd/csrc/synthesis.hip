@@ -6,11 +6,11 @@
 //                          the phase accumulation keeps the reference's strictly sequential
 //                          order (lane l adds increments 0..l one after another), so pulse
 //                          positions are bit-identical; pulses are compacted in order.
-//   synth_run_kernel       GetOneFrameSegment :183-221 and the overlap-add of :378-383 for a RUN of consecutive
-//                          pulses of one utterance by one wavefront: 7 (voiced) or 4 (unvoiced) real FFTs of
-//                          fft_size per pulse in LDS/registers, the responses added into the run's strip.
-//   synth_combine_kernel   every output sample = the sum of the strips that cover it, in run order
-//                          (deterministic; "rendering by runs" below).
+//   synth_pulse_kernel     GetOneFrameSegment :183-221: one wavefront per pulse, 7 (voiced) or
+//                          4 (unvoiced) real FFTs of fft_size in LDS/registers.
+//   synth_ola_kernel       the overlap-add of :378-383 in gather form: every output sample sums
+//                          the responses that cover it in pulse order (deterministic, same
+//                          association as the reference's sequential +=).
 // The reference's randn() draws for pulse i are R[idx_i - idx_0 ...) of the universal table
 // (synthesis.cpp:341 reseed, :369 noise_size).
 #include <stdlib.h>
@@ -48,7 +48,7 @@ __device__ __forceinline__ double coarse_vuv(const double* __restrict__ f0, int 
 // Part 1 of GetTimeBase (synthesis.cpp:287-307): per-sample interpolation of the coarse f0 / vuv
 // contours and the phase increment 2 pi f0 / fs.  Fully parallel over samples.
 // (All f0-only kernels take their utterances through a list: Synthesis prepares the batch in two parts, the
-// shortest utterances first -- launch_synthesis.)
+// shortest utterances first -- synthesis_prepare_part.)
 __global__ __launch_bounds__(256) void synth_inc_kernel(
     const int* __restrict__ utts, const double* __restrict__ f0, const int64_t* __restrict__ f_off,
     const int64_t* __restrict__ y_off, int fs, double fp, double lowest_f0, double* __restrict__ vuv_out,
@@ -266,6 +266,47 @@ __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
   }
 }
 
+// Pulse numbers of a part of the batch: utterance utts[k] owns [off[u], off[u] + cnt[u]), numbered from `base` on in
+// list order; info[0] = the part's total, info[1] = its largest count (pinned host memory).
+__global__ __launch_bounds__(256) void synth_pulse_off_kernel(const int* __restrict__ utts, const int* __restrict__ cnt,
+                                                              int n_list, int64_t base, int64_t* __restrict__ off,
+                                                              int64_t* __restrict__ info) {
+  __shared__ int64_t part[256];
+  __shared__ int mx[256];
+  const int per = (n_list + 255) / 256;
+  const int lo = threadIdx.x * per, hi = imin(n_list, lo + per);
+  int64_t sum = 0;
+  int m = 0;
+  for (int k = lo; k < hi; ++k) {
+    const int c = cnt[utts[k]];
+    sum += c;
+    m = imax(m, c);
+  }
+  part[threadIdx.x] = sum;
+  mx[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    int mm = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int64_t v = part[i];
+      part[i] = run;
+      run += v;
+      mm = imax(mm, mx[i]);
+    }
+    info[0] = run;
+    info[1] = mm;
+    __threadfence_system();
+  }
+  __syncthreads();
+  int64_t run = base + part[threadIdx.x];
+  for (int k = lo; k < hi; ++k) {
+    const int u = utts[k];
+    off[u] = run;
+    run += cnt[u];
+  }
+}
+
 __global__ void synth_dc_remover_kernel(int fft_size, double* __restrict__ dcr) {   // GetDCRemover :322-334
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double dc = 0.0;
@@ -441,7 +482,9 @@ __device__ __forceinline__ void minimum_phase_pair(const double* lsp, const doub
   wave_sync();
 }
 
-// Everything a pulse needs that is not spectral data (wave-uniform: the run kernel fills it with scalar loads).
+// Everything a pulse needs that is not spectral data, gathered by a fully parallel kernel so that
+// the per-pulse kernel starts with ONE (scalar) load instead of a binary search over the pulse
+// offsets followed by four levels of dependent loads.
 struct PulseRec {
   int64_t fbase;      // first frame of the utterance
   int nf;             // frames of the utterance
@@ -452,165 +495,251 @@ struct PulseRec {
   double cvuv;        // interpolated vuv at the pulse
 };
 
-// The pulses of a stretch of output samples are found in a table: first[m] = number (within the utterance) of the
-// first pulse whose index is at least kOlaStep * m, m = 0 .. ceil(ylen / kOlaStep); utterance u owns the entries from
-// ola_table_base(yb, u) on (two spare entries per utterance keep the ranges apart whatever yb is).
+struct PulseVoicedPred {                       // synthesis.cpp:197: the pulses that have a periodic response
+  const PulseRec* rec;
+  __device__ bool operator()(int i) const { return rec[i].cvuv > 0.5; }
+};
+
+// The overlap-add finds the pulses of a stretch of output samples in a table: first[m] = number (within the
+// utterance) of the first pulse whose index is at least kOlaStep * m, m = 0 .. ceil(ylen / kOlaStep); utterance u owns
+// the entries from ola_table_base(yb, u) on (two spare entries per utterance keep the ranges apart whatever yb is).
 constexpr int kOlaStep = 128;
 __host__ __device__ inline int64_t ola_table_base(int64_t yb, int u) { return yb / kOlaStep + 2 * (int64_t)u; }
 
-__global__ __launch_bounds__(256) void synth_first_kernel(const int* __restrict__ utts,
-                                                          const int64_t* __restrict__ y_off,
-                                                          const int* __restrict__ p_cnt,
-                                                          const int* __restrict__ pulse_idx, int* __restrict__ first) {
+__global__ __launch_bounds__(256) void synth_pulse_rec_kernel(
+    const int* __restrict__ utts, const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off,
+    const int64_t* __restrict__ p_off, const int* __restrict__ p_cnt, const int* __restrict__ pulse_idx,
+    const double* __restrict__ pulse_shift, const double* __restrict__ vuv, PulseRec* __restrict__ rec,
+    int* __restrict__ first) {
   const int u = utts[blockIdx.y];
+  const int64_t pb = p_off[u];
   const int np = p_cnt[u];
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
   int* fu = first + ola_table_base(yb, u);
   const int m_last = (ylen + kOlaStep - 1) / kOlaStep;
-  if (np == 0) {                                              // no pulse at all: every entry says so
-    for (int m = blockIdx.x * 256 + threadIdx.x; m <= m_last; m += gridDim.x * 256) fu[m] = 0;
-    return;
-  }
   for (int pi = blockIdx.x * 256 + threadIdx.x; pi < np; pi += gridDim.x * 256) {
+    PulseRec r;
+    r.fbase = f_off[u];
+    r.nf = (int)(f_off[u + 1] - f_off[u]);
+    r.idx = pulse_idx[yb + pi];
+    r.roff = r.idx - pulse_idx[yb];
+    r.noise_size = pulse_idx[yb + imin(np - 1, pi + 1)] - r.idx;
+    r.shift = pulse_shift[yb + pi];
+    r.cvuv = vuv[yb + r.idx];
+    rec[pb + pi] = r;
     // table entries whose sample kOlaStep * m lies in (index of the pulse before, index of this pulse]: every entry
     // is written by exactly one pulse; the last pulse also writes the entries behind it (= np: no such pulse)
-    const int idx = pulse_idx[yb + pi];
     const int prev = pi > 0 ? pulse_idx[yb + pi - 1] : -1;
-    for (int m = prev < 0 ? 0 : prev / kOlaStep + 1; m <= imin(m_last, idx / kOlaStep); ++m) fu[m] = pi;
+    for (int m = prev < 0 ? 0 : prev / kOlaStep + 1; m <= imin(m_last, r.idx / kOlaStep); ++m) fu[m] = pi;
     if (pi == np - 1)
-      for (int m = idx / kOlaStep + 1; m <= m_last; ++m) fu[m] = np;
+      for (int m = r.idx / kOlaStep + 1; m <= m_last; ++m) fu[m] = np;
   }
 }
 
-// The response of one pulse (GetOneFrameSegment, synthesis.cpp:183-221) by one wavefront: 7 (voiced) or 4 (unvoiced)
-// real transforms of F points in LDS / registers.  emit(m, j, a, b) receives response[j], response[j + 1] (fftshifted
-// positions, j even, every pair once; m < F / 128 is the compile-time number of the pair within the lane, which
-// delivers the pairs 2 (lane + 64 m)); `out` is a row of F doubles of the
-// wavefront's own where intermediate results wait (LEAN).
-template <int F> struct PulseCfg {
-  static constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
+// One wavefront per pulse.  resp[(p - p_begin) * F + j] = response[j] of synthesis.cpp:211-215.
+template <int F>
+__global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 : 2))) void synth_pulse_kernel(
+    const double* __restrict__ sp, const double* __restrict__ ap, const PulseRec* __restrict__ rec,
+    const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs, double fp, int64_t p_begin,
+    int64_t p_end, const int* __restrict__ perm, double* __restrict__ resp) {
+  constexpr int N = F / 2, M = N / 64, H = F / 2, MB = M + 1;
   // LEAN (fft_size 2048: 16 complex values per lane and array): to run two waves per SIMD nothing of a spectrum's
   // size lives through a transform -- the interpolated envelope and aperiodicity are fetched again for the aperiodic
-  // half instead of being kept (68 registers), the periodic response waits in the row `out` (32), and the log
-  // spectrum shares the LDS image of the transform that consumes it (8 KB: 9 workgroups per CU instead of 6).  One
-  // wave per SIMD had nothing to hide the LDS round trips of its transforms behind.
-  static constexpr bool LEAN = F == 2048 || F == 1024;
+  // half instead of being kept (68 registers), the periodic response waits in the response row it is headed for
+  // (32), and the log spectrum shares the LDS image of the transform that consumes it (8 KB: 9 workgroups per CU
+  // instead of 6).  One wave per SIMD had nothing to hide the LDS round trips of its transforms behind.
+  constexpr bool LEAN = F == 2048 || F == 1024;
   // PAIRED: the two minimum-phase spectra of a voiced pulse through one pair of complex transforms
   // (minimum_phase_pair).  At fft 2048 the pair's registers cost four spilled ones at two waves per SIMD and the
   // kernel is 1 % slower with it than without (A/B at 48 kHz: 10.08 against 9.95 ms), so only fft 1024 takes it.
-  static constexpr bool PAIRED = F == 1024;
-  static constexpr int kSmem = 2 * FftLds<N>::kElems + (LEAN ? 0 : H + 2);       // doubles of LDS
-  static constexpr int kWaves = F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 : 2));   // per SIMD
-};
-
-template <int F, class Emit>
-__device__ __forceinline__ void pulse_response(const double* __restrict__ sp, const double* __restrict__ ap,
-                                               const PulseRec& r, const double* __restrict__ dcr,
-                                               const uint32_t* __restrict__ rtab, int fs, double fp,
-                                               const FftTw<F / 2>& tw, double* smem, double* out, int lane0, Emit emit
-#ifdef WM_PHASE
-                                               , PhaseClock& phase_clock_
-#endif
-                                               ) {
-  constexpr int N = PulseCfg<F>::N, M = PulseCfg<F>::M, H = PulseCfg<F>::H, MB = PulseCfg<F>::MB;
-  constexpr bool LEAN = PulseCfg<F>::LEAN, PAIRED = PulseCfg<F>::PAIRED;
+  constexpr bool PAIRED = F == 1024;
+  __shared__ __attribute__((aligned(16))) double smem[2 * FftLds<N>::kElems + (LEAN ? 0 : H + 2)];
   cpx* img = reinterpret_cast<cpx*>(smem);
   double* ls = LEAN ? smem : smem + 2 * FftLds<N>::kElems;
-  const int lane = opaque_lane(lane0);
-  const int nf = r.nf;
-  const int idx = r.idx;
-  const int noise_size = r.noise_size;                            // synthesis.cpp:369
-  const double cvuv = r.cvuv;
-  const double ctime = idx / (double)fs;                          // pulse_locations = time_axis[i]
-  const double shift = r.shift;
+  const int lane0 = threadIdx.x;
+  FftTw<N> tw;
+  tw.init(lane0);
 
-  // ---- GetSpectralEnvelope / GetAperiodicRatio (:140-178) ----
-  const int ff = imin(nf - 1, (int)floor(ctime / fp));
-  const int fc = imin(nf - 1, (int)ceil(ctime / fp));
-  const double wgt = ff == fc ? 0.0 : ctime / fp - ff;    // beyond the last frame both indices are clamped: a copy there too
-  const double* s0 = sp + (r.fbase + ff) * (int64_t)(H + 1);
-  const double* s1 = sp + (r.fbase + fc) * (int64_t)(H + 1);
-  const double* a0 = ap + (r.fbase + ff) * (int64_t)(H + 1);
-  const double* a1 = ap + (r.fbase + fc) * (int64_t)(H + 1);
-  auto spectral = [&](double (&env)[MB], double (&rat)[MB]) {
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int k = m < M ? lane + 64 * m : H;
-      // synthesis.cpp:140-178 copies row ff when ff == fc and interpolates otherwise; with wgt = 0 (set above for
-      // that case) the interpolation IS the copy (1 x + 0 y = x for finite y, and y is then the same row), so there
-      // is one form and no branch inside the loop: behind one, every bin's loads were a trip to memory of their own
-      env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
-      const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
-      rat[m] = a * a;
-    }
-  };
-  double env_keep[LEAN ? 1 : MB], rat_keep[LEAN ? 1 : MB];
-  double rat0;
-  if constexpr (LEAN) {
-    const double a = (1.0 - wgt) * safe_ap(a0[0]) + wgt * safe_ap(a1[0]);   // bin 0, every lane
-    rat0 = uniform_d(a * a);
-  } else {
-    spectral(env_keep, rat_keep);
-    rat0 = __shfl(rat_keep[0], 0, 64);
-  }
+  // perm lists the chunk's voiced pulses (7 transforms) before its unvoiced ones (4): round-robin over the
+  // list gives every wave the same number of each (partition.hpp)
+  WM_FOR_EACH_LISTED(pi, perm, p_end - p_begin) {
+    const int64_t p = p_begin + pi;
+    const int lane = opaque_lane(lane0);
+    const PulseRec r = rec[p];                                      // wave-uniform
+    const int nf = r.nf;
+    const int idx = r.idx;
+    const int noise_size = r.noise_size;                            // synthesis.cpp:369
+    const double cvuv = r.cvuv;
+    const double ctime = idx / (double)fs;                          // pulse_locations = time_axis[i]
+    const double shift = r.shift;
 
-  // ---- GetPeriodicResponse (:105-138) ----
-  double xp[LEAN ? 1 : M];            // periodic c2r output, x-index i = 2n + c for n < N/2 (first half)
-  double dc = 0.0;
-  const bool periodic = !(cvuv <= 0.5 || rat0 > 0.999);
+    // ---- GetSpectralEnvelope / GetAperiodicRatio (:140-178) ----
+    const int ff = imin(nf - 1, (int)floor(ctime / fp));
+    const int fc = imin(nf - 1, (int)ceil(ctime / fp));
+    const double wgt = ff == fc ? 0.0 : ctime / fp - ff;    // beyond the last frame both indices are clamped: a copy there too
+    const double* s0 = sp + (r.fbase + ff) * (int64_t)(H + 1);
+    const double* s1 = sp + (r.fbase + fc) * (int64_t)(H + 1);
+    const double* a0 = ap + (r.fbase + ff) * (int64_t)(H + 1);
+    const double* a1 = ap + (r.fbase + fc) * (int64_t)(H + 1);
+    auto spectral = [&](double (&env)[MB], double (&rat)[MB]) {
 #pragma unroll
-  for (int m = 0; m < (LEAN ? 1 : M); ++m) xp[m] = 0.0;
-  // A voiced pulse needs two minimum-phase spectra (periodic and aperiodic part): their phases come from ONE pair
-  // of complex transforms (minimum_phase_pair), their amplitudes are the square roots of the spectra themselves
-  if (periodic) {
-    wave_sync();
-    auto log_periodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        ls[lane + 64 * m] = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < MB; ++m) {
+        const int k = m < M ? lane + 64 * m : H;
+        // synthesis.cpp:140-178 copies row ff when ff == fc and interpolates otherwise; with wgt = 0 (set above for
+        // that case) the interpolation IS the copy (1 x + 0 y = x for finite y, and y is then the same row), so there
+        // is one form and no branch inside the loop: behind one, every bin's loads were a trip to memory of their own
+        env[m] = (1.0 - wgt) * fabs(s0[k]) + wgt * fabs(s1[k]);
+        const double a = (1.0 - wgt) * safe_ap(a0[k]) + wgt * safe_ap(a1[k]);
+        rat[m] = a * a;
       }
-      if (lane == 0) ls[H] = wm_log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
     };
-    cpx mp[MB];
-    if constexpr (PAIRED) {
-      double* ls2 = ls + H + 2;                                   // the aperiodic log spectrum beside the periodic one
-      {
-        double env[MB], rat[MB];
-        spectral(env, rat);
+    double env_keep[LEAN ? 1 : MB], rat_keep[LEAN ? 1 : MB];
+    double rat0;
+    if constexpr (LEAN) {
+      const double a = (1.0 - wgt) * safe_ap(a0[0]) + wgt * safe_ap(a1[0]);   // bin 0, every lane
+      rat0 = uniform_d(a * a);
+    } else {
+      spectral(env_keep, rat_keep);
+      rat0 = __shfl(rat_keep[0], 0, 64);
+    }
+    double* out = resp + (p - p_begin) * (int64_t)F;
+
+    // ---- GetPeriodicResponse (:105-138) ----
+    double xp[LEAN ? 1 : M];            // periodic c2r output, x-index i = 2n + c for n < N/2 (first half)
+    double dc = 0.0;
+    const bool periodic = !(cvuv <= 0.5 || rat0 > 0.999);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const int k = m < M ? lane + 64 * m : H;
-          const double lp = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
-          const double la = wm_log(env[m] * rat[m]) / 2.0;        // cvuv > 0.5 here (synthesis.cpp:53-56)
-          if (m < M || lane == 0) {
-            ls[k] = lp;
-            ls2[k] = la;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+    for (int m = 0; m < (LEAN ? 1 : M); ++m) xp[m] = 0.0;
+    // A voiced pulse needs two minimum-phase spectra (periodic and aperiodic part): their phases come from ONE pair
+    // of complex transforms (minimum_phase_pair), their amplitudes are the square roots of the spectra themselves
+    if (periodic) {
       wave_sync();
-      {
-        double php[M], pha[M];
-        WM_PHASE_MARK(1)
-        minimum_phase_pair<N>(ls, ls2, img, tw, lane, php, pha);
-        WM_PHASE_MARK(2)
-        // the aperiodic part's phases wait in the first half of the response row (free until the response is
-        // written; every lane re-reads its own), the periodic part's in the slots of the spectrum they become
+      auto log_periodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          out[lane + 64 * m] = pha[m];
-          mp[m] = make_double2(0.0, php[m]);
+          ls[lane + 64 * m] = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        mp[M] = make_double2(0.0, 0.0);                             // bin H: real
+        if (lane == 0) ls[H] = wm_log(env[M] * (1.0 - rat[M]) + kSafe) / 2.0;
+      };
+      cpx mp[MB];
+      if constexpr (PAIRED) {
+        double* ls2 = ls + H + 2;                                   // the aperiodic log spectrum beside the periodic one
+        {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int k = m < M ? lane + 64 * m : H;
+            const double lp = wm_log(env[m] * (1.0 - rat[m]) + kSafe) / 2.0;
+            const double la = wm_log(env[m] * rat[m]) / 2.0;        // cvuv > 0.5 here (synthesis.cpp:53-56)
+            if (m < M || lane == 0) {
+              ls[k] = lp;
+              ls2[k] = la;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        wave_sync();
+        {
+          double php[M], pha[M];
+          minimum_phase_pair<N>(ls, ls2, img, tw, lane, php, pha);
+          // the aperiodic part's phases wait in the first half of the response row (free until the response is
+          // written; every lane re-reads its own), the periodic part's in the slots of the spectrum they become
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            out[lane + 64 * m] = pha[m];
+            mp[m] = make_double2(0.0, php[m]);
+          }
+          mp[M] = make_double2(0.0, 0.0);                             // bin H: real
+        }
+        {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+#pragma unroll
+          for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * (1.0 - rat[m]) + kSafe);
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          double sn = 0.0, cs = 1.0;
+          if (m < M) sincospi(mp[m].y * (1.0 / kPi), &sn, &cs);
+          mp[m] = make_double2(mp[m].x * cs, mp[m].x * sn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        if constexpr (LEAN) {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+          log_periodic(env, rat);
+        } else {
+          log_periodic(env_keep, rat_keep);
+        }
+        wave_sync();
+        minimum_phase<N>(ls, img, tw, lane, mp);
+      }
+      const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
+      // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
+      // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
+      double rc, rs, dc64, ds64;
+      // in half-turns (coef / pi = 2 shift fs / F): the argument's own rounding, 1e-16 of up to 2000 half-turns,
+      // moves a phase by 1e-12 rad at most -- the size of the rounding of coef * k itself
+      const double ch = coef * (1.0 / kPi);
+      double snH, reH;
+      wm_sincospi(ch * lane, &rs, &rc);
+      wm_sincospi(ch * 64.0, &ds64, &dc64);
+      wm_sincospi(ch * H, &snH, &reH);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {                                // :88-100
+        const int k = m < M ? lane + 64 * m : H;
+        const double re2 = m < M ? rc : reH;
+        {
+          const double nc = rc * dc64 - rs * ds64;
+          rs = rs * dc64 + rc * ds64;
+          rc = nc;
+        }
+        // synthesis.cpp:96 takes the sine as sqrt(1 - cos^2): always >= 0.  The rotated cosine can pass 1 by a
+        // rounding where the reference's cos() cannot: wm_sqrt returns 0 there instead of a NaN
+        const double im2 = wm_sqrt(1.0 - re2 * re2);
+        const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
+        if (m < M || lane == 0) img[k] = s;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cpx v[M];
+      rfft_backward<N>(img, v, img, tw, lane);
+      // fftshift + RemoveDCComponent (:73-82, :135-137): dc = sum of the shifted second half = x[0..H)
+#pragma unroll
+      for (int m = 0; m < M / 2; ++m) {
+        if constexpr (LEAN) {                                       // waits where it is headed for (every lane re-reads its own)
+          const int i0 = 2 * (lane + 64 * m);
+          *reinterpret_cast<cpx*>(out + i0 + H) = v[m];
+        } else {
+          xp[2 * m] = v[m].x;
+          xp[2 * m + 1] = v[m].y;
+        }
+        dc += v[m].x + v[m].y;
+      }
+      dc = wave_sum(dc);
+      if constexpr (LEAN) dc = uniform_d(dc);
+      wave_sync();
+    }
+
+    // ---- GetAperiodicResponse (:38-68) ----
+    wave_sync();
+    cpx mp[MB];
+    if (PAIRED && periodic) {
+      // phases from the pair above (parked in the response row); amplitude sqrt(env * rat) (cvuv > 0.5 on a periodic pulse)
+      {
+        const int lp_ = opaque_lane(lane);
+#pragma unroll
+        for (int m = 0; m < M; ++m) mp[m] = make_double2(0.0, out[lp_ + 64 * m]);
+        mp[M] = make_double2(0.0, 0.0);
       }
       {
         double env[MB], rat[MB];
         spectral(env, rat);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * (1.0 - rat[m]) + kSafe);
+        for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * rat[m]);
       }
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
@@ -620,440 +749,247 @@ __device__ __forceinline__ void pulse_response(const double* __restrict__ sp, co
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (LEAN) {
-        double env[MB], rat[MB];
-        spectral(env, rat);
-        log_periodic(env, rat);
-      } else {
-        log_periodic(env_keep, rat_keep);
+      {
+        auto log_aperiodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
+#pragma unroll
+          for (int m = 0; m < MB; ++m) {
+            const int k = m < M ? lane + 64 * m : H;
+            const double val = wm_log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
+            if (m < M || lane == 0) ls[k] = val;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        if constexpr (LEAN) {
+          double env[MB], rat[MB];
+          spectral(env, rat);
+          log_aperiodic(env, rat);
+        } else {
+          log_aperiodic(env_keep, rat_keep);
+        }
       }
       wave_sync();
       minimum_phase<N>(ls, img, tw, lane, mp);
     }
-    WM_PHASE_MARK(3)
-    const double coef = 2.0 * kPi * shift * fs / F;               // :130-131
-    // cos(coef k) for k = lane + 64 m by rotation from cos/sin(coef lane) in steps of 64 coef
-    // (the reference evaluates cos per bin; the rotation is within 1e-15 of it); bin H directly
-    double rc, rs, dc64, ds64;
-    // in half-turns (coef / pi = 2 shift fs / F): the argument's own rounding, 1e-16 of up to 2000 half-turns,
-    // moves a phase by 1e-12 rad at most -- the size of the rounding of coef * k itself
-    const double ch = coef * (1.0 / kPi);
-    double snH, reH;
-    wm_sincospi(ch * lane, &rs, &rc);
-    wm_sincospi(ch * 64.0, &ds64, &dc64);
-    wm_sincospi(ch * H, &snH, &reH);
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {                                // :88-100
-      const int k = m < M ? lane + 64 * m : H;
-      const double re2 = m < M ? rc : reH;
-      {
-        const double nc = rc * dc64 - rs * ds64;
-        rs = rs * dc64 + rc * ds64;
-        rc = nc;
-      }
-      // synthesis.cpp:96 takes the sine as sqrt(1 - cos^2): always >= 0.  The rotated cosine can pass 1 by a
-      // rounding where the reference's cos() cannot: wm_sqrt returns 0 there instead of a NaN
-      const double im2 = wm_sqrt(1.0 - re2 * re2);
-      const cpx s = make_double2(mp[m].x * re2 + mp[m].y * im2, mp[m].y * re2 - mp[m].x * im2);
-      if (m < M || lane == 0) img[k] = s;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    // GetNoiseSpectrum (:19-33)
     cpx v[M];
-    WM_PHASE_MARK(4)
-    rfft_backward<N>(img, v, img, tw, lane);
-    // fftshift + RemoveDCComponent (:73-82, :135-137): dc = sum of the shifted second half = x[0..H)
+    {
+      // LEAN: the draws are fetched here (their addresses hang on a fenced lane), not ahead of the transforms above
+      const int ln = LEAN ? opaque_lane(lane) : lane;
+      const int roff = r.roff;
+      double sum = 0.0;
 #pragma unroll
-    for (int m = 0; m < M / 2; ++m) {
-      if constexpr (LEAN) {                                       // waits where it is headed for (every lane re-reads its own)
-        const int i0 = 2 * (lane + 64 * m);
-        *reinterpret_cast<cpx*>(out + i0 + H) = v[m];
-      } else {
-        xp[2 * m] = v[m].x;
-        xp[2 * m + 1] = v[m].y;
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (ln + 64 * m);
+        const double n0 = i0 < noise_size ? randn_at(rtab, roff + i0) : 0.0;
+        const double n1 = i0 + 1 < noise_size ? randn_at(rtab, roff + i0 + 1) : 0.0;
+        v[m] = make_double2(n0, n1);
+        sum += n0 + n1;
       }
-      dc += v[m].x + v[m].y;
-    }
-    dc = wave_sum(dc);
-    if constexpr (LEAN) dc = uniform_d(dc);
-    wave_sync();
-  }
-
-  // ---- GetAperiodicResponse (:38-68) ----
-  wave_sync();
-  WM_PHASE_MARK(5)
-  cpx mp[MB];
-  if (PAIRED && periodic) {
-    // phases from the pair above (parked in the response row); amplitude sqrt(env * rat) (cvuv > 0.5 on a periodic pulse)
-    {
-      const int lp_ = opaque_lane(lane);
+      const double avg = wave_sum(sum) / noise_size;
 #pragma unroll
-      for (int m = 0; m < M; ++m) mp[m] = make_double2(0.0, out[lp_ + 64 * m]);
-      mp[M] = make_double2(0.0, 0.0);
+      for (int m = 0; m < M; ++m) {
+        const int i0 = 2 * (ln + 64 * m);
+        if (i0 < noise_size) v[m].x -= avg;
+        if (i0 + 1 < noise_size) v[m].y -= avg;
+      }
     }
-    {
-      double env[MB], rat[MB];
-      spectral(env, rat);
-#pragma unroll
-      for (int m = 0; m < MB; ++m) mp[m].x = wm_sqrt(env[m] * rat[m]);
-    }
+    rfft_forward_nz<N>(v, img, img, tw, lane, (noise_size + 127) >> 7);   // the draws up to the next pulse, zeros behind
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      double sn = 0.0, cs = 1.0;
-      if (m < M) sincospi(mp[m].y * (1.0 / kPi), &sn, &cs);
-      mp[m] = make_double2(mp[m].x * cs, mp[m].x * sn);
-      __builtin_amdgcn_sched_barrier(0);
+      const int k = m < M ? lane + 64 * m : H;
+      const cpx ns = img[k];
+      const cpx s = make_double2(mp[m].x * ns.x - mp[m].y * ns.y, mp[m].x * ns.y + mp[m].y * ns.x);
+      if (m < M || lane == 0) img[k] = s;
     }
-  } else {
-    {
-      auto log_aperiodic = [&](const double (&env)[MB], const double (&rat)[MB]) {
+    rfft_backward<N>(img, v, img, tw, lane);
+
+    // ---- response = (periodic * sqrt(noise_size) + aperiodic) / fft_size (:211-215), fftshifted ----
+    const double sq = sqrt((double)noise_size);
+    cpx xq[LEAN ? M / 2 : 1];
+    const int lo = LEAN ? opaque_lane(lane) : lane;   // LEAN: the DC remover's table is fetched here, not ahead of the transforms
+    if constexpr (LEAN) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const int k = m < M ? lane + 64 * m : H;
-          const double val = wm_log(cvuv != 0.0 ? env[m] * rat[m] : env[m]) / 2.0;
-          if (m < M || lane == 0) ls[k] = val;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if constexpr (LEAN) {
-        double env[MB], rat[MB];
-        spectral(env, rat);
-        log_aperiodic(env, rat);
-      } else {
-        log_aperiodic(env_keep, rat_keep);
+      for (int m = 0; m < M / 2; ++m)
+        xq[m] = periodic ? *reinterpret_cast<const cpx*>(out + 2 * (lo + 64 * m) + H) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int n = lo + 64 * m;
+      const int i0 = 2 * n;                           // x-index; shifted position j = (i + H) mod F
+      double r0, r1;
+      if (m < M / 2) {                                // i < H  ->  j = i + H (second half)
+        const double x0 = LEAN ? xq[LEAN ? m : 0].x : xp[LEAN ? 0 : 2 * m];
+        const double x1 = LEAN ? xq[LEAN ? m : 0].y : xp[LEAN ? 0 : 2 * m + 1];
+        const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 + H);   // unconditional: a load behind the
+        const double p0 = periodic ? x0 - dc * dr.x : 0.0;                    // (uniform) branch is waited for on its own
+        const double p1 = periodic ? x1 - dc * dr.y : 0.0;
+        r0 = (p0 * sq + v[m].x) / F;
+        r1 = (p1 * sq + v[m].y) / F;
+        out[i0 + H] = r0;
+        out[i0 + 1 + H] = r1;
+      } else {                                        // i >= H ->  j = i - H (first half, periodic overwritten)
+        const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 - H);
+        const double p0 = periodic ? -dc * dr.x : 0.0;
+        const double p1 = periodic ? -dc * dr.y : 0.0;
+        r0 = (p0 * sq + v[m].x) / F;
+        r1 = (p1 * sq + v[m].y) / F;
+        out[i0 - H] = r0;
+        out[i0 + 1 - H] = r1;
       }
     }
     wave_sync();
-    minimum_phase<N>(ls, img, tw, lane, mp);
   }
-  // GetNoiseSpectrum (:19-33)
-  WM_PHASE_MARK(6)
-  cpx v[M];
-  {
-    // LEAN: the draws are fetched here (their addresses hang on a fenced lane), not ahead of the transforms above
-    const int ln = LEAN ? opaque_lane(lane) : lane;
-    const int roff = r.roff;
-    double sum = 0.0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int i0 = 2 * (ln + 64 * m);
-      const double n0 = i0 < noise_size ? randn_at(rtab, roff + i0) : 0.0;
-      const double n1 = i0 + 1 < noise_size ? randn_at(rtab, roff + i0 + 1) : 0.0;
-      v[m] = make_double2(n0, n1);
-      sum += n0 + n1;
-    }
-    const double avg = wave_sum(sum) / noise_size;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int i0 = 2 * (ln + 64 * m);
-      if (i0 < noise_size) v[m].x -= avg;
-      if (i0 + 1 < noise_size) v[m].y -= avg;
-    }
-  }
-  rfft_forward_nz<N>(v, img, img, tw, lane, (noise_size + 127) >> 7);   // the draws up to the next pulse, zeros behind
-  WM_PHASE_MARK(7)
-#pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    const int k = m < M ? lane + 64 * m : H;
-    const cpx ns = img[k];
-    const cpx s = make_double2(mp[m].x * ns.x - mp[m].y * ns.y, mp[m].x * ns.y + mp[m].y * ns.x);
-    if (m < M || lane == 0) img[k] = s;
-  }
-  rfft_backward<N>(img, v, img, tw, lane);
-
-  WM_PHASE_MARK(8)
-  // ---- response = (periodic * sqrt(noise_size) + aperiodic) / fft_size (:211-215), fftshifted ----
-  const double sq = sqrt((double)noise_size);
-  cpx xq[LEAN ? M / 2 : 1];
-  const int lo = LEAN ? opaque_lane(lane) : lane;   // LEAN: the DC remover's table is fetched here, not ahead of the transforms
-  if constexpr (LEAN) {
-#pragma unroll
-    for (int m = 0; m < M / 2; ++m)
-      xq[m] = periodic ? *reinterpret_cast<const cpx*>(out + 2 * (lo + 64 * m) + H) : make_double2(0.0, 0.0);
-  }
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int n = lo + 64 * m;
-    const int i0 = 2 * n;                           // x-index; shifted position j = (i + H) mod F
-    double r0, r1;
-    if (m < M / 2) {                                // i < H  ->  j = i + H (second half)
-      const double x0 = LEAN ? xq[LEAN ? m : 0].x : xp[LEAN ? 0 : 2 * m];
-      const double x1 = LEAN ? xq[LEAN ? m : 0].y : xp[LEAN ? 0 : 2 * m + 1];
-      const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 + H);   // unconditional: a load behind the
-      const double p0 = periodic ? x0 - dc * dr.x : 0.0;                    // (uniform) branch is waited for on its own
-      const double p1 = periodic ? x1 - dc * dr.y : 0.0;
-      r0 = (p0 * sq + v[m].x) / F;
-      r1 = (p1 * sq + v[m].y) / F;
-      emit(m, i0 + H, r0, r1);
-    } else {                                        // i >= H ->  j = i - H (first half, periodic overwritten)
-      const double2 dr = *reinterpret_cast<const double2*>(dcr + i0 - H);
-      const double p0 = periodic ? -dc * dr.x : 0.0;
-      const double p1 = periodic ? -dc * dr.y : 0.0;
-      r0 = (p0 * sq + v[m].x) / F;
-      r1 = (p1 * sq + v[m].y) / F;
-      emit(m, i0 - H, r0, r1);
-    }
-  }
-  wave_sync();
-  WM_PHASE_MARK(9)
 }
 
-// ---- rendering by runs ----
-// Until round 4 every pulse had a row of fft_size doubles in a scratch array (one wavefront per pulse wrote it) and an
-// overlap-add kernel gathered the rows into y: 8 KB written and read back per pulse, two rows of sp and two of ap
-// fetched per pulse whatever its neighbours had just fetched (31.9 KB of memory traffic per frame against 8.2
-// algorithmic), a host round trip for the pulse count that sized the scratch, and pieces of the pulse list so that the
-// overlap-add of one could run beside the pulse kernel of the next -- where it took from the pulse kernel what it
-// cost (both are limited by memory: 1.6 ms alone, 1.95 beside the overlap-add).
-//
-// Now the unit of work is a RUN: the pulses of one utterance whose index lies in [r S, (r + 1) S), S = kRunS samples,
-// in order, by one wavefront.  Their responses cover the samples [r S - F/2 + 1, (r + 1) S - 1 + F/2]: the run's STRIP
-// of S + F doubles, zeroed by the wavefront and added into pulse by pulse -- the reference's sequential += per sample
-// (synthesis.cpp:378-383) within the run.  A strip is written by one wavefront only, lives in L2 while it is, and
-// leaves for memory once; consecutive pulses share their sp / ap rows through the caches.  synth_combine_kernel then
-// gives every output sample the sum of the (at most 1 + ceil(F / S)) strips that cover it, in run order.  The order of
-// additions is fixed by the utterance alone (not by the batch, the split into parts, or the scheduling), so y is
-// reproducible bit for bit; it differs from the reference's single chain by the association (a + b) + (c + d) at run
-// boundaries, 1e-16 relative.
-// Nothing here depends on the number of pulses: the scratch is sized from the output lengths, so Synthesis has no host
-// round trip any more.  Runs are handed out through a counter (a wavefront takes the next run when it is done with
-// its own): an unvoiced run of 16 pulses x 4 transforms and a voiced one of 3 x 7 differ too much to deal in advance.
-// S is the batch's (Batch::run_s, a multiple of kOlaStep so that two entries of the first-pulse table bracket a run's
-// pulses): 512 when that still makes several runs per resident wavefront, down to 128 for a single utterance -- whose
-// pulses would otherwise queue up behind each other on a few wavefronts (a run of 512 samples is 6 voiced pulses of
-// 45 us each; the drop-in Synthesis() of one utterance took 1.32 ms with it against 1.0 with a wavefront per pulse).
-
-template <int F>
-__global__ __launch_bounds__(64, PulseCfg<F>::kWaves) void synth_run_kernel(
-    const double* __restrict__ sp, const double* __restrict__ ap, const int* __restrict__ run_list, int k_begin,
-    int k_end, int* __restrict__ next, const int* __restrict__ run_utt, const int* __restrict__ run_off,
-    const int64_t* __restrict__ f_off, const int64_t* __restrict__ y_off, const int* __restrict__ p_cnt,
-    const int* __restrict__ pulse_idx, const double* __restrict__ pulse_shift, const double* __restrict__ vuv,
-    const int* __restrict__ first, const double* __restrict__ dcr, const uint32_t* __restrict__ rtab, int fs,
-    double fp, int run_s, double* __restrict__ park, double* __restrict__ strips, int* __restrict__ run_cnt) {
-  constexpr int N = F / 2;
-  const int kRunS = run_s, kStride = run_s + F;
-  __shared__ __attribute__((aligned(16))) double smem[PulseCfg<F>::kSmem];
-  const int lane0 = threadIdx.x;
-  FftTw<N> tw;
-  tw.init(lane0);
-  double* out = park + (int64_t)blockIdx.x * F;                     // this wavefront's row for intermediates
-  WM_PHASE_DECL
-  for (;;) {
-    int k = 0;
-    if (lane0 == 0) k = atomicAdd(next, 1);
-    k = __builtin_amdgcn_readfirstlane(k) + k_begin;
-    if (k >= k_end) break;                                          // every wavefront gets here: the counter only grows
-    WM_PHASE_MARK(10)
-    const int g = run_list[k];
-    const int u = run_utt[g];
-    const int r = g - run_off[u];
-    const int64_t yb = y_off[u];
-    const int ylen = (int)(y_off[u + 1] - yb);
-    const int np = p_cnt[u];
-    const int* fu = first + ola_table_base(yb, u);
-    const int m_last = (ylen + kOlaStep - 1) / kOlaStep;
-    const int pa = np > 0 ? fu[imin(m_last, r * (kRunS / kOlaStep))] : 0;
-    const int pb = np > 0 ? fu[imin(m_last, (r + 1) * (kRunS / kOlaStep))] : 0;
-    const int slot = k - k_begin;
-    if (lane0 == 0) run_cnt[slot] = pb - pa;
-    if (pa >= pb) continue;                                         // no pulse in these samples: the strip is not read
-    double* strip = strips + (int64_t)slot * kStride;
-    for (int i = lane0; i < kStride; i += 64) strip[i] = 0.0;
-    const int* pidx = pulse_idx + yb;
-    const double* pshift = pulse_shift + yb;
-    PulseRec rec;
-    rec.fbase = f_off[u];
-    rec.nf = (int)(f_off[u + 1] - f_off[u]);
-    const int idx_first = pidx[0];
-    for (int pi = pa; pi < pb; ++pi) {
-      rec.idx = pidx[pi];
-      rec.roff = rec.idx - idx_first;
-      rec.noise_size = pidx[imin(np - 1, pi + 1)] - rec.idx;
-      rec.shift = pshift[pi];
-      rec.cvuv = vuv[yb + rec.idx];
-      // response[j] belongs to sample idx - F/2 + 1 + j (synthesis.cpp:378-383), the strip starts at sample
-      // r S - F/2 + 1: position idx - r S + j
-      double* at = strip + (rec.idx - r * kRunS);
-      WM_PHASE_MARK(0)
-      // The pairs of the response wait in registers until all are there; then the strip's values are fetched together,
-      // added to and written back.  (Adding inside emit() made every pair its own trip to L2 -- the compiler keeps a
-      // load behind the store before it -- and the end of a pulse 20 % of its time.)
-      constexpr int MP = F / 128;
-      double ra[MP], rb[MP];
-      int rj[MP];
-      pulse_response<F>(sp, ap, rec, dcr, rtab, fs, fp, tw, smem, out, lane0, [&](int m, int j, double a, double b2) {
-        ra[m] = a;
-        rb[m] = b2;
-        rj[m] = j;
-      }
-#ifdef WM_PHASE
-      , phase_clock_
-#endif
-      );
-      {
-        double2_a8 cur[MP];
-#pragma unroll
-        for (int m = 0; m < MP; ++m) cur[m] = *reinterpret_cast<const double2_a8*>(at + rj[m]);
-#pragma unroll
-        for (int m = 0; m < MP; ++m) {
-          cur[m].x += ra[m];
-          cur[m].y += rb[m];
-        }
-#pragma unroll
-        for (int m = 0; m < MP; ++m) *reinterpret_cast<double2_a8*>(at + rj[m]) = cur[m];
-      }
-      WM_PHASE_MARK(11)
-    }
-  }
-  WM_PHASE_FLUSH(0)
-}
-
-// y[n] = the sum of the strips that cover sample n, in run order (every sample of the part's utterances is written:
-// y needs no clearing).  Run r covers [r S - h + 1, (r + 1) S - 1 + h], h = fft_size / 2.
-__global__ __launch_bounds__(256) void synth_combine_kernel(const int* __restrict__ utts,
-                                                            const int64_t* __restrict__ y_off,
-                                                            const int* __restrict__ run_off,
-                                                            const int* __restrict__ run_pos, int k_begin,
-                                                            const int* __restrict__ run_cnt, int fft_size,
-                                                            int run_s, const double* __restrict__ strips,
-                                                            double* __restrict__ y) {
-  const int kRunS = run_s;
+// y[n] += sum over pulses p (of this utterance, within [p_begin, p_end)) covering n, in pulse order:
+// index = j + idx - F/2 + 1  (synthesis.cpp:378-383)  ->  j = n - idx + F/2 - 1.
+// ONE WAVEFRONT owns a stretch of kOlaSeg consecutive output samples (lane l the pairs 2 l + 128 q, q < kOlaQ) and
+// streams through the response rows of the pulses that reach into it, in pulse order, adding into registers: the
+// association is the reference's sequential += per sample, a row is read once per stretch it touches (1 + F / kOlaSeg
+// stretches: 3 at fft 1024), in 16-byte loads of consecutive lanes.  A chunk of 128 samples that a row does not reach
+// is skipped (wave-uniform), one that it covers whole takes one load per lane, the two at the row's ends two
+// predicated 8-byte loads.  Adding nothing where the round-3 kernel added an exact + 0.0 is the same sum: the
+// accumulator starts from y (+0.0 or a sum) and x + 0.0 == x unless x is -0.0, which a sum starting at +0.0 never is.
+// The pulse range of a stretch comes from the first-pulse table (synth_pulse_rec_kernel), not from a search.
+// Round 3 gave a thread one sample of a tile of 256 and walked every pulse near the tile with 8-byte loads, four in
+// flight: 0.8 TB/s where a stream reads at 6, 15.8 ms busy per configs[4] step beside the pulse kernel.
+constexpr int kOlaQ = 4, kOlaSeg = 128 * kOlaQ, kOlaWaves = 4;
+__global__ __launch_bounds__(64 * kOlaWaves) void synth_ola_kernel(const int* __restrict__ utts,
+                                                                   const int64_t* __restrict__ y_off,
+                                                                   const int64_t* __restrict__ p_off,
+                                                                   const int* __restrict__ p_cnt,
+                                                                   const int* __restrict__ pulse_idx,
+                                                                   const int* __restrict__ first, int fft_size,
+                                                                   int64_t p_begin, int64_t p_end,
+                                                                   const double* __restrict__ resp,
+                                                                   double* __restrict__ y) {
   const int u = utts[blockIdx.y];
+  const int lane = threadIdx.x & 63;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
-  const int nruns = (ylen + kRunS - 1) / kRunS;
-  const int g0 = run_off[u];
+  const int n0 = (blockIdx.x * kOlaWaves + (threadIdx.x >> 6)) * kOlaSeg;      // wave-uniform
+  const int64_t pu = p_off[u];
+  const int np = p_cnt[u];
+  // pulses of another part of the batch (their numbers lie outside this launch's piece) or none at all
+  if (n0 >= ylen || np == 0 || pu >= p_end || pu + np <= p_begin) return;
   const int h = fft_size / 2;
-  const int64_t stride = kRunS + fft_size;
-  for (int n = blockIdx.x * 256 + threadIdx.x; n < ylen; n += gridDim.x * 256) {
-    const int r_lo = n >= h ? (n - h) / kRunS : 0;
-    const int r_hi = imin(nruns - 1, (n + h - 1) / kRunS);
-    double acc = 0.0;
-    for (int r = r_lo; r <= r_hi; ++r) {
-      const int slot = run_pos[g0 + r] - k_begin;
-      if (run_cnt[slot] > 0) acc += strips[slot * stride + (n - r * kRunS + h - 1)];
+  // pulses with n0 - h <= idx <= n0 + kOlaSeg + h - 2 reach into the stretch; the table brackets them (a few more on
+  // the left, whose rows end before the stretch and are skipped chunk by chunk)
+  const int* fu = first + ola_table_base(yb, u);
+  const int m_last = (ylen + kOlaStep - 1) / kOlaStep;
+  const int lo_s = imax(0, n0 - h), hi_s = n0 + kOlaSeg + h - 2;
+  int pa = fu[lo_s / kOlaStep];
+  int pb = fu[imin(m_last, hi_s / kOlaStep + 1)];
+  const int64_t rel_a = p_begin - pu, rel_b = p_end - pu;        // the piece's pulses, utterance-relative
+  pa = rel_a > pa ? (int)(rel_a < np ? rel_a : np) : pa;
+  pb = rel_b < pb ? (int)(rel_b > 0 ? rel_b : 0) : pb;
+  if (pa >= pb) return;
+  const int* pidx = pulse_idx + yb;
+  double2_a8 acc[kOlaQ];
+#pragma unroll
+  for (int q = 0; q < kOlaQ; ++q) {
+    const int n = n0 + 128 * q + 2 * lane;
+    acc[q].x = n < ylen ? y[yb + n] : 0.0;
+    acc[q].y = n + 1 < ylen ? y[yb + n + 1] : 0.0;
+  }
+  for (int base = pa; base < pb; base += 64) {
+    const int cnt = imin(64, pb - base);
+    const int my_idx = pidx[base + imin(lane, cnt - 1)];         // the indices of up to 64 pulses, one per lane
+    for (int k = 0; k < cnt; ++k) {
+      const int idx = __builtin_amdgcn_readlane(my_idx, k);
+      const int s = idx - h + 1 - n0;                             // stretch-relative sample of response[0]
+      const double* row = resp + ((int64_t)(pu + base + k) - p_begin) * fft_size;
+#pragma unroll
+      for (int q = 0; q < kOlaQ; ++q) {
+        const int c0 = 128 * q - s;                               // response index of the chunk's first sample
+        if (c0 + 127 < 0 || c0 >= fft_size) continue;             // the row does not reach the chunk
+        const int j = c0 + 2 * lane;
+        if (c0 >= 0 && c0 + 127 < fft_size) {
+          const double2_a8 v = *reinterpret_cast<const double2_a8*>(row + j);
+          acc[q].x += v.x;
+          acc[q].y += v.y;
+        } else {
+          const bool in0 = j >= 0 && j < fft_size, in1 = j + 1 >= 0 && j + 1 < fft_size;
+          const double v0 = row[imin(fft_size - 1, imax(0, j))];
+          const double v1 = row[imin(fft_size - 1, imax(0, j + 1))];
+          if (in0) acc[q].x += v0;
+          if (in1) acc[q].y += v1;
+        }
+      }
     }
-    y[yb + n] = acc;
+  }
+#pragma unroll
+  for (int q = 0; q < kOlaQ; ++q) {
+    const int n = n0 + 128 * q + 2 * lane;
+    if (n < ylen) y[yb + n] = acc[q].x;
+    if (n + 1 < ylen) y[yb + n + 1] = acc[q].y;
   }
 }
 
 // Synthesis in two stages.  The PREPARE stage is everything that depends on f0 only: sample-rate f0 / vuv, the time
-// base, the pulse list and the first-pulse table.  The RENDER stage turns sp / ap into the strips of the runs and
-// combines them.  Both are asynchronous on the context's stream.
+// base, the pulse list and its per-pulse records; it ends with the one host round trip of the path (the pulse count
+// sizes the response scratch).  The RENDER stage turns sp / ap into responses and overlap-adds them.
 //
-// Both work on a PART of the batch: a list of utterances and the runs of those utterances (Batch::d_syn_order holds
-// the identity order and the utterances sorted by output length, Batch::d_run_list the runs in either order).
-// launch_analyze_synthesize() (context.cpp) prepares the whole batch as one part on a side stream while CheapTrick
-// and D4C occupy the main one.  launch_synthesis() -- Synthesis alone, BASELINE.json configs[4] -- has nothing to hide
-// the prepare stage behind but its own render stage, so it splits the batch: part A, the shortest utterances making
-// up a third of the output samples, is prepared on the caller's stream (its phase chain is as long as ITS longest
-// utterance); while A is rendered, the rest is prepared on a third stream.  y does not depend on the split.
+// Both work on a PART of the batch: a list of utterances (Batch::d_syn_order holds the batch's utterances sorted by
+// output length; the identity order when the batch is prepared as one part).  launch_analyze_synthesize()
+// (context.cpp) prepares the whole batch as one part on a side stream while CheapTrick and D4C occupy the main one.
+// launch_synthesis() -- Synthesis alone, BASELINE.json configs[4] -- has nothing to hide the prepare stage behind
+// but its own render stage, so it splits the batch: part A, the shortest utterances making up a sixth of the output
+// samples, is prepared on the caller's stream (its phase chain is as long as ITS longest utterance, a third of the
+// batch's); while A is rendered, the rest is prepared on a third stream.  An utterance's pulses keep their order and
+// every sample its order of additions, so y does not depend on the split (tests: against the one-part form, bit for bit).
 struct SynPart {
   const int* d_list;      // utterance numbers of the part (device)
-  const int* h_list;      // the same on the host
   int n;                  // how many
   int max_y_len;          // longest output among them
-  const int* d_run_list;  // the order of runs the part's range refers to
-  const int* d_run_pos;   // its inverse: position of a run in that order
-  int k_begin, k_end;     // the part's runs: positions [k_begin, k_end) of d_run_list
+  int64_t p_base;         // number of the part's first pulse
+  int64_t total_p = 0;    // its pulses (after the host round trip)
+  int max_np = 0;
 };
 
 static int synthesis_arena(Batch& b) {
   Context& c = *b.ctx;
   const int F = b.p.fft_size;
   if (b.d_pulse_idx) return WM_OK;
-  // the runs: utterance u owns ceil(ylen / kRunS) of them, numbered from run_off[u] on
-  const size_t ny = (size_t)b.total_y, nu = (size_t)b.n_utt;
-  {
-    const int64_t want = (int64_t)c.num_cu * 16 * 4;      // several runs per wavefront of a full machine
-    int S = 512;
-    while (S > kOlaStep && b.total_y / S < want) S /= 2;
-    if (const char* e = getenv("WORLD_MI355_SYN_RUN")) {
-      const int v = atoi(e);
-      if (v >= kOlaStep && v % kOlaStep == 0 && v <= 8192) S = v;
-    }
-    b.run_s = S;
-  }
-  const int kRunS = b.run_s;
-  b.run_off.assign(nu + 1, 0);
-  for (size_t u = 0; u < nu; ++u) b.run_off[u + 1] = b.run_off[u] + (b.y_len[u] + kRunS - 1) / kRunS;
-  const size_t nr = (size_t)b.run_off[nu];
   // one allocation for the work arrays of this batch (sections aligned to 256 bytes)
+  const size_t ny = (size_t)b.total_y, nu = (size_t)b.n_utt;
   const size_t tiles = (size_t)((b.max_y_len + kSearchTile - 1) / kSearchTile + 1);
   size_t at = 0;
   auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
   const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
-  const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_dcr = take(8 * (size_t)F);
+  const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
   const size_t o_first = take(4 * (ny / kOlaStep + 2 * nu + 4));
   const size_t o_order = take(4 * 2 * nu);
-  const size_t o_roff = take(4 * (nu + 1)), o_rutt = take(4 * nr), o_rlist = take(4 * 2 * nr), o_rpos = take(4 * 2 * nr);
-  const size_t o_rcnt = take(4 * nr), o_next = take(4 * 8);
   unsigned char* base = nullptr;
   int rc = wm_check(dev_alloc(&base, at));
   if (rc) return rc;
+  if (!c.h_pulse_info) {            // per context: two pinned, device-visible integers
+    rc = wm_check(hipHostMalloc((void**)&c.h_pulse_info, sizeof(int64_t) * 2, hipHostMallocMapped));
+    if (!rc) rc = wm_check(hipHostGetDevicePointer((void**)&c.d_pulse_info, c.h_pulse_info, 0));
+    if (rc) { dev_free(base); return rc; }
+  }
   b.d_syn_arena = base;
   b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
   b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
   b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
-  b.d_dc_remover = (double*)(base + o_dcr);
+  b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
   b.d_pulse_first = (int*)(base + o_first);
   b.d_syn_order = (int*)(base + o_order);
-  b.d_run_off = (int*)(base + o_roff); b.d_run_utt = (int*)(base + o_rutt);
-  b.d_run_list = (int*)(base + o_rlist); b.d_run_pos = (int*)(base + o_rpos);
-  b.d_run_cnt = (int*)(base + o_rcnt); b.d_run_next = (int*)(base + o_next);
   // [0, n): the identity; [n, 2 n): the utterances by output length, shortest first (stable)
   std::vector<int> order(2 * nu);
   for (size_t u = 0; u < nu; ++u) order[u] = order[nu + u] = (int)u;
   std::stable_sort(order.begin() + (long)nu, order.end(), [&](int x, int y) { return b.y_len[(size_t)x] < b.y_len[(size_t)y]; });
-  b.syn_order.assign(order.begin(), order.end());
-  // the runs in both orders, and where each run stands in either
-  std::vector<int> rutt(nr ? nr : 1), rlist(2 * nr + 1), rpos(2 * nr + 1);
-  b.run_first.assign(2 * nu + 1, 0);          // first position of an utterance's runs in either order
-  for (int half = 0; half < 2; ++half) {
-    size_t k = 0;
-    for (size_t i = 0; i < nu; ++i) {
-      const int u = order[half * nu + i];
-      b.run_first[half * nu + i] = (int)k;
-      for (int g = b.run_off[(size_t)u]; g < b.run_off[(size_t)u + 1]; ++g, ++k) {
-        rlist[half * nr + k] = g;
-        rpos[half * nr + (size_t)g] = (int)k;
-        rutt[(size_t)g] = u;
-      }
-    }
-  }
-  b.run_first[2 * nu] = (int)nr;
-  rc = wm_check(hipMemcpy(b.d_syn_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
-  rc = rc ? rc : wm_check(hipMemcpy(b.d_run_off, b.run_off.data(), sizeof(int) * (nu + 1), hipMemcpyHostToDevice));
-  if (nr) {
-    rc = rc ? rc : wm_check(hipMemcpy(b.d_run_utt, rutt.data(), sizeof(int) * nr, hipMemcpyHostToDevice));
-    rc = rc ? rc : wm_check(hipMemcpy(b.d_run_list, rlist.data(), sizeof(int) * 2 * nr, hipMemcpyHostToDevice));
-    rc = rc ? rc : wm_check(hipMemcpy(b.d_run_pos, rpos.data(), sizeof(int) * 2 * nr, hipMemcpyHostToDevice));
-  }
+  b.syn_sorted.assign(order.begin() + (long)nu, order.end());
+  rc = wm_check(hipMemcpyAsync(b.d_syn_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, c.stream));
+  rc = rc ? rc : wm_check(hipStreamSynchronize(c.stream));      // `order` is pageable and goes out of scope
   hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, c.stream, F, b.d_dc_remover);
   return rc;
 }
 
-// part = the utterances [i0, i1) of one of the two orders (half 0: the identity, 1: by output length)
-static SynPart synthesis_part(const Batch& b, int half, int i0, int i1) {
-  const size_t nu = (size_t)b.n_utt, nr = (size_t)b.run_off[nu];
-  SynPart p;
-  p.d_list = b.d_syn_order + half * nu + (size_t)i0;
-  p.h_list = b.syn_order.data() + half * nu + (size_t)i0;
-  p.n = i1 - i0;
-  p.max_y_len = 0;
-  for (int i = i0; i < i1; ++i) p.max_y_len = imax(p.max_y_len, b.y_len[(size_t)b.syn_order[half * nu + (size_t)i]]);
-  p.d_run_list = b.d_run_list + half * nr;
-  p.d_run_pos = b.d_run_pos + half * nr;
-  p.k_begin = b.run_first[half * nu + (size_t)i0];
-  p.k_end = i1 == (int)nu ? (int)nr : b.run_first[half * nu + (size_t)i1];
-  return p;
-}
-
-// The f0-only kernels of a part: asynchronous on the context's stream.
+// The f0-only kernels of a part, up to its pulse numbers: asynchronous on the context's stream.
 static int synthesis_prepare_launch(Batch& b, const SynPart& part, const double* d_f0) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
-  if (part.n == 0) return WM_OK;
   const int F = b.p.fft_size, fs = b.p.fs;
   const double fp = b.p.frame_period / 1000.0;
   const double lowest_f0 = fs / F + 1.0;                  // integer division as in synthesis.cpp:359
@@ -1077,110 +1013,189 @@ static int synthesis_prepare_launch(Batch& b, const SynPart& part, const double*
     hipLaunchKernelGGL(synth_pulse_search_kernel<true>, dim3(tiles_part, part.n), dim3(256), 0, st, part.d_list,
                        b.d_y_off, b.d_phase, fs, tiles_max, b.d_pulse_tile_cnt, b.d_pulse_idx, b.d_pulse_shift,
                        b.d_pulse_cnt);
-    // a pulse every other sample at most (a phase wrap needs two): the grid strides over whatever there is
-    hipLaunchKernelGGL(synth_first_kernel, dim3(imin(64, (part.max_y_len / 2 + 255) / 256), part.n), dim3(256), 0, st,
-                       part.d_list, b.d_y_off, (const int*)b.d_pulse_cnt, (const int*)b.d_pulse_idx, b.d_pulse_first);
+  }
+  // Pulse numbers stay on the device; the host needs two numbers only -- the part's total, which sizes the response
+  // scratch, and the largest count, which sizes a grid -- and reads them from pinned memory the kernel writes
+  // directly.  No hipMemcpy in either direction: a small copy queues on the same DMA engine as whatever bulk
+  // transfer another stream has in flight (a 1 GB feature download held this synchronisation, and with it the
+  // whole step, for 20 ms).
+  hipLaunchKernelGGL(synth_pulse_off_kernel, dim3(1), dim3(256), 0, st, part.d_list, (const int*)b.d_pulse_cnt, part.n,
+                     part.p_base, b.d_pulse_off, c.d_pulse_info);
+  return wm_check(hipGetLastError());
+}
+
+// After the host round trip: the part's totals are known.  `in_flight`: kernels of an earlier part may be using the
+// pulse records and the response scratch, which therefore must not move.
+static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more, bool in_flight) {
+  Context& c = *b.ctx;
+  hipStream_t st = c.stream;
+  const int F = b.p.fft_size;
+  part.total_p = c.h_pulse_info[0];
+  part.max_np = (int)c.h_pulse_info[1];
+  if (part.total_p == 0) return WM_OK;
+  // The responses of a piece of the pulse list wait in scratch memory for the overlap-add.  The scratch holds two
+  // pieces: while one is added into y on the second stream the pulse kernel fills the other (synthesis_render).
+  // A piece is half of the list when that fits, else what half of the scratch cap holds.  Measured (tools/syn_sweep.sh,
+  // ms per pass, configs[1] | configs[4]): 1 piece 14.64 | 20.86, 2 pieces 14.64 | 20.73, 4 pieces 14.81 | 20.75,
+  // 8 pieces 15.76 | 20.62 -- every launch of the pulse kernel has a tail, so a short list wants few pieces.
+  int64_t cap_mb = 4096;
+  if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
+  int64_t chunk = (cap_mb * 1024 * 1024 / 8) / F / 2;
+  if (chunk < 1) chunk = 1;
+  int pieces = 2;
+  if (const char* e = getenv("WORLD_MI355_SYN_PIECES")) pieces = atoi(e) > 0 ? atoi(e) : pieces;
+  const int64_t list = part.total_p > expect_more ? part.total_p : expect_more;     // the longest list still to come
+  const int64_t share = (list + pieces - 1) / pieces;
+  if (share >= 16384 && chunk > share) chunk = share;       // short lists: one piece, nothing to overlap
+  if (chunk > list) chunk = list;
+  int rc = c.ensure_side();
+  if (rc) return rc;
+  if (in_flight) {
+    // what is there stays: this part is cut into pieces of the size the scratch was laid out for
+    chunk = b.syn_chunk > 0 ? b.syn_chunk : chunk;
+  } else {
+    rc = c.ensure_scratch((chunk < list ? 2 : 1) * chunk * F);
+    if (rc) return rc;
+    b.syn_chunk = chunk;
+  }
+  const int64_t need = part.p_base + part.total_p + (in_flight ? 0 : expect_more);
+  if (need > b.pulse_rec_cap) {
+    if (in_flight) {
+      // the earlier part's kernels read the records: let them finish (they no longer need theirs afterwards)
+      rc = wm_check(hipDeviceSynchronize());
+      if (rc) return rc;
+    }
+    if (b.d_pulse_rec) dev_free(b.d_pulse_rec);
+    b.d_pulse_rec = nullptr;
+    b.pulse_rec_cap = 0;
+    if (b.d_pulse_perm) dev_free(b.d_pulse_perm);
+    b.d_pulse_perm = nullptr;
+    const int64_t cap = need + need / 8 + 64;
+    rc = wm_check(dev_alloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
+    if (rc) return rc;
+    rc = wm_check(dev_alloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
+    if (rc) return rc;
+    b.pulse_rec_cap = cap;
+  }
+  hipLaunchKernelGGL(synth_pulse_rec_kernel, dim3(imin(64, (part.max_np + 255) / 256), part.n), dim3(256), 0, st,
+                     part.d_list, b.d_f_off, b.d_y_off, b.d_pulse_off, (const int*)b.d_pulse_cnt, b.d_pulse_idx,
+                     b.d_pulse_shift, b.d_vuv, (PulseRec*)b.d_pulse_rec, b.d_pulse_first);
+  // The voiced-first order of every piece of the list, here rather than in front of each pulse kernel: two short
+  // dependent launches per piece that sat between D4C and the first pulse kernel and between the pieces.  A piece's
+  // order lives at its own place of the array (perm + p0); the block counts are scratch of one launch pair.
+  const int64_t piece = b.syn_chunk, p_end = part.p_base + part.total_p;
+  for (int64_t p0 = part.p_base; p0 < p_end; p0 += piece) {
+    const int64_t np = p_end - p0 < piece ? p_end - p0 : piece;
+    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
+                     b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm + p0, b.d_pulse_perm + b.pulse_rec_cap);
   }
   return wm_check(hipGetLastError());
 }
 
-// The runs of a part: strips by the run kernel, y by the combine kernel, both on the context's stream.  The strips of
-// a part that would not fit the scratch cap (WORLD_MI355_SCRATCH_MB, default 4 GiB: 350 k runs, 50 hours of 16 kHz
-// audio per GB ...) are done in groups of whole utterances, one after the other.
-static int synthesis_render_part(Batch& b, const SynPart& part, int half, int i0, const double* d_sp, const double* d_ap,
-                                 double* d_y) {
+// The pulses [part.p_base, part.p_base + part.total_p): responses by the pulse kernel on the caller's stream, added
+// into y on the second stream.  `piece` counts the pieces of the whole call (the halves of the scratch alternate
+// across parts).
+static int synthesis_render_part(Batch& b, const SynPart& part, const double* d_sp, const double* d_ap, double* d_y,
+                                 int& piece) {
   Context& c = *b.ctx;
   hipStream_t st = c.stream;
-  if (part.n == 0 || part.k_end <= part.k_begin) return WM_OK;
   const int F = b.p.fft_size, fs = b.p.fs;
   const double fp = b.p.frame_period / 1000.0;
-  const int kRunS = b.run_s;
-  const int64_t stride = kRunS + F;
-  int64_t cap_mb = 4096;
-  if (const char* e = getenv("WORLD_MI355_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
-  const int64_t cap_fit = cap_mb * 1024 * 1024 / 8 / stride;
-  const int64_t cap_runs = cap_fit > 1 ? cap_fit : 1;
-  const size_t nu = (size_t)b.n_utt;
-  int per_cu = 0;
+  const int64_t chunk = b.syn_chunk;
+  const int ola_tiles = (part.max_y_len + kOlaSeg * kOlaWaves - 1) / (kOlaSeg * kOlaWaves);
+  // Piece k: pulse kernel on the caller's stream into half k & 1 of the scratch, overlap-add on the second stream.
+  // The overlap-adds run in list order on one stream, so every sample is summed in the order of one piece per launch
+  // whatever the timing; the pulse kernel of piece k + 2 waits for the overlap-add of piece k to release its half.
   int rc = WM_OK;
-#define WM_SY_OCC(FF) case FF: per_cu = persistent_grid(c, synth_run_kernel<FF>, 64, (int64_t)1 << 40) / imax(1, c.num_cu * c.oversub); break;
-  switch (F) { WM_SY_OCC(512) WM_SY_OCC(1024) WM_SY_OCC(2048) WM_SY_OCC(4096) }
-#undef WM_SY_OCC
-  const int waves = imax(1, c.num_cu * imax(1, per_cu));
-  // groups of whole utterances whose runs fit the cap (one utterance alone may exceed it: it is then a group)
-  int i = 0;
-  while (i < part.n && !rc) {
-    const int first_k = b.run_first[half * nu + (size_t)(i0 + i)];
-    int j = i;
-    int last_k = first_k;
-    while (j < part.n) {
-      const int next_k = (i0 + j + 1 == (int)nu) ? b.run_off[nu] : b.run_first[half * nu + (size_t)(i0 + j + 1)];
-      if (j > i && next_k - first_k > cap_runs) break;
-      last_k = next_k;
-      ++j;
-    }
-    const int n_runs = last_k - first_k;
-    int max_y = 0;
-    for (int q = i; q < j; ++q) max_y = imax(max_y, b.y_len[(size_t)part.h_list[q]]);
-    if (n_runs > 0) {
-      const int grid = imin(waves, n_runs);
-      rc = c.ensure_scratch((int64_t)n_runs * stride + (int64_t)waves * F);
-      if (rc) break;
-      double* strips = c.d_scratch;
-      double* park = c.d_scratch + (int64_t)n_runs * stride;
-      rc = wm_check(hipMemsetAsync(b.d_run_next, 0, sizeof(int), st));
-      if (rc) break;
-#define WM_SY_CASE(FF)                                                                                            \
-  case FF:                                                                                                        \
-    hipLaunchKernelGGL(synth_run_kernel<FF>, dim3(grid), dim3(64), 0, st, d_sp, d_ap, part.d_run_list, first_k,   \
-                       last_k, b.d_run_next, (const int*)b.d_run_utt, (const int*)b.d_run_off, b.d_f_off,         \
-                       b.d_y_off, (const int*)b.d_pulse_cnt, (const int*)b.d_pulse_idx,                           \
-                       (const double*)b.d_pulse_shift, (const double*)b.d_vuv, (const int*)b.d_pulse_first,       \
-                       (const double*)b.d_dc_remover, c.d_rng, fs, fp, kRunS, park, strips, b.d_run_cnt);         \
-    break;
-      {
-        TimedScope ts_(b.ctx, "synth_pulse_kernel");
-        switch (F) {
-          WM_SY_CASE(512)
-          WM_SY_CASE(1024)
-          WM_SY_CASE(2048)
-          WM_SY_CASE(4096)
-        }
+  const int64_t lo = part.p_base, hi = part.p_base + part.total_p;
+  for (int64_t p0 = lo; p0 < hi && !rc; p0 += chunk, ++piece) {
+    const int64_t p1 = p0 + chunk < hi ? p0 + chunk : hi;
+    const int64_t np = p1 - p0;
+    const int h = piece & 1;
+    double* resp = c.d_scratch + (int64_t)h * chunk * F;
+    const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
+    if (piece >= 2) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[h], 0));
+    if (rc) break;
+#define WM_SY_CASE(FF)                                                                                          \
+  case FF: {                                                                                                    \
+    const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
+    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
+                       (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
+                       (const int*)b.d_pulse_perm + p0, resp);                                                  \
+  } break;
+    {
+      TimedScope ts_(b.ctx, "synth_pulse_kernel");
+      switch (F) {
+        WM_SY_CASE(512)
+        WM_SY_CASE(1024)
+        WM_SY_CASE(2048)
+        WM_SY_CASE(4096)
       }
+    }
 #undef WM_SY_CASE
-      {
-        TimedScope ts_(b.ctx, "synth_ola_kernel");
-        hipLaunchKernelGGL(synth_combine_kernel, dim3(imin(256, (max_y + 255) / 256), j - i), dim3(256), 0, st,
-                           part.d_list + i, b.d_y_off, (const int*)b.d_run_off, part.d_run_pos, first_k,
-                           (const int*)b.d_run_cnt, F, kRunS, (const double*)strips, d_y);
-      }
-      rc = wm_check(hipGetLastError());
+    static const bool overlap = !(getenv("WORLD_MI355_SYN_OVERLAP") && atoi(getenv("WORLD_MI355_SYN_OVERLAP")) == 0);
+    hipStream_t so = overlap ? c.side : st;
+    rc = wm_check(hipEventRecord(c.ev_pulse[h], st));
+    rc = rc ? rc : wm_check(hipStreamWaitEvent(so, c.ev_pulse[h], 0));
+    if (rc) break;
+    {
+      c.stream = so;                                       // the timing bracket records on the context's stream
+      TimedScope ts2_(b.ctx, "synth_ola_kernel");
+      hipLaunchKernelGGL(synth_ola_kernel, dim3(ola_tiles, part.n), dim3(64 * kOlaWaves), 0, so, part.d_list, b.d_y_off,
+                         b.d_pulse_off, (const int*)b.d_pulse_cnt, b.d_pulse_idx, (const int*)b.d_pulse_first, F, p0,
+                         p1, resp, d_y);
     }
-    i = j;
+    c.stream = st;
+    rc = wm_check(hipEventRecord(c.ev_ola[h], so));
   }
-  return rc;
+  c.stream = st;
+  return rc ? rc : wm_check(hipGetLastError());
 }
 
-static int synthesis_check(Batch& b) {
-  const int F = b.p.fft_size;
-  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
-  int rc = b.ctx->ensure_rng(b.rng_bound_synthesis());
-  return rc ? rc : synthesis_arena(b);
+// y is complete, and both halves of the scratch are free again, when the last overlap-add is: everything after the
+// call on the caller's stream is ordered behind it
+static int synthesis_join(Batch& b, int pieces) {
+  Context& c = *b.ctx;
+  if (pieces == 0) return WM_OK;
+  return wm_check(hipStreamWaitEvent(c.stream, c.ev_ola[(pieces - 1) & 1], 0));
 }
 
 // ---- the whole batch as one part (launch_analyze_synthesize: prepare on a side stream, render on the main one) ----
-// synthesis_begin() queues the f0-only kernels and returns.  The drop-in Synthesis() gathers the caller's `double**`
-// rows of sp / ap into pinned memory behind it, i.e. while the phase chain of the utterance runs (capi.cpp).
+// synthesis_begin() queues the f0-only kernels and returns; synthesis_prepare_wait() is the host round trip behind
+// them.  Between the two the host is free: the drop-in Synthesis() gathers the caller's `double**` rows of sp / ap
+// into pinned memory there, i.e. while the phase chain of the utterance runs (capi.cpp).
 int synthesis_begin(Batch& b, const double* d_f0, double* d_y) {
-  (void)d_y;                                                        // every sample is written by the combine kernel
-  int rc = synthesis_check(b);
+  Context& c = *b.ctx;
+  const int F = b.p.fft_size;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
+  int rc = c.ensure_rng(b.rng_bound_synthesis());
+  rc = rc ? rc : synthesis_arena(b);
+  rc = rc ? rc : wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, c.stream));
   if (rc) return rc;
-  return synthesis_prepare_launch(b, synthesis_part(b, 0, 0, b.n_utt), d_f0);
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  return synthesis_prepare_launch(b, part, d_f0);
 }
-int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) { return synthesis_begin(b, d_f0, d_y); }
+int synthesis_prepare_wait(Batch& b) {
+  Context& c = *b.ctx;
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  int rc = wm_check(hipStreamSynchronize(c.stream));            // the one host round trip of the path
+  b.syn_chunk = 0;
+  rc = rc ? rc : synthesis_prepare_finish(b, part, 0, false);
+  b.syn_total_p = part.total_p;
+  return rc;
+}
+int synthesis_prepare(Batch& b, const double* d_f0, double* d_y) {
+  int rc = synthesis_begin(b, d_f0, d_y);
+  return rc ? rc : synthesis_prepare_wait(b);
+}
 
 int synthesis_render(Batch& b, const double* d_sp, const double* d_ap, double* d_y) {
-  return synthesis_render_part(b, synthesis_part(b, 0, 0, b.n_utt), 0, 0, d_sp, d_ap, d_y);
+  if (b.syn_total_p == 0) return WM_OK;
+  SynPart part{b.d_syn_order, b.n_utt, b.max_y_len, 0};
+  part.total_p = b.syn_total_p;
+  int piece = 0;
+  int rc = synthesis_render_part(b, part, d_sp, d_ap, d_y, piece);
+  return rc ? rc : synthesis_join(b, piece);
 }
 
 // ---- Synthesis alone: the batch in two parts (see the top of this section) ----
@@ -1192,11 +1207,14 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
     int rc = synthesis_prepare(b, d_f0, d_y);
     return rc ? rc : synthesis_render(b, d_sp, d_ap, d_y);
   }
-  int rc = synthesis_check(b);
+  const int F = b.p.fft_size;
+  if (F != 512 && F != 1024 && F != 2048 && F != 4096) return WM_ERR_UNSUPPORTED_FFT;
+  int rc = c.ensure_rng(b.rng_bound_synthesis());
+  rc = rc ? rc : synthesis_arena(b);
   rc = rc ? rc : c.ensure_side();
   if (!rc && !c.prep) {
     // the highest priority there is: its workgroups are few and latency-bound, and they only get the slots the
-    // run kernel's workgroups leave as they retire
+    // pulse kernel's workgroups leave as they retire
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     rc = wm_check(hipStreamCreateWithPriority(&c.prep, hipStreamNonBlocking, prio_hi));
@@ -1205,24 +1223,41 @@ int launch_synthesis(Batch& b, const double* d_f0, const double* d_sp, const dou
   }
   if (rc) return rc;
   hipStream_t st = c.stream;
-  // part A: the shortest utterances up to a third of the output samples
-  const size_t nu = (size_t)b.n_utt;
+  // part A: the shortest utterances up to a sixth of the output samples
   int n_a = 0;
   int64_t acc = 0;
   const int denom = split_env >= 2 ? split_env : 3;
-  while (n_a < b.n_utt - 1 && acc < b.total_y / denom) acc += b.y_len[(size_t)b.syn_order[nu + (size_t)n_a++]];
-  const SynPart pa = synthesis_part(b, 1, 0, n_a), pb = synthesis_part(b, 1, n_a, b.n_utt);
-  rc = wm_check(hipEventRecord(c.ev_call, st));                    // the caller's f0 is ready from here on
+  while (n_a < b.n_utt - 1 && acc < b.total_y / denom) acc += b.y_len[(size_t)b.syn_sorted[(size_t)n_a++]];
+  const int* sorted = b.d_syn_order + b.n_utt;
+  SynPart pa{sorted, n_a, b.y_len[(size_t)b.syn_sorted[(size_t)n_a - 1]], 0};
+  SynPart pb{sorted + n_a, b.n_utt - n_a, b.max_y_len, 0};
+  rc = wm_check(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)b.total_y, st));
+  rc = rc ? rc : wm_check(hipEventRecord(c.ev_call, st));          // the caller's f0 is ready from here on
   rc = rc ? rc : synthesis_prepare_launch(b, pa, d_f0);
+  rc = rc ? rc : wm_check(hipStreamSynchronize(st));               // host round trip of part A
+  if (rc) return rc;
+  b.syn_chunk = 0;
+  const int64_t guess_b = (int64_t)((double)c.h_pulse_info[0] * (double)(b.total_y - acc) / (double)(acc > 0 ? acc : 1) * 1.25) + 1024;
+  rc = synthesis_prepare_finish(b, pa, guess_b, false);
+  if (rc) return rc;
   // part B's f0-only kernels on the third stream, beside part A's render stage
-  rc = rc ? rc : wm_check(hipStreamWaitEvent(c.prep, c.ev_call, 0));
+  pb.p_base = pa.total_p;
+  rc = wm_check(hipStreamWaitEvent(c.prep, c.ev_call, 0));
   c.stream = c.prep;
   rc = rc ? rc : synthesis_prepare_launch(b, pb, d_f0);
+  c.stream = st;
+  int piece = 0;
+  if (!rc && pa.total_p > 0) rc = synthesis_render_part(b, pa, d_sp, d_ap, d_y, piece);
+  rc = rc ? rc : wm_check(hipStreamSynchronize(c.prep));           // host round trip of part B (A's render is queued)
+  if (rc) return rc;
+  c.stream = c.prep;
+  rc = synthesis_prepare_finish(b, pb, 0, pa.total_p > 0);
   rc = rc ? rc : wm_check(hipEventRecord(c.ev_prep_b, c.prep));
   c.stream = st;
-  rc = rc ? rc : synthesis_render_part(b, pa, 1, 0, d_sp, d_ap, d_y);
   rc = rc ? rc : wm_check(hipStreamWaitEvent(st, c.ev_prep_b, 0));
-  return rc ? rc : synthesis_render_part(b, pb, 1, n_a, d_sp, d_ap, d_y);
+  if (!rc && pb.total_p > 0) rc = synthesis_render_part(b, pb, d_sp, d_ap, d_y, piece);
+  b.syn_total_p = pa.total_p + pb.total_p;
+  return rc ? rc : synthesis_join(b, piece);
 }
 
 #ifdef WM_PHASE

@@ -15,9 +15,7 @@ W, sd = pkg.world, pkg.synth_data
 NAMES = {0: ["pipe", "centroids", "centroid dc", "hann frame", "power fft", "dc + smooth", "group delay", "band window",
              "band fft", "sort/peel/log", "row"],
          1: ["pipe", "frame", "power fft", "dc", "smooth", "noise + log", "fft 2", "lifter", "fft 3", "exp + row"],
-         2: ["run: strip + pulse record", "spectra + two logs", "min phase pair", "periodic amplitude + sincos", "time shift",
-             "periodic c2r + dc", "aperiodic spectrum (unvoiced: whole min phase)", "noise frame + r2c", "product",
-             "c2r + response", "run: queue", "strip"]}
+         2: ["pipe", "spectra", "min phase 1", "mid", "min phase 2", "noise", "response"]}
 unit = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 fs = 16000
 xs = sd.make_batch(64, fs, (2.0, 8.0), workers=8)

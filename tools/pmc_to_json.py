@@ -4,8 +4,7 @@ of the kernel's sources (bench.py prints `roofline.traffic` only while that hash
 
     python tools/pmc_to_json.py FETCH_DIR WRITE_DIR FRAMES FS TAG [WORKLOAD]
 
-WORKLOAD: analysis_synthesis (default; d4c_kernel), harvest (hv_band_fft_kernel), synthesis (synth_run_kernel, which
-bench.py times under the name synth_pulse_kernel).
+WORKLOAD: analysis_synthesis (default; d4c_kernel), harvest (hv_band_fft_kernel), synthesis (synth_pulse_kernel).
 The readings are stored as reported; bench.py applies the factors of profiles/hbm_counter_calibration.json.
 """
 import csv
@@ -33,7 +32,7 @@ def counts_as_launch(name):
 
 MATCH = {"analysis_synthesis": is_usual_d4c,
          "harvest": lambda n: "hv_band_fft_kernel" in n,
-         "synthesis": lambda n: "synth_run_kernel" in n}
+         "synthesis": lambda n: "synth_pulse_kernel" in n}
 
 
 # a kernel that runs exactly once per pass of the workload: its launches count the passes of a profiled run, so that a
