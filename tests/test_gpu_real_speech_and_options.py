@@ -258,3 +258,52 @@ def test_real_speech_front_end_options(gpu, oracle, name):
         same_voicing(f0.cpu().numpy(), fo)
         np.testing.assert_allclose(f0.cpu().numpy(), fo, atol=F0_TOL, rtol=0)
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,thr", [(16000, 0.0), (16000, 0.85), (48000, 0.85)])
+def test_one_call_forms_with_frames_outside_the_usual_range(gpu, oracle, fs, thr):
+    """WorldMi355Analyze / AnalyzeSynthesize run D4C's preparation on a second stream beside CheapTrick and the launch
+    for frames outside the usual range (f0 >= fs / 16, windows past half the D4C transform) on a third, from the
+    second call on a batch on (the first allocates in the plain order).  With Dio's range opened (40 Hz .. 0.3 fs) a
+    batch of a whistle, a growl and ordinary speech has such frames: every call gives the bits of the first, the
+    one-call forms those of the stage-by-stage calls, and the rows are the oracle's."""
+    import importlib
+    torch, W, ctx = gpu
+    sd = importlib.import_module("hts-train-world_amd.synth_data")
+    rng = np.random.default_rng(17)
+    n = int(0.5 * fs)
+    tt = np.arange(n) / fs
+    whistle = sum(np.sin(2 * np.pi * (fs / 14.0) * h * tt + h) / h for h in (1, 2, 3)) * 0.2   # between fs / 16 and StoneMask's fs / 12
+    growl = sum(np.sin(2 * np.pi * 45.0 * h * tt + 0.3 * h) / h for h in range(1, 40)) * 0.1
+    xs = [np.round((whistle + 1e-3 * rng.standard_normal(n)) * 32768.0) / 32768.0,
+          np.round((growl + 1e-3 * rng.standard_normal(n)) * 32768.0) / 32768.0,
+          sd.make_utterance(91, fs, duration=0.6)]
+    opt = dict(f0_floor=40.0, f0_ceil=0.3 * fs, d4c_threshold=thr)      # fft 2048 at 16 kHz, 4096 at 48 kHz
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, **opt), x_lengths=[len(x) for x in xs])
+    xc = torch.from_numpy(np.concatenate(xs)).cuda()
+    first = [a.clone() for a in b.analyze(xc)]
+    f0 = first[1].cpu().numpy()
+    fo = np.asarray(b.frame_offsets)
+    F = int(b.fft_size)                                    # follows the lowered f0_floor (cheaptrick.cpp:191-194)
+    fd = 2 ** (1 + int(np.log2(4.0 * fs / 47.0 + 1.0)))
+    rare = (f0 >= fs / 16.0) | ((f0 > 0) & (2 * np.round(2.0 * fs / np.maximum(f0, 47.0)) + 1 > fd // 2) & (fd < 4096))
+    assert rare[fo[0]:fo[1]].any(), "the whistle has no frame beyond fs / 16"
+    for _ in range(2):                                     # the streamed order from here on
+        again = b.analyze(xc)
+        for a, c in zip(first, again):
+            assert torch.equal(a, c)
+    staged_sp = b.cheaptrick(xc, first[0], first[1])
+    staged_ap = b.d4c(xc, first[0], first[1])
+    assert torch.equal(staged_sp, first[2]) and torch.equal(staged_ap, first[3])
+    y = b.synthesize(first[1], first[2], first[3]).clone()
+    for _ in range(2):
+        t2, f02, sp2, ap2, y2 = b.analyze_synthesize(xc)
+        assert torch.equal(f02, first[1]) and torch.equal(sp2, first[2]) and torch.equal(ap2, first[3])
+        assert torch.equal(y2, y)
+    ap = first[3].cpu().numpy()
+    for u, x in enumerate(xs):
+        s = slice(fo[u], fo[u + 1])
+        want = oracle.d4c(x, fs, first[0].cpu().numpy()[s], f0[s], F, thr)
+        np.testing.assert_allclose(ap[s], want, atol=AP_TOL, rtol=0)
+    b.close()
