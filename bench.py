@@ -514,13 +514,19 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
         torch.cuda.empty_cache()
         cpu = not args.no_cpu_baseline
         sides = {}
-        sides["harvest"] = compact(harvest_bench(env, ctx, side_data["harvest"], 48000, 1.0, 5, 2, 2.0, cpu=cpu))
-        sides["synthesis"] = compact(synthesis_bench(env, ctx, xs, feats, fs, fp, 5, 2, 2.0, cpu=cpu))
-        del feats
-        torch.cuda.empty_cache()
         corpus = side_data["corpus"]
         counts = [len(v) for v in corpus]
-        sides["sweep"] = compact(sweep_bench(env, ctx, counts, dict(enumerate(corpus)), fs, fp, 3, 1, cpu=cpu))
+        for w in "hsw":
+            if w == "h":
+                sides["harvest"] = compact(harvest_bench(env, ctx, side_data["harvest"], 48000, 1.0, 5, 2, 2.0, cpu=cpu))
+            elif w == "s":
+                sides["synthesis"] = compact(synthesis_bench(env, ctx, xs, feats, fs, fp, 5, 2, 2.0, cpu=cpu))
+            elif w == "w":
+                # two warm-up passes, as `--workload sweep` takes: the second pass over a batch is the first in the
+                # streamed order (D4C's preparation beside CheapTrick)
+                sides["sweep"] = compact(sweep_bench(env, ctx, counts, dict(enumerate(corpus)), fs, fp, 3, 2, cpu=cpu))
+            torch.cuda.empty_cache()
+        del feats
         line["side_workloads"] = sides
     else:
         batch.close()
@@ -706,10 +712,14 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
     t0 = time.perf_counter()
     for _ in range(steps):
         ph = sw.run(sink, io_threads)
+        if os.environ.get("WM_BENCH_PHASES"):
+            print("  pass: %s" % {k: round(v * 1e3, 2) for k, v in ph.items() if isinstance(v, float)}, file=sys.stderr)
         for k in phases:
             phases[k] += ph.get(k, 0.0)
     env.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("WM_BENCH_PHASES"):
+        print("sweep phases (s over %d steps): %s elapsed %.4f" % (steps, {k: round(v, 4) for k, v in phases.items()}, elapsed), file=sys.stderr)
     kernel_ms = {k: ctx.timing_query(k) for k in ANALYSIS_KERNELS}
     ctx.timing_enable(False)
     elapsed_max, _ = env.reduce(elapsed, sw.my_frames)
