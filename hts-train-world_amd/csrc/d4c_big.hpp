@@ -304,12 +304,13 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_centroid_kernel(
 // Power spectrum |X[k]|^2, k = 0 .. FD / 2, of a real frame of FD samples given as packed pairs in two halves:
 // va[m] = (x[2 n], x[2 n + 1]), vb[m] the same NS pairs later (n = lane + 64 m < NS); `folded` says whether vb holds
 // anything (wave-uniform).  pe[m] = power at bin 2 (lane + 64 m), pe[MS] = power at bin FD / 2 (every lane),
-// po[m] = power at bin 2 (lane + 64 m) + 1.  The operand of the odd bins waits in registers while the even bins are
+// po[m] = power at bin 2 (lane + 64 m) + 1.  nz: only va[0 .. nz) may be non-zero (the window's reach; MS when folded):
+// both transforms take the pruned first pass (fft.hpp).  The operand of the odd bins waits in registers while the even bins are
 // transformed (64 registers; parking it in memory cost 32 KB of traffic per call and a trip there and back).
 // va / vb are consumed.
 template <int FD>
 __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx (&vb)[D4cBig<FD>::MS], bool folded,
-                                                  cpx* img, const FftTw<D4cBig<FD>::NS>& tw, int lane,
+                                                  int nz, cpx* img, const FftTw<D4cBig<FD>::NS>& tw, int lane,
                                                   double (&pe)[D4cBig<FD>::MS + 1], double (&po)[D4cBig<FD>::MS]) {
   constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS;
   // the packed sequence vp of 2 NS points splits into even bins FFT_NS(va + vb) and odd bins
@@ -326,7 +327,7 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
     }
   }
   // even bins: the real transform of 2 NS points as it is
-  rfft_forward<NS>(va, img, img, tw, lane);
+  rfft_forward_nz<NS>(va, img, img, tw, lane, nz);
 #pragma unroll
   for (int m = 0; m < MS; ++m) {
     const cpx s = img[lane + 64 * m];
@@ -337,7 +338,7 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
     pe[MS] = s.x * s.x + s.y * s.y;
   }
   // odd bins: X[2 j + 1] from O[j] and O[NS - 1 - j] with the twiddle W_FD^(2 j + 1)
-  fft_forward<NS>(odd, img, tw, lane);
+  fft_forward_nz<NS>(odd, img, tw, lane, nz);
   store_all<NS>(odd, img, lane);
   {
     const cpx w1 = cis_neg2pi(1.0 / (double)FD);                  // W_FD
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
         for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
       }
       double pe[MS + 1], po[MS];
-      real_power_halves<FD>(va, vb, fg.L > 2 * NS, img, tw, lane, pe, po);
+      real_power_halves<FD>(va, vb, fg.L > 2 * NS, fg.L > 2 * NS ? MS : (fg.L + 127) >> 7, img, tw, lane, pe, po);
       cpx* arr2 = reinterpret_cast<cpx*>(arr);
 #pragma unroll
       for (int m = 0; m < MS; ++m) arr2[lane + 64 * m] = make_double2(pe[m], po[m]);   // bins 2 j, 2 j + 1
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_band_kernel(const 
     cpx none[MS];
 #pragma unroll
     for (int m = 0; m < MS; ++m) none[m] = make_double2(0.0, 0.0);
-    real_power_halves<FD>(vp, none, false, img, tw, lane, pe, po);   // the window never folds
+    real_power_halves<FD>(vp, none, false, (wl + 127) >> 7, img, tw, lane, pe, po);   // the window never folds
     // through LDS into strided order (p[t] = bin lane + 64 t): the main lobe the peel removes is a run of
     // neighbouring bins, which then sit in different lanes and go in one or two steps of peel_largest()
     double p[NP];
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(64, FL > 4096 ? 1 : 2) void d4cb_lovetrain_kernel(
       for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
     }
     double pe[MS + 1], po[MS];
-    real_power_halves<FL>(va, vb, fg.L > 2 * NS, img, tw, lane, pe, po);
+    real_power_halves<FL>(va, vb, fg.L > 2 * NS, fg.L > 2 * NS ? MS : (fg.L + 127) >> 7, img, tw, lane, pe, po);
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
