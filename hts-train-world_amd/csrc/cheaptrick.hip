@@ -73,6 +73,10 @@ struct CtUsualPred {
   __device__ bool operator()(int i) const { return 2 + (int)(ct_frame_f0(f0[i], fs, F) * F / fs) <= F / 8; }
 };
 
+// Three waves per SIMD at fft <= 1024, and no more: the kernel would fit four (125 registers), but in the one-call forms
+// the f0-only kernels of Synthesis and D4C's preparation run beside it on other streams, in the registers a fourth wave
+// would take -- with four they waited for CheapTrick to end and ran beside `d4c_kernel` instead (+0.3 ms there).
+// (A clobbered v135 makes the allocation 136 registers; amdgpu_waves_per_eu(3, 3) does not raise it on gfx950.)
 template <int F, bool WIDE>
 __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     const int* __restrict__ rng_off, const uint32_t* __restrict__ rtab, int fs_arg, double q1,
     int64_t total_frames, const int* __restrict__ perm, const int* __restrict__ n_usual,
     double* __restrict__ sp) {
+  if constexpr (F <= 1024) asm volatile("; three waves per SIMD: see above" ::: "v135");
   constexpr int N = F / 2, M = N / 64, H = F / 2;
   constexpr int kBM = CtMargin<F, WIDE>::kBM;
   constexpr int kImg = 2 * FftLds<N>::kElems;                 // doubles
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
 
     // ---- GetWindowedWaveform (cheaptrick.cpp:87-142), straight into the FFT operand ----
     const FrameGeom fg = frame_geom(fs, cf0, uniform_d(tpos[frame]), 3.0);
-    frame_packed<kHann, true, M>(x + x_off[u], x_len[u], fg, rtab, roff, lane, v);
+    frame_packed<kHann, true, M, (F <= 1024)>(x + x_off[u], x_len[u], fg, rtab, roff, lane, v);
     WM_PHASE_MARK(1)
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----

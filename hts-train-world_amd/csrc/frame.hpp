@@ -185,7 +185,7 @@ __device__ __forceinline__ double frame_strided_to_memory(const double* __restri
 // by the reciprocal of sqrt(sum w^2).
 // The window values are not kept between the passes (they would double the registers of the frame): each pass
 // regenerates them by rotation from the two saved bases.  Loads are issued in groups of 8 pairs.
-template <int TYPE, bool NORMALISE, int M>
+template <int TYPE, bool NORMALISE, int M, bool KEEP_W = false>
 __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int xl, const FrameGeom& fg,
                                              const uint32_t* __restrict__ rtab, int roff, int lane,
                                              cpx (&v)[M]) {
@@ -195,6 +195,13 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
   CosGen ge0, go0;
   ge0.init(fg.a, 2 * lane - fg.hw, 128);
   go0.init(fg.a, 2 * lane + 1 - fg.hw, 128);
+  // KEEP_W: the window values of the first pass stay in registers for the later ones (2 M doubles; CheapTrick at fft
+  // 1024 has them to spare at three waves per SIMD) instead of being regenerated by rotation in every pass
+  double kw0[KEEP_W ? M : 1], kw1[KEEP_W ? M : 1];
+  if (KEEP_W) {
+#pragma unroll
+    for (int m = 0; m < (KEEP_W ? M : 1); ++m) kw0[m] = kw1[m] = 0.0;
+  }
   double inv_scale = 1.0;
   if (NORMALISE) {
     CosGen he = ge0, ho = go0;
@@ -204,13 +211,25 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
       if (WM_FRAME_BRANCH(128 * m < L)) {
         const double w0 = 128 * m + 2 * lane < L ? window_value<TYPE>(he.c) : 0.0;
         const double w1 = 128 * m + 2 * lane + 1 < L ? window_value<TYPE>(ho.c) : 0.0;
+        if (KEEP_W) {
+          kw0[KEEP_W ? m : 0] = w0;
+          kw1[KEEP_W ? m : 0] = w1;
+        }
         e += w0 * w0 + w1 * w1;
         he.next();
         ho.next();
       }
     }
     inv_scale = 1.0 / sqrt(wave_sum(e));
+    if (KEEP_W) {
+#pragma unroll
+      for (int m = 0; m < (KEEP_W ? M : 1); ++m) {
+        kw0[m] *= inv_scale;
+        kw1[m] *= inv_scale;
+      }
+    }
   }
+  constexpr bool HAVE_W = KEEP_W && NORMALISE;        // the first pass that makes window values is the energy pass
   CosGen ge = ge0, go = go0;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -232,16 +251,26 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
       v[m] = make_double2(0.0, 0.0);
       if (WM_FRAME_BRANCH(128 * m < L)) {
         const bool in0 = 128 * m + 2 * lane < L, in1 = 128 * m + 2 * lane + 1 < L;
-        const double w0 = NORMALISE ? window_value<TYPE>(ge.c) * inv_scale : window_value<TYPE>(ge.c);
-        const double w1 = NORMALISE ? window_value<TYPE>(go.c) * inv_scale : window_value<TYPE>(go.c);
+        double w0, w1;
+        if (HAVE_W) {                                  // zero beyond the window already
+          w0 = kw0[KEEP_W ? m : 0];
+          w1 = kw1[KEEP_W ? m : 0];
+        } else {
+          w0 = NORMALISE ? window_value<TYPE>(ge.c) * inv_scale : window_value<TYPE>(ge.c);
+          w1 = NORMALISE ? window_value<TYPE>(go.c) * inv_scale : window_value<TYPE>(go.c);
+          ge.next();
+          go.next();
+        }
         const double v0 = xa[r] * w0 + ((double)ra[r] / 268435456.0 - 6.0) * kSafe;
         const double v1 = xb[r] * w1 + ((double)rb[r] / 268435456.0 - 6.0) * kSafe;
         v[m].x = in0 ? v0 : 0.0;
         v[m].y = in1 ? v1 : 0.0;
         s1 += v[m].x + v[m].y;
         s2 += (in0 ? w0 : 0.0) + (in1 ? w1 : 0.0);
-        ge.next();
-        go.next();
+        if (KEEP_W && !HAVE_W) {
+          kw0[KEEP_W ? m : 0] = in0 ? w0 : 0.0;
+          kw1[KEEP_W ? m : 0] = in1 ? w1 : 0.0;
+        }
       }
     }
   }
@@ -251,12 +280,17 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (WM_FRAME_BRANCH(128 * m < L)) {
-      const double w0 = NORMALISE ? window_value<TYPE>(ge.c) * inv_scale : window_value<TYPE>(ge.c);
-      const double w1 = NORMALISE ? window_value<TYPE>(go.c) * inv_scale : window_value<TYPE>(go.c);
-      v[m].x -= (128 * m + 2 * lane < L ? w0 : 0.0) * coef;
-      v[m].y -= (128 * m + 2 * lane + 1 < L ? w1 : 0.0) * coef;
-      ge.next();
-      go.next();
+      if (KEEP_W) {
+        v[m].x -= kw0[KEEP_W ? m : 0] * coef;
+        v[m].y -= kw1[KEEP_W ? m : 0] * coef;
+      } else {
+        const double w0 = NORMALISE ? window_value<TYPE>(ge.c) * inv_scale : window_value<TYPE>(ge.c);
+        const double w1 = NORMALISE ? window_value<TYPE>(go.c) * inv_scale : window_value<TYPE>(go.c);
+        v[m].x -= (128 * m + 2 * lane < L ? w0 : 0.0) * coef;
+        v[m].y -= (128 * m + 2 * lane + 1 < L ? w1 : 0.0) * coef;
+        ge.next();
+        go.next();
+      }
     }
   }
 }
