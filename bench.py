@@ -121,6 +121,51 @@ def measured_traffic(fs, workload="analysis_synthesis"):
     return None, "kernel sources changed since the PMC passes in profiles/pmc_traffic.json (now %s)" % sha
 
 
+# timing scope of the library (WorldMi355TimingQuery) -> kernel names of the PMC passes it brackets
+SCOPE_KERNELS = {
+    "dio_lowcut_kernel": ("dio_lowcut_fft_kernel",),
+    "dio_band_kernel": ("dio_band_fft_kernel", "dio_band_scan_kernel", "dio_band_compact_kernel"),
+    "d4c_lovetrain_kernel": ("d4c_lovetrain_all_pass_kernel", "d4c_lovetrain_kernel", "d4cb_lovetrain_kernel"),
+    "d4c_kernel": ("d4c_kernel", "d4cb_centroid_kernel", "d4cb_spectrum_kernel", "d4cb_band_kernel", "d4cb_output_kernel"),
+    "synth_search_kernel": ("synth_pulse_search_kernel",),
+    "hv_decimate": ("decim_fwd_kernel", "decim_bwd_kernel"),
+    "hv_band_kernel": ("hv_band_fft_kernel", "hv_band_scan_kernel", "hv_band_compact_kernel"),
+}
+
+
+def per_kernel_rooflines(fs, workload, kernel_ms, steps, units):
+    """`roofline.kernels`: every timed scope of the workload with its HIP-event time per step, the bytes it moved at
+    the L2's memory side (the PMC passes of profiles/pmc_traffic.json, calibrated, scaled to this step's units) and
+    what that is against the HBM peak.  None when the passes are not those of the current sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            recs = json.load(f)
+    except (OSError, ValueError):
+        return None
+    key = "analysis_synthesis" if workload == "sweep" else workload
+    sha = kernel_source_hash(key)
+    rec = next((r for r in recs if r.get("fs") == fs and r.get("workload", "analysis_synthesis") == key
+                and r.get("source_sha") == sha and r.get("per_kernel")), None)
+    if rec is None:
+        return None
+    ff, wf, _ = counter_calibration()
+    out = {}
+    for scope, (ms, n) in kernel_ms.items():
+        if n == 0:
+            continue
+        names = SCOPE_KERNELS.get(scope, (scope,))
+        kb = sum(rec["per_kernel"][k]["fetch_kb"] * ff + rec["per_kernel"][k]["write_kb"] * wf
+                 for k in names if k in rec["per_kernel"])
+        per_step_ms = ms / max(1, steps)
+        moved = kb * 1024.0 * units / rec["frames"]
+        gbs = moved / (per_step_ms * 1e-3) / 1e9 if per_step_ms > 0 else None
+        out[scope] = {"ms": round(per_step_ms, 4), "moved_mb": round(moved / 1e6, 1),
+                      "gbs": round(gbs, 1) if gbs is not None else None,
+                      "frac_hbm": round(gbs / HBM_PEAK_GBS, 4) if gbs is not None else None}
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -539,7 +584,8 @@ def compact(line):
         return None
     roof = line.get("roofline") or {}
     keep_roof = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_note",
-                                          "launch_ms", "units_per_launch", "bytes_per_unit", "fp64", "kernel_ms_per_step")
+                                          "launch_ms", "units_per_launch", "bytes_per_unit", "fp64", "kernel_ms_per_step", "kernels",
+                                          "kernels_note")
                  if k in roof}
     out = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
            "steps": line["steps"], "scaling": line["scaling"], "dtype": line["dtype"],
@@ -648,6 +694,12 @@ def kernel_roofline(workload, kernel, note, kernel_ms, steps, units, bytes_per_u
         fl = flops_per_launch / per_step
         roof["fp64"] = {"achieved_tflops": round(fl / avg_s / 1e12, 3) if ok else None, "peak_tflops": FP64_PEAK_TFLOPS,
                         "frac": round(fl / avg_s / 1e12 / FP64_PEAK_TFLOPS, 5) if ok else None}
+    kernels = per_kernel_rooflines(fs, workload, kernel_ms, steps, units * per_step)
+    if kernels:
+        roof["kernels"] = kernels
+        roof["kernels_note"] = ("per timed scope: HIP-event ms per step, MB moved at the L2's memory side (PMC FETCH_SIZE x read "
+                                "factor + WRITE_SIZE per kernel, %s), GB/s and fraction of the %g GB/s HBM peak; scopes on "
+                                "different streams overlap in time" % (tnote.split(";")[0] if tnote else "", HBM_PEAK_GBS))
     return roof
 
 

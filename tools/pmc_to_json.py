@@ -64,6 +64,27 @@ def total(dirname, counter, match=is_usual_d4c, mark=None):
     return kb, launches, name, passes
 
 
+def short_name(kn):
+    """`void wm::hv_raw_kernel<...>(args)` -> `hv_raw_kernel`"""
+    kn = kn.split("(")[0].split("<")[0].strip()
+    return kn.split("::")[-1].split(" ")[-1]
+
+
+def per_kernel(dirname, counter):
+    """KB per kernel name over the whole profiled process (every wm:: kernel), and its launches."""
+    out = {}
+    for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                kn = row.get("Kernel_Name", "")
+                if row.get("Counter_Name") != counter or "wm::" not in kn:
+                    continue
+                e = out.setdefault(short_name(kn), [0.0, 0])
+                e[0] += float(row["Counter_Value"])
+                e[1] += 1
+    return out
+
+
 def main():
     fdir, wdir, frames, fs, tag = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     workload = sys.argv[6] if len(sys.argv) > 6 else "analysis_synthesis"
@@ -83,6 +104,13 @@ def main():
            "files": "profiles/%s_pmc_fetch.csv, profiles/%s_pmc_write.csv" % (tag, tag),
            "unit_note": "FETCH_SIZE / WRITE_SIZE as reported (KB); bench.py multiplies by the factors measured in "
                         "profiles/hbm_counter_calibration.json (reads x 2.0, writes x 1.0 on gfx950)"}
+    # every kernel of the workload, per pass: what bench.py's per-kernel rooflines are made of (roofline.kernels)
+    pf, pw = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    total_passes = fp * per
+    rec["per_kernel"] = {k: {"fetch_kb": round(pf[k][0] / total_passes * per, 3),
+                             "write_kb": round(pw.get(k, [0.0, 0])[0] / total_passes * per, 3),
+                             "launches_per_pass": round(pf[k][1] / total_passes * per, 3)}
+                         for k in sorted(pf)}
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     recs = []
     if os.path.exists(path):
