@@ -7,8 +7,10 @@
 
 namespace wm {
 
+// nz < 0: the plain transform; nz >= 0: rfft_forward_nz with that many leading packed registers declared non-zero
+// (the rows must then be zero from sample 128 nz on: the pruned first pass does not read what lies behind)
 template <int F>
-__global__ __launch_bounds__(64) void rfft_test_kernel(int count, const double* __restrict__ x,
+__global__ __launch_bounds__(64) void rfft_test_kernel(int count, int nz, const double* __restrict__ x,
                                                        double* __restrict__ re, double* __restrict__ im,
                                                        double* __restrict__ xb) {
   constexpr int N = F / 2, M = N / 64;
@@ -25,7 +27,8 @@ __global__ __launch_bounds__(64) void rfft_test_kernel(int count, const double* 
       const int n = lane + 64 * m;
       v[m] = make_double2(xr[2 * n], xr[2 * n + 1]);
     }
-    rfft_forward<N>(v, img, img, tw, lane);
+    if (nz < 0) rfft_forward<N>(v, img, img, tw, lane);
+    else rfft_forward_nz<N>(v, img, img, tw, lane, nz);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int k = lane + 64 * m;
@@ -51,14 +54,21 @@ __global__ __launch_bounds__(64) void rfft_test_kernel(int count, const double* 
 
 // Forward / backward real FFT of `count` rows of length n (1024, 2048, 4096) on `stream`; layouts as
 // externs/WORLD_v2/src/fft.cpp:26-72 (re / im split, n / 2 + 1 bins).  Returns 0, or -1 for another n.
+extern "C" int FftHookRfftNz(void* stream, int n, int count, int nz, const double* x, double* re, double* im,
+                             double* xb);
 extern "C" int FftHookRfft(void* stream, int n, int count, const double* x, double* re, double* im, double* xb) {
+  return FftHookRfftNz(stream, n, count, -1, x, re, im, xb);
+}
+// The same with the pruned first pass: nz leading packed registers (128 samples each) may be non-zero.
+extern "C" int FftHookRfftNz(void* stream, int n, int count, int nz, const double* x, double* re, double* im,
+                             double* xb) {
   using namespace wm;
   hipStream_t st = (hipStream_t)stream;
   const int grid = count < 1024 ? count : 1024;
   switch (n) {
-    case 1024: hipLaunchKernelGGL(rfft_test_kernel<1024>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
-    case 2048: hipLaunchKernelGGL(rfft_test_kernel<2048>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
-    case 4096: hipLaunchKernelGGL(rfft_test_kernel<4096>, dim3(grid), dim3(64), 0, st, count, x, re, im, xb); break;
+    case 1024: hipLaunchKernelGGL(rfft_test_kernel<1024>, dim3(grid), dim3(64), 0, st, count, nz, x, re, im, xb); break;
+    case 2048: hipLaunchKernelGGL(rfft_test_kernel<2048>, dim3(grid), dim3(64), 0, st, count, nz, x, re, im, xb); break;
+    case 4096: hipLaunchKernelGGL(rfft_test_kernel<4096>, dim3(grid), dim3(64), 0, st, count, nz, x, re, im, xb); break;
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? (hipStreamSynchronize(st) == hipSuccess ? 0 : -2) : -2;

@@ -67,6 +67,40 @@ def test_wavefront_fft_vs_numpy(gpu, n):
     assert np.abs(xb.cpu().numpy() / n - x.cpu().numpy()).max() < 1e-13
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_pruned_first_pass_of_the_fft(gpu, n):
+    """rfft_forward_nz (csrc/fft.hpp): the first pass of a transform whose operand is zero from some register on skips
+    what the zeros make trivial (DftNz), in four sizes chosen at run time.  Rows of every length class, zero-padded,
+    through the pruned pass declared with exactly their reach and with more than it: the spectrum of the plain
+    transform to rounding (the skipped additions are of exact zeros: the same bits but for the sign of a zero)."""
+    import ctypes as C
+    torch, W, ctx = gpu
+    lib = C.CDLL(os.environ.get("WORLD_MI355_FFT_HOOK") or os.path.join(os.path.dirname(__file__), "hooks", "libfft_hook.so"))
+    vp = C.c_void_p
+    lib.FftHookRfftNz.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    M = n // 128                                           # packed registers per lane
+    g = torch.Generator(device="cuda").manual_seed(3 * n)
+    for reach in (1, 2, M // 8, M // 4, M // 4 + 1, M // 2, M // 2 + 1, M - 1, M):
+        reach = max(1, reach)
+        x = torch.randn(8, n, dtype=torch.float64, device="cuda", generator=g)
+        x[:, 128 * reach:] = 0.0
+        x[3, 128 * reach - 5:] = 0.0                       # a window that ends inside its last register
+        ref = np.fft.rfft(x.cpu().numpy(), axis=1)
+        scale = np.abs(ref).max()
+        outs = []
+        for nz in (-1, reach, min(M, reach + 1), M):
+            re = torch.empty(8, n // 2 + 1, dtype=torch.float64, device="cuda")
+            im, xb = torch.empty_like(re), torch.empty_like(x)
+            torch.cuda.synchronize()
+            assert lib.FftHookRfftNz(vp(torch.cuda.current_stream().cuda_stream), n, 8, nz, vp(x.data_ptr()),
+                                     vp(re.data_ptr()), vp(im.data_ptr()), vp(xb.data_ptr())) == 0
+            got = re.cpu().numpy() + 1j * im.cpu().numpy()
+            assert np.abs(got - ref).max() < 1e-14 * n * scale, (reach, nz)
+            outs.append(got)
+        for got in outs[1:]:
+            assert np.abs(got - outs[0]).max() <= 1e-15 * n * scale
+
+
 @pytest.fixture(scope="module")
 def batch16(gpu, oracle):
     torch, W, ctx = gpu
