@@ -205,9 +205,15 @@ class ShardedSweep:
         self._write_busy = 0.0
         t0 = time.perf_counter()
         with ThreadPoolExecutor(io_threads) as pool:
+            dbg = [] if os.environ.get("WM_SWEEP_TIMELINE") else None
+
             def drain(k):
                 """round k is on the host: hand its utterances to the writers"""
+                if dbg is not None:
+                    dbg.append(("drain%d wait" % k, time.perf_counter() - t0))
                 marks[k][4].synchronize()
+                if dbg is not None:
+                    dbg.append(("drain%d on host" % k, time.perf_counter() - t0))
                 if host_gather:                        # every rank, every round, in the same order: a collective
                     tg = time.perf_counter()
                     res = sharding.gather_features(hosts[k], round_counts[k][self.rank], dst=0,
@@ -267,9 +273,13 @@ class ShardedSweep:
                     drain(k - 1)                      # while round k runs on the GPU
             if self.rounds:
                 drain(self.rounds - 1)
+            if dbg is not None:
+                dbg.append(("all submitted", time.perf_counter() - t0))
             for p in pending:
                 p.result()
             t_end = time.perf_counter()
+            if dbg is not None:
+                dbg.append(("writers done", t_end - t0))
         torch.cuda.synchronize()
         ph = {"compute": 0.0, "gather": 0.0, "to_host": 0.0, "write": 0.0}
         for c0, c1, x0, x1, x2 in marks:
@@ -283,6 +293,13 @@ class ShardedSweep:
             # span from the first submit to the last completion
             ph["write"] = self._write_busy if self._write_busy > 0 else t_end - t_first_submit[0]
         ph["wall"] = t_end - t0
+        if dbg is not None:
+            base = marks[0][0]
+            ev_ms = [(base.elapsed_time(m[1]), base.elapsed_time(m[2]), base.elapsed_time(m[4])) for m in marks]
+            import sys
+            print("  timeline ms: " + ", ".join("%s %.2f" % (n, v * 1e3) for n, v in dbg), file=sys.stderr)
+            print("  rounds (compute end, copy start, on host; ms after the first kernel): "
+                  + "; ".join("%.2f %.2f %.2f" % e for e in ev_ms), file=sys.stderr)
         if self.world > 1 and dist.is_initialized():
             dist.barrier()
         return ph
