@@ -184,6 +184,13 @@ def parse():
                          "setting the reference's author committed (config.status: SAMPFREQ=48000)")
     ap.add_argument("--gather", action="store_true", help="include the RCCL feature gather in the timed step itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true",
+                    help="skip the two PCIe-inclusive legs: every launch of the run is then one the line's launch_ms "
+                         "averages (what tools/profile_round.sh profiles)")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the FULL line goes (per-kernel tables, notes); default gpurun_out/bench_detail.json "
+                         "when that directory exists.  stdout carries the compact line (driver_line()).")
+    ap.add_argument("--full-line", action="store_true", help="print the full line on stdout instead of the compact one")
     ap.add_argument("--no-side", action="store_true",
                     help="analysis_synthesis at one GPU: skip the side_workloads (configs[2], [4], [3]) after the headline")
     ap.add_argument("--separate-calls", action="store_true",
@@ -404,7 +411,8 @@ def main():
     else:
         line = headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data if side else None)
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        detail = write_detail(args, line)
+        print(json.dumps(line if args.full_line else driver_line(line, detail)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -500,8 +508,10 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
                                "gather_alone includes the float64 -> float32 conversion of the slabs"
                                % ("RCCL send/recv" if args.backend == "nccl" else "gloo rehearsal")}
     comm = env.comm_record()
-    hi = host_inclusive(env, ctx, xs, fs, fp)
-    hic = host_inclusive(env, ctx, xs, fs, fp, coded=(50, 25))
+    hi = hic = None
+    if not args.no_host_inclusive:
+        hi = host_inclusive(env, ctx, xs, fs, fp)
+        hic = host_inclusive(env, ctx, xs, fs, fp, coded=(50, 25))
 
     line = None
     if rank == 0:
@@ -542,8 +552,10 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
             line["with_gather"] = with_gather
         if comm:
             line["rccl"] = comm
-        line["host_inclusive"] = hi
-        line["host_inclusive_coded"] = hic
+        if hi:
+            line["host_inclusive"] = hi
+        if hic:
+            line["host_inclusive_coded"] = hic
         if cpu_o2:
             line["cpu_baseline_O2"] = cpu_o2
         if cpu_all:
@@ -596,6 +608,118 @@ def compact(line):
         if k in line:
             out[k] = line[k]
     return out
+
+
+# The line a driver records is the LAST 8 KB of stdout: round 4's full line (per-kernel tables and a paragraph of
+# provenance per workload: 14 KB) lost its first half there.  stdout now carries driver_line(): every number of
+# every workload, no table and no prose twice; the full line goes to a file beside it (write_detail).
+DRIVER_LINE_MAX = 6500
+_DROP_EVERYWHERE = ("kernels", "kernels_note", "traffic_note", "layout", "model", "flags", "overlapped")
+_NOTE_KEYS = ("note",)
+
+
+def _sig(v, digits=8):
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, v))
+    return v
+
+
+def _prune(o, depth=0, keep_notes=False):
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in _DROP_EVERYWHERE or (k in _NOTE_KEYS and not keep_notes):
+                continue
+            if k == "sample" and isinstance(v, str) and len(v) > 96:
+                v = v[:93] + "..."
+            out[k] = v if k in ("value", "ms_per_step") and not isinstance(v, (dict, list)) else _prune(v, depth + 1, keep_notes)
+        return out
+    if isinstance(o, list):
+        return [_prune(v, depth + 1, keep_notes) for v in o]
+    return _sig(o)
+
+
+def driver_line(full, detail=None):
+    """The compact stdout line: the contract's keys, `roofline` and `cpu_baseline` of the headline in full (numbers),
+    every side workload's value / ms_per_step / roofline numbers / cpu_baseline / parity, the host-inclusive and
+    gather figures -- and, last, `summary`: the handful of numbers a reader wants first."""
+    line = _prune(full)
+    cfg = dict(line.get("config") or {})
+    if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 150:
+        cfg["workload"] = cfg["workload"][:147] + "..."
+    line["config"] = cfg
+    roof = (full.get("roofline") or {})
+    notes = {}
+    if roof.get("traffic_note"):
+        notes["traffic"] = roof["traffic_note"] if len(roof["traffic_note"]) < 330 else roof["traffic_note"][:327] + "..."
+    if roof.get("note"):
+        notes["roofline"] = roof["note"]
+    if detail:
+        notes["detail_file"] = detail + " (full line: per-kernel MB moved / GB/s tables, provenance notes)"
+    sides = {}
+    for name, sl in (line.pop("side_workloads", None) or {}).items():
+        if sl is None:
+            continue
+        for k in ("metric", "unit", "steps", "dtype"):
+            sl.pop(k, None)
+        sl["frames"] = (sl.pop("config", None) or {}).get("frames")
+        r = sl.get("roofline") or {}
+        if "fp64" in r:
+            r["fp64_frac"] = (r.pop("fp64") or {}).get("frac")
+        for k in ("peak", "unit", "launches_per_step"):
+            r.pop(k, None)
+        cb = sl.get("cpu_baseline")
+        if cb:
+            sl["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        sides[name] = sl
+    if sides:
+        line["side_workloads"] = sides
+    if notes:
+        line["notes"] = notes
+    summary = {"value": line.get("value"), "ms_per_step": line.get("ms_per_step"),
+               "roofline_frac": (line.get("roofline") or {}).get("frac"),
+               "d4c_launch_ms": (line.get("roofline") or {}).get("launch_ms")}
+    for k in ("host_inclusive", "host_inclusive_coded", "with_gather", "with_gather_raw"):
+        if isinstance(line.get(k), dict):
+            summary[k] = line[k].get("value")
+    for name, sl in sides.items():
+        summary[name] = sl.get("value")
+        summary[name + "_ms"] = sl.get("ms_per_step")
+    if isinstance(line.get("cpu_baseline"), dict) and line["cpu_baseline"].get("value"):
+        summary["x_cpu_1thread"] = _sig(line["value"] / line["cpu_baseline"]["value"], 4)
+    if isinstance(full.get("parity"), dict):
+        summary["parity"] = {k: _sig(v, 3) for k, v in full["parity"].items() if isinstance(v, float)}
+    line["summary"] = summary
+    text = json.dumps(line)
+    if len(text) > DRIVER_LINE_MAX:
+        # still too long (many ranks' rccl records, ...): drop the per-scope times of the side workloads, then the notes
+        for sl in sides.values():
+            (sl.get("roofline") or {}).pop("kernel_ms_per_step", None)
+        if len(json.dumps(line)) > DRIVER_LINE_MAX:
+            line.pop("notes", None)
+        if len(json.dumps(line)) > DRIVER_LINE_MAX and isinstance(line.get("rccl"), dict):
+            line["rccl"] = {k: v for k, v in line["rccl"].items() if k != "ranks"}
+    return line
+
+
+def write_detail(args, full):
+    """The full line as a file; returns the path written (relative), or None."""
+    path = args.detail_file
+    if path is None:
+        d = os.path.join(os.getcwd(), "gpurun_out")
+        if not os.path.isdir(d):
+            return None
+        name = "bench_detail.json" if args.workload == "analysis_synthesis" and args.fs == 16000 else \
+            "bench_detail_%s_%d.json" % (args.workload, args.fs)
+        path = os.path.join("gpurun_out", name)
+    try:
+        with open(path, "w") as f:
+            f.write(json.dumps(full) + "\n")
+        return path
+    except OSError:
+        return None
 
 
 def host_inclusive(env, ctx, xs, fs, fp, coded=None):

@@ -41,8 +41,16 @@ int phase_read_synthesis(unsigned long long* out32);
 using namespace wm;
 
 // the drop-in entry points' failure handler (WorldMi355SetErrorHandler; see die() below)
+// The handler and its argument are read and written as a pair under their own lock (not g_mu: die() runs while an
+// entry point holds that one).
+static std::mutex g_err_mu;
 static WorldMi355ErrorHandler g_on_error = nullptr;
 static void* g_on_error_user = nullptr;
+static WorldMi355ErrorHandler error_handler(void** user) {
+  std::lock_guard<std::mutex> lock(g_err_mu);
+  *user = g_on_error_user;
+  return g_on_error;
+}
 
 struct WorldMi355Context { Context c; };
 struct WorldMi355Batch { Batch b; };
@@ -128,6 +136,9 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   if (c.ev_d4c) hipEventDestroy(c.ev_d4c);
   if (c.ev_rare) hipEventDestroy(c.ev_rare);
   if (c.aux) { hipStreamSynchronize(c.aux); hipStreamDestroy(c.aux); }
+  if (c.prep) { hipStreamSynchronize(c.prep); hipStreamDestroy(c.prep); }
+  if (c.ev_call) hipEventDestroy(c.ev_call);
+  if (c.ev_prep_b) hipEventDestroy(c.ev_prep_b);
   for (int h = 0; h < 2; ++h) {
     if (c.ev_pulse[h]) hipEventDestroy(c.ev_pulse[h]);
     if (c.ev_ola[h]) hipEventDestroy(c.ev_ola[h]);
@@ -365,6 +376,7 @@ __attribute__((visibility("default"))) int WorldMi355DebugPhases(int unit, unsig
 }
 #endif
 void WorldMi355SetErrorHandler(WorldMi355ErrorHandler handler, void* user) {
+  std::lock_guard<std::mutex> lock(g_err_mu);
   g_on_error = handler;
   g_on_error_user = user;
 }
@@ -409,9 +421,12 @@ WorldMi355Context* g_ctx = nullptr;
 struct DropInError {
   const char* where;
   int code;
+  WorldMi355ErrorHandler handler;   // the handler that was installed when the failure happened: a concurrent
+  void* user;                       // WorldMi355SetErrorHandler(NULL) cannot make the failure vanish
 };
 [[noreturn]] void die(const char* where, int rc) {
-  if (g_on_error) throw DropInError{where, rc};
+  void* user = nullptr;
+  if (WorldMi355ErrorHandler handler = error_handler(&user)) throw DropInError{where, rc, handler, user};
   fprintf(stderr, "libworld_mi355: %s failed (code %d): %s\n", where, rc, WorldMi355LastError());
   abort();
 }
@@ -529,7 +544,7 @@ void drop_in_failed(const DropInError& e) {
   g_ws.pending.clear();
   g_ws.stage_at = 0;
   g_ws.x_valid = false;
-  if (g_on_error) g_on_error(e.where, e.code, WorldMi355LastError(), g_on_error_user);
+  e.handler(e.where, e.code, WorldMi355LastError(), e.user);
 }
 
 hipStream_t ws_stream() { return default_context()->c.stream; }

@@ -1054,7 +1054,9 @@ static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more
     // what is there stays: this part is cut into pieces of the size the scratch was laid out for
     chunk = b.syn_chunk > 0 ? b.syn_chunk : chunk;
   } else {
-    rc = c.ensure_scratch((chunk < list ? 2 : 1) * chunk * F);
+    // one half only when this part is the whole call AND fits one piece: a later part (expect_more > 0) starts at
+    // whatever piece parity the earlier one ended on, so the split path always lays out both halves
+    rc = c.ensure_scratch((chunk < list || expect_more > 0 ? 2 : 1) * chunk * F);
     if (rc) return rc;
     b.syn_chunk = chunk;
   }
@@ -1073,7 +1075,8 @@ static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more
     const int64_t cap = need + need / 8 + 64;
     rc = wm_check(dev_alloc(&b.d_pulse_rec, sizeof(PulseRec) * (size_t)cap));
     if (rc) return rc;
-    rc = wm_check(dev_alloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + cap / kPartBlock + 8)));
+    // perm[cap], then two sets of partition scratch (n_true + block counts), one per part of a split call
+    rc = wm_check(dev_alloc(&b.d_pulse_perm, sizeof(int) * (size_t)(cap + 2 * (cap / kPartBlock + 8))));
     if (rc) return rc;
     b.pulse_rec_cap = cap;
   }
@@ -1083,11 +1086,13 @@ static int synthesis_prepare_finish(Batch& b, SynPart& part, int64_t expect_more
   // The voiced-first order of every piece of the list, here rather than in front of each pulse kernel: two short
   // dependent launches per piece that sat between D4C and the first pulse kernel and between the pieces.  A piece's
   // order lives at its own place of the array (perm + p0); the block counts are scratch of one launch pair.
+  // The second part of a split call partitions on another stream than the first: its count scratch is its own.
   const int64_t piece = b.syn_chunk, p_end = part.p_base + part.total_p;
+  int* part_scratch = b.d_pulse_perm + b.pulse_rec_cap + (in_flight ? b.pulse_rec_cap / kPartBlock + 8 : 0);
   for (int64_t p0 = part.p_base; p0 < p_end; p0 += piece) {
     const int64_t np = p_end - p0 < piece ? p_end - p0 : piece;
-    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np,
-                     b.d_pulse_perm + b.pulse_rec_cap + 4, b.d_pulse_perm + p0, b.d_pulse_perm + b.pulse_rec_cap);
+    launch_partition(st, PulseVoicedPred{(const PulseRec*)b.d_pulse_rec + p0}, (int)np, part_scratch + 4,
+                     b.d_pulse_perm + p0, part_scratch);
   }
   return wm_check(hipGetLastError());
 }

@@ -986,6 +986,38 @@ def test_synthesis_in_response_chunks(gpu, monkeypatch):
     b.close()
 
 
+def test_synthesis_split_with_a_short_pulse_list(gpu):
+    """Synthesis alone splits a batch of 16 or more utterances and 4 Mi output samples into two parts.  With few
+    pulses (low-pitched, fully voiced: fewer than 32 Ki in all) each part is one piece of the response scratch, and
+    the second part lands in the scratch's second half: the layout must hold both (it held one; the second part's
+    responses went past the end).  Every utterance must come out as from a batch of its own, bit for bit."""
+    torch, W, ctx = gpu
+    fs, fp, n_utt = 48000, 5.0, 18
+    p = W.default_params(fs, fp)
+    rng = np.random.default_rng(5)
+    T = [int(rng.integers(1000, 1300)) for _ in range(n_utt)]
+    Y = [int((t - 1) * fp / 1000.0 * fs) + 1 for t in T]
+    assert sum(Y) >= 4 << 20
+    bs = W.WorldBatch(ctx, p, f0_lengths=T, y_lengths=Y)
+    H = bs.fft_size // 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nt = sum(T)
+    f0 = 70.0 + 25.0 * torch.rand(nt, dtype=torch.float64, device="cuda", generator=g)
+    k = torch.arange(H, dtype=torch.float64, device="cuda")
+    sp = (1e-3 * torch.exp(-k / 300.0))[None, :] * (0.5 + torch.rand(nt, H, dtype=torch.float64, device="cuda", generator=g))
+    ap = 0.05 + 0.9 * torch.rand(nt, H, dtype=torch.float64, device="cuda", generator=g) * (k / H)[None, :]
+    y = bs.synthesize(f0, sp, ap).clone()
+    assert bool(torch.isfinite(y).all()) and float(y.abs().max()) > 0
+    fo, yo = np.concatenate([[0], np.cumsum(T)]), np.concatenate([[0], np.cumsum(Y)])
+    for u in range(n_utt):
+        b1 = W.WorldBatch(ctx, p, f0_lengths=[T[u]], y_lengths=[Y[u]])
+        fr = slice(int(fo[u]), int(fo[u + 1]))
+        y1 = b1.synthesize(f0[fr].contiguous(), sp[fr].contiguous(), ap[fr].contiguous())
+        assert torch.equal(y1, y[int(yo[u]):int(yo[u + 1])]), u
+        b1.close()
+    bs.close()
+
+
 def test_pcm16_conversions(gpu):
     """wavread's s / 32768 and wavwrite's clamp(int(y * 32767)) (test/audioio.cpp:236-249, :160-167) over a batch."""
     torch, W, ctx = gpu

@@ -63,3 +63,38 @@ def test_native_file_writer(tmp_path):
         W.write_files([(tmp_path / "no_such_dir" / "a.f0", slab[:3])], threads=2)
     with pytest.raises(AssertionError):
         W.write_files([(tmp_path / "t.f0", slab[:, 0])])   # a column of a slab is not contiguous
+
+
+def test_driver_line_fits_the_drivers_tail():
+    """bench.py prints a compact line (the driver records the last 8 KB of stdout; round 4's 14 KB line lost its first
+    half there): every workload's numbers survive, the contract's keys and objects are intact."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    with open(os.path.join(root, "profiles", "r04_g_bench_default.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 8192                         # the case that went wrong
+    line = bench.driver_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= 7000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert line["roofline"][k] == full["roofline"][k], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["host_inclusive"]["value"] == full["host_inclusive"]["value"]
+    assert line["host_inclusive_coded"]["value"] == full["host_inclusive_coded"]["value"]
+    assert line["parity"]["vs"] == "reference"
+    for name in ("harvest", "synthesis", "sweep"):
+        side, ref = line["side_workloads"][name], full["side_workloads"][name]
+        assert side["value"] == ref["value"] and side["ms_per_step"] == ref["ms_per_step"]
+        assert side["roofline"]["frac"] == ref["roofline"]["frac"] and side["roofline"]["launch_ms"] == ref["roofline"]["launch_ms"]
+        assert side["cpu_baseline"]["value"] == ref["cpu_baseline"]["value"] and side["parity"]
+        assert line["summary"][name] == ref["value"]
+    assert list(line)[-1] == "summary"                           # the numbers that matter are the line's last bytes

@@ -12,7 +12,9 @@ if [ "$wl" = "synthesis" ]; then u64="--utts 256"; fi
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag gpurun_out/pmcf_$tag gpurun_out/pmcw_$tag
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o ks --output-format csv -- python3 bench.py $wa --steps 3 --warmup 1 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err && echo stats ok && \
+# the stats pass times what the line times: no host-inclusive legs (their launches run beside copy kernels), the default
+# pre-warm, the driver's step counts -- kernel_stats.csv's AverageNs of the dominant kernel is the line's launch_ms
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o ks --output-format csv -- python3 bench.py $wa --steps 20 --warmup 5 --no-cpu-baseline --no-host-inclusive --detail-file gpurun_out/${tag}_bench_under_rocprof_detail.json > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err && echo stats ok && \
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmcf_$tag -o f --output-format csv -- python3 bench.py $wa --steps 1 --warmup 0 $u64 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_pmc_fetch.json 2> gpurun_out/${tag}_pmc_fetch.err && echo fetch ok && \
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmcw_$tag -o w --output-format csv -- python3 bench.py $wa --steps 1 --warmup 0 $u64 --no-cpu-baseline --prewarm 0 > gpurun_out/${tag}_pmc_write.json 2> gpurun_out/${tag}_pmc_write.err && echo write ok
 find gpurun_out/prof_$tag -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;
