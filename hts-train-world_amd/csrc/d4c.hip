@@ -200,7 +200,7 @@ __device__ __forceinline__ void d4c_centroid(const double* __restrict__ xu, int 
   double x[QX];
   double pwr;
   const int nzc = (fg.L + 63) >> 6;                 // registers of the operand the window reaches (not LONG: L <= N)
-  frame_strided<kBlackman, QX, !LONG>(xu, xl, fg, rtab, ro, lane, x, pwr);
+  frame_strided<kBlackman, QX, !LONG, (LONG ? 16 : 8)>(xu, xl, fg, rtab, ro, lane, x, pwr);
   // normalisation to unit energy (d4c.cpp:96-100) and the 1 / (2 s) of the identity above, on the result
   const double scale = uniform_d(1.0 / (2.0 * s * pwr));
   cpx v[M];
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
 
 }  // namespace wm
 #include "d4c_big.hpp"
+#include "d4c_q.hpp"
 namespace wm {
 
 // fft_size_d4c = 4096 / 8192: the four-kernel form of d4c_big.hpp for the usual frames
@@ -779,11 +780,32 @@ int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, 
                        b.d_rng_off_d4c, c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf,                \
                        (const int*)b.d_perm_d4c, (const int*)b.d_part_n_d4c, d_ap);                               \
   } break;
+  // fft_size_d4c 2048 (the headline's 16 kHz): WORLD_MI355_D4C_Q=1 selects the three-waves-per-SIMD form on the
+  // 512-point engine (d4c_q.hpp).  Built in round 5 because two waves looked latency-starved (SQ_ACTIVE_INST_VALU 36 %
+  // per wave); measured (profiles/r05_b_*): the same number of shader cycles per launch -- every wave64 vector
+  // instruction holds the SIMD for four cycles, and 2.52 M instructions per SIMD x 4.45 cycles already ARE the 11.4 M
+  // cycles of the two-wave launch -- 5 % more instructions, and a clock 12 % lower (2.26 -> 1.98 GHz: the denser issue
+  // costs power, and the kernels that follow inherit the lower clock).  5.05 -> 5.8 ms: off by default.
+  static const bool use_q = getenv("WORLD_MI355_D4C_Q") && atoi(getenv("WORLD_MI355_D4C_Q")) != 0;
+#define WM_D4CQ_LAUNCH(OB)                                                                                \
+  {                                                                                                       \
+    const int per_ = persistent_grid(c, d4cq_kernel<2048, OB>, 64, (int64_t)1 << 40);                     \
+    hipLaunchKernelGGL((d4cq_kernel<2048, OB>), dim3(imin(grid, per_)), dim3(64), 0, st, d_x, b.d_x_off,  \
+                       b.d_x_len, b.d_frame_utt, d_t, d_f0, (const double*)b.d_ap0, b.d_rng_off_d4c,      \
+                       c.d_rng, fs, b.p.d4c_threshold, tab, b.p.fft_size, tf, (const int*)b.d_perm_d4c,   \
+                       (const int*)b.d_part_n_d4c, d_ap);                                                 \
+  }
   {
     TimedScope ts_(b.ctx, "d4c_kernel");
     switch (FD) {
       WM_D4C_CASE(1024, 2)
-      WM_D4C_CASE(2048, 2)
+      case 2048: {
+        if (use_q && tab.nap == 1) WM_D4CQ_LAUNCH(true)
+        else if (use_q) WM_D4CQ_LAUNCH(false)
+        else {
+          switch (FD) { WM_D4C_CASE(2048, 2) }
+        }
+      } break;
       case 4096: {              // four kernels on the 1024-point transform (d4c_big.hpp)
         rc = launch_d4c_big<4096>(b, d_x, d_t, d_f0, tab, d_ap);
         if (rc) return rc;
@@ -795,6 +817,7 @@ int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, 
     }
   }
 #undef WM_D4C_CASE
+#undef WM_D4CQ_LAUNCH
   return wm_check(hipGetLastError());
 }
 

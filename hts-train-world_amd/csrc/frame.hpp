@@ -50,11 +50,14 @@ __device__ __forceinline__ FrameGeom frame_geom(int fs, double f0, double pos, d
 // KEEP_W: the window values stay in registers between the two passes (QX more doubles); otherwise the second
 // pass regenerates them with a fresh rotation (long frames, where the registers are worth more than the flops).
 // Loads are issued in groups of at most 16 per array.
-template <int TYPE, int QX, bool KEEP_W>
+// GMAX: registers per load group; groups wholly beyond the window are skipped (the usual D4C frame of fft 2048 is
+// 4 periods = 250 ... 900 samples of the 1024 its 16 registers cover: with groups of 8 the upper half costs nothing
+// from 125 Hz up).
+template <int TYPE, int QX, bool KEEP_W, int GMAX = 16>
 __device__ __forceinline__ void frame_strided(const double* __restrict__ xu, int xl, const FrameGeom& fg,
                                               const uint32_t* __restrict__ rtab, int roff, int lane,
                                               double (&x)[QX], double& pwr) {
-  constexpr int G = QX < 16 ? QX : 16;
+  constexpr int G = QX < GMAX ? QX : GMAX;
   static_assert(QX % G == 0, "QX is a multiple of the load group");
   const int L = fg.L;
   CosGen g;
@@ -238,12 +241,19 @@ __device__ __forceinline__ void frame_packed(const double* __restrict__ xu, int 
     uint32_t ra[G], rb[G];
 #pragma unroll
     for (int r = 0; r < G; ++r) {
-      const int m = c * G + r;
-      const int i0 = imin(128 * m + 2 * lane, L - 1), i1 = imin(128 * m + 2 * lane + 1, L - 1);   // no branch: see above
-      xa[r] = xu[imin(xl - 1, imax(0, fg.origin + i0 - fg.hw))];
-      xb[r] = xu[imin(xl - 1, imax(0, fg.origin + i1 - fg.hw))];
-      ra[r] = rtab[roff + i0];
-      rb[r] = rtab[roff + i1];
+      xa[r] = xb[r] = 0.0;
+      ra[r] = rb[r] = 0u;
+    }
+    if (M == G || 128 * G * c < L) {                    // a group wholly beyond the window is not fetched (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int m = c * G + r;
+        const int i0 = imin(128 * m + 2 * lane, L - 1), i1 = imin(128 * m + 2 * lane + 1, L - 1);   // no branch: see above
+        xa[r] = xu[imin(xl - 1, imax(0, fg.origin + i0 - fg.hw))];
+        xb[r] = xu[imin(xl - 1, imax(0, fg.origin + i1 - fg.hw))];
+        ra[r] = rtab[roff + i0];
+        rb[r] = rtab[roff + i1];
+      }
     }
 #pragma unroll
     for (int r = 0; r < G; ++r) {

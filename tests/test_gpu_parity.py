@@ -222,6 +222,51 @@ def test_other_sampling_rates(gpu, oracle, fs, fft):
     b.close()
 
 
+_D4C_Q_CHILD = r"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+pkg = importlib.import_module("hts-train-world_amd")
+from oracle.bindings import Oracle
+W, sd, o = pkg.world, pkg.synth_data, Oracle()
+ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
+worst = 0.0
+for fs, seeds, dur in ((16000, (3, 4, 90), 1.2), (22050, (52,), 0.7), (12500, (7,), 0.8)):
+    xs = [sd.make_utterance(i, fs, duration=dur) for i in seeds]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    t, f0, sp, ap = b.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
+    for u, x in enumerate(xs):
+        g = slice(b.frame_offsets[u], b.frame_offsets[u + 1])
+        to, f0d = o.dio(x, fs, 5.0)
+        f0o = o.stonemask(x, fs, to, f0d)
+        # low-pitched frames too (windows longer than a quarter of the transform): half of the contour an octave down
+        apo = o.d4c(x, fs, to, f0o, b.fft_size, 0.0)
+        worst = max(worst, float(np.abs(ap[g].cpu().numpy() - apo).max()))
+    # the same frames an octave down: four periods then reach into the second quarter of the transform
+    f0_low = torch.where(f0 > 0, f0 * 0.5, f0)
+    ap_low = b.d4c(torch.from_numpy(np.concatenate(xs)).cuda(), t, f0_low)
+    for u, x in enumerate(xs):
+        g = slice(b.frame_offsets[u], b.frame_offsets[u + 1])
+        apo = o.d4c(x, fs, t[g].cpu().numpy(), f0_low[g].cpu().numpy(), b.fft_size, 0.0)
+        worst = max(worst, float(np.abs(ap_low[g].cpu().numpy() - apo).max()))
+    b.close()
+print("WORST", worst)
+"""
+
+
+def test_d4c_three_wave_form(gpu):
+    """WORLD_MI355_D4C_Q=1: D4C at fft_size_d4c 2048 on the 512-point engine at three waves per SIMD (d4c_q.hpp; off by
+    default).  The switch is read once per process, so a child process runs it: 16 kHz (one band),
+    22.05 kHz (two bands), 12.5 kHz (the longest band window), each also an octave down (frames longer than a quarter of
+    the transform), against the oracle."""
+    env = dict(os.environ, WORLD_MI355_D4C_Q="1")
+    out = subprocess.run([sys.executable, "-c", _D4C_Q_CHILD.format(root=ROOT)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().splitlines()[-1].split()[1])
+    assert worst < AP_TOL, worst
+
+
 def test_fft_size_512_at_8khz(gpu, pkg, oracle):
     """fs <= 12.8 kHz: GetFFTSizeForCheapTrick gives 512 (cheaptrick.cpp:191-194), D4C has no band at all
     (fs / 2 - 3000 < 3000, d4c.cpp:351-353).  Whole chain, codec and the drop-in entry points."""
