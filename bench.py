@@ -361,7 +361,7 @@ def main():
         # the lengths alone and generates only its own utterances
         counts = [sd.utterance_samples(i, fs, tuple(args.dur)) for i in range(utts)]
         frames_all = [sh.frame_count(n, fs, fp) for n in counts]
-        mine = sh.lpt_shards(frames_all, world)[rank]
+        mine = sh.lpt_shards(frames_all, world, sh.rank0_handicap(world) if args.writers == "rank0" else None)[rank]
         plan = (counts, mine)
         if args.plan_only:
             print(json.dumps({"rank": rank, "world": world, "local_rank": local, "workload": "sweep", "utterances": mine,
@@ -461,9 +461,13 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
             t, f0, sp, ap, _ = batch.analyze_synthesize(x, out=outs, y=y)
         return f0, sp, ap
 
-    def gather(f0, sp, ap):
-        # the on-disk types of the reference CLI are float32 (test/analysis.cpp:360-390)
-        feats = [f0.float(), sp.float(), ap.float()]
+    def gather(f0, sp, ap, raw=False):
+        # What travels to rank 0 is what its files hold.  Default: the recipe's own call (`analysis ... 5 F 50 25`,
+        # data/Makefile.in:214): float32 lf0 / mgc[50] / bap[25], 304 B per frame, coded on every rank before the send
+        # (WorldMi355RecipeFeatures).  raw: the CLI without compression arguments: float32 f0 / sp / ap
+        # (test/analysis.cpp:360-390), 4.1 KB per frame -- seven peers' worth of that into one rank per step is what
+        # no link budget scales.
+        feats = list(batch.recipe_features(f0, sp, ap, 50, 25)) if not raw else [f0.float(), sp.float(), ap.float()]
         if args.backend == "gloo":
             feats = [v.cpu() for v in feats]
         sh.gather_features(feats, frame_counts, dst=0, all_counts=all_counts)
@@ -471,7 +475,7 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
     def step():
         f0, sp, ap = compute()
         if args.gather and world > 1:
-            gather(f0, sp, ap)
+            gather(f0, sp, ap, raw=args.raw)
 
     # the ramp runs the rank-local part only: its length is set by each rank's clock, so it must not hold a collective
     ctx.timing_enable(False)
@@ -488,38 +492,42 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
     kernel_ms = {k: ctx.timing_query(k) for k in ANALYSIS_KERNELS + SYNTHESIS_KERNELS}
     ctx.timing_enable(False)
     elapsed_max, total_frames = env.reduce(elapsed, frames)
-    with_gather = None
+    with_gather = with_gather_raw = None
     if world > 1 and not args.gather:
-        # the same step followed by the one exchange the path has: the gather-v of the float32 feature slabs to
-        # rank 0 (RCCL grouped send/recv over xGMI), under the same timing contract
-        def step_g():
-            gather(*compute())
-        step_g()
-        env.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        # the same step followed by the one exchange the path has -- the gather-v of every rank's feature slabs to
+        # rank 0 (RCCL grouped send/recv over xGMI) -- under the same timing contract: coded (what the recipe writes)
+        # and raw
+        def gather_leg(raw):
+            def step_g():
+                gather(*compute(), raw=raw)
             step_g()
-        env.barrier()
-        eg, _ = env.reduce(time.perf_counter() - t0, frames)
-        per_rank = 4 * frames * (1 + 2 * batch.bins)
-        # the exchange alone (features already computed): what the links into rank 0 carry
-        f0_, sp_, ap_ = compute()
-        gather(f0_, sp_, ap_)
-        env.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            gather(f0_, sp_, ap_)
-        env.barrier()
-        ego, _ = env.reduce(time.perf_counter() - t0, frames)
-        del f0_, sp_, ap_
-        with_gather = {"value": round(total_frames * args.steps / eg, 1), "unit": "frames/s",
-                       "ms_per_step": round(eg / args.steps * 1e3, 3),
-                       "gathered_bytes_per_step": per_rank * (world - 1),
-                       "gather_alone_ms": round(ego / args.steps * 1e3, 3),
-                       "gather_alone_gbs_into_rank0": round(per_rank * (world - 1) * args.steps / ego / 1e9, 2),
-                       "note": "analysis + synthesis, then float32 f0/sp/ap of every rank gathered to rank 0 (%s); "
-                               "gather_alone includes the float64 -> float32 conversion of the slabs"
-                               % ("RCCL send/recv" if args.backend == "nccl" else "gloo rehearsal")}
+            env.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_g()
+            env.barrier()
+            eg, _ = env.reduce(time.perf_counter() - t0, frames)
+            per_rank = 4 * frames * ((1 + 2 * batch.bins) if raw else (1 + 50 + 25))
+            # the exchange alone (features already computed): what the links into rank 0 carry
+            f0_, sp_, ap_ = compute()
+            gather(f0_, sp_, ap_, raw=raw)
+            env.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                gather(f0_, sp_, ap_, raw=raw)
+            env.barrier()
+            ego, _ = env.reduce(time.perf_counter() - t0, frames)
+            return {"value": round(total_frames * args.steps / eg, 1), "unit": "frames/s",
+                    "ms_per_step": round(eg / args.steps * 1e3, 3),
+                    "gathered_bytes_per_step": per_rank * (world - 1),
+                    "gather_alone_ms": round(ego / args.steps * 1e3, 3),
+                    "gather_alone_gbs_into_rank0": round(per_rank * (world - 1) * args.steps / ego / 1e9, 2),
+                    "note": "analysis + synthesis, then %s of every rank gathered to rank 0 (%s); gather_alone includes "
+                            "%s" % ("float32 f0/sp/ap" if raw else "the recipe's coded float32 lf0/mgc[50]/bap[25]",
+                                    "RCCL send/recv" if args.backend == "nccl" else "gloo rehearsal",
+                                    "the float64 -> float32 conversion of the slabs" if raw else "the coding kernels")}
+        with_gather = gather_leg(False)
+        with_gather_raw = gather_leg(True)
     comm = env.comm_record()
     hi = hic = None
     if not args.no_host_inclusive:
@@ -563,6 +571,8 @@ def headline_bench(env, ctx, xs, fs, fp, cpu_all, side_data):
             line["config"]["note"] = env.rehearsal_note()
         if with_gather:
             line["with_gather"] = with_gather
+        if with_gather_raw:
+            line["with_gather_raw"] = with_gather_raw
         if comm:
             line["rccl"] = comm
         if hi:
@@ -945,11 +955,21 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
         # host and the file writes stay with rank 0 (its xGMI links carry 7/8 of the bytes the copy engine then moves
         # down).  A pass is a pipeline over the rounds: the longest stage bounds it, one round of the others is exposed.
         R = max(1, sw.rounds)
-        c8 = comp_max / k / 8.0
+        h8 = pkg.sharding.rank0_handicap(8)[0] if args.writers == "rank0" else 1.0
+        c8 = comp_max / k / (7.0 + 1.0 / h8)             # the seven peers' share (rank 0's is smaller by its handicap)
         host_side = (phases["to_host"] + phases["gather"]) / k
         wr = phases["write"] / k
         n_files = 3 * len(counts)
-        pred8 = max(c8, host_side, wr) + (c8 + host_side + wr - max(c8, host_side, wr)) / R
+
+        def pass8(cores):
+            # the file writes are page-cache fills by two native threads per usable core: they scale with the cores
+            # of the node the eight ranks run on (rank 0's process sees all of them there), the PCIe copy does not
+            w = wr * float(ncpu) / float(cores)
+            longest = max(c8, host_side, w)
+            return longest + (c8 + host_side + w - longest) / R
+        pred8 = pass8(ncpu)
+        by_cores = {str(c): round(pass8(c) * 1e3, 3) for c in (16, 64, 128)}
+        speed_by_cores = {c: round(elapsed_max / steps / (v * 1e-3), 2) for c, v in by_cores.items()} if world == 1 else None
         line = {
             "metric": "WORLD analysis sweep frames/sec @16kHz, 5ms hop (corpus -> float32 feature files on rank 0)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -980,9 +1000,12 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
             "predicted": {"ranks": 8, "ms_per_step": round(pred8 * 1e3, 3),
                           "speedup_over_this_run": round(elapsed_max / steps / pred8, 2) if world == 1 and pred8 > 0 else None,
                           "host_cores_assumed": ncpu, "writer_threads_assumed": io_threads,
-                          "model": "max(compute/8, gather + to_host, write) + (the other two stages) / rounds, from "
-                                   "this run's phases; rank 0 keeps the host side at THIS box's cores (the writes are "
-                                   "page-cache fills: they scale with the writer threads, 4..64, two per usable core)"},
+                          "ms_per_step_by_host_cores": by_cores, "speedup_by_host_cores": speed_by_cores,
+                          "rank0_handicap": round(h8, 3),
+                          "model": "max(compute/(7 + 1/handicap), gather + to_host, write) + (the other two stages) / "
+                                   "rounds, from this run's phases; the writes are page-cache fills by two native threads "
+                                   "per usable core and scale with the host cores rank 0 may use (this box: 16; an "
+                                   "8-GPU node: 64-128), the PCIe copy does not"},
             "value_compute_only": round(total * k / comp_max, 1) if comp_max > 0 else None,
             "roofline": roof, "cpu_baseline": None,
         }

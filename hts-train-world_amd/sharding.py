@@ -42,20 +42,44 @@ def frame_count(n_samples: int, fs: int, frame_period: float) -> int:
     return int(1000.0 * n_samples / fs / frame_period) + 1
 
 
-def lpt_shards(costs, world_size: int) -> list[list[int]]:
+def lpt_shards(costs, world_size: int, handicap=None) -> list[list[int]]:
     """Longest-processing-time partition of utterance indices by cost (frame counts).
 
-    Deterministic: ties broken by index.  Every rank gets a (possibly empty) list."""
+    handicap: per-rank cost factors >= 1 (a frame on rank r counts handicap[r] frames): the rank that also receives,
+    copies and writes everybody's features (rank 0 of the sweep) analyses its frames more slowly and gets fewer of
+    them, so that it is not the last to finish.  Deterministic: ties broken by index.  Every rank gets a (possibly
+    empty) list."""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
-    load = [0] * world_size
+    scale = [1.0] * world_size if handicap is None else [float(h) for h in handicap]
+    assert len(scale) == world_size and all(h >= 1.0 for h in scale)
+    load = [0.0] * world_size
     shards: list[list[int]] = [[] for _ in range(world_size)]
     for i in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
+        r = min(range(world_size), key=lambda k: (load[k] + costs[i] * scale[k], k))
         shards[r].append(i)
-        load[r] += costs[i]
+        load[r] += costs[i] * scale[r]
     for s in shards:
         s.sort()
     return shards
+
+
+def rank0_handicap(world_size: int, factor=None) -> list[float]:
+    """The cost factors of the sweep's partition (lpt_shards handicap): rank 0 > 1, the others 1.
+
+    Rank 0 moves EVERY rank's features to the host while it analyses its own shard.  A device-to-host copy is a kernel
+    on this platform, and the store-heavy Dio kernels that run beside one take several times their normal time
+    (profiles/r04_d_kernel_trace.csv): with a copy always in flight a pass' analysis
+    takes about 1.37 x.  On one rank the copies (5.5 ms per pass of the 1000-utterance corpus) cover 0.145 of the
+    analysis (38 ms); on N ranks rank 0's analysis is N times shorter and the copies are not, so they cover
+    min(1, 0.145 N) of it: factor = 1 + 0.37 min(1, 0.145 N) -- 1.11 / 1.21 / 1.37 at 2 / 4 / 8 ranks.
+    WORLD_MI355_SWEEP_HANDICAP overrides rank 0's factor; one rank has none."""
+    import os
+    if world_size <= 1:
+        return [1.0] * max(1, world_size)
+    if factor is None:
+        env = os.environ.get("WORLD_MI355_SWEEP_HANDICAP")
+        factor = float(env) if env else 1.0 + 0.37 * min(1.0, 0.145 * world_size)
+    return [max(1.0, factor)] + [1.0] * (world_size - 1)
 
 
 def gather_features(tensors, frame_counts, dst: int = 0, group=None, all_counts=None):

@@ -85,7 +85,10 @@ class ShardedSweep:
         self.spec_dim, self.ap_dim = int(spec_dim), int(ap_dim)
         self.samples = [int(n) for n in sample_counts]
         self.frames = [sharding.frame_count(n, self.fs, self.fp) for n in self.samples]
-        self.shards = sharding.lpt_shards(self.frames, world)
+        # rank 0 also moves everybody's features to the host and into files: fewer frames for it (sharding.rank0_handicap);
+        # when every rank writes its own shard there is no such rank
+        self.handicap = sharding.rank0_handicap(world) if writers == "rank0" else [1.0] * world
+        self.shards = sharding.lpt_shards(self.frames, world, self.handicap)
         self.writers = writers
         # batch plan of EVERY rank (rank 0 needs the layout of what it receives): longest first inside a shard; with
         # several rounds the rounds taper off (tapered_batches)

@@ -231,7 +231,7 @@ from oracle.bindings import Oracle
 W, sd, o = pkg.world, pkg.synth_data, Oracle()
 ctx = W.Context(stream_ptr=torch.cuda.current_stream().cuda_stream)
 worst = 0.0
-for fs, seeds, dur in ((16000, (3, 4, 90), 1.2), (22050, (52,), 0.7), (12500, (7,), 0.8)):
+for fs, seeds, dur in ((16000, (3, 4, 90), 1.2), (22050, (52,), 0.7), (14000, (7,), 0.8)):
     xs = [sd.make_utterance(i, fs, duration=dur) for i in seeds]
     b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
     t, f0, sp, ap = b.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
@@ -257,7 +257,7 @@ print("WORST", worst)
 def test_d4c_three_wave_form(gpu):
     """WORLD_MI355_D4C_Q=1: D4C at fft_size_d4c 2048 on the 512-point engine at three waves per SIMD (d4c_q.hpp; off by
     default).  The switch is read once per process, so a child process runs it: 16 kHz (one band),
-    22.05 kHz (two bands), 12.5 kHz (the longest band window), each also an octave down (frames longer than a quarter of
+    22.05 kHz (two bands), 14 kHz (a longer band window), each also an octave down (frames longer than a quarter of
     the transform), against the oracle."""
     env = dict(os.environ, WORLD_MI355_D4C_Q="1")
     out = subprocess.run([sys.executable, "-c", _D4C_Q_CHILD.format(root=ROOT)], env=env, capture_output=True, text=True,

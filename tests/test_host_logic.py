@@ -39,6 +39,27 @@ def test_lpt_shards_balance_and_cover():
     assert sh.lpt_shards([5, 3], 4) == [[0], [1], [], []]
 
 
+def test_lpt_shards_with_a_handicap_for_rank_0():
+    """The sweep's rank 0 also moves everybody's features to the host: its frames count for more, so it gets fewer
+    (sharding.rank0_handicap: 1.11 / 1.21 / 1.37 at 2 / 4 / 8 ranks); every utterance is still dealt exactly once and
+    the WEIGHTED loads balance."""
+    rng = np.random.default_rng(1)
+    costs = rng.integers(400, 1600, 1000).tolist()
+    assert sh.rank0_handicap(1) == [1.0]
+    for world, f0 in ((2, 1.1073), (4, 1.2146), (8, 1.37)):
+        h = sh.rank0_handicap(world)
+        assert abs(h[0] - f0) < 1e-3 and h[1:] == [1.0] * (world - 1)
+        shards = sh.lpt_shards(costs, world, h)
+        assert sorted(i for s in shards for i in s) == list(range(1000))
+        loads = [sum(costs[i] for i in s) for s in shards]
+        weighted = [l * k for l, k in zip(loads, h)]
+        assert max(weighted) - min(weighted) <= max(costs) * h[0]
+        assert loads[0] < min(loads[1:])                      # rank 0 analyses less ...
+        assert abs(loads[0] * h[0] - np.mean(loads[1:])) <= max(costs) * h[0]   # ... by its factor
+    assert sh.lpt_shards(costs, 4, None) == sh.lpt_shards(costs, 4, [1.0] * 4)
+    assert sh.rank0_handicap(8, factor=2.0)[0] == 2.0
+
+
 def test_native_file_writer(tmp_path):
     """WorldMi355WriteFiles (host only): a list of arrays to a list of files with plain threads -- the fwrite loops at
     the end of the reference's analysis CLI (test/analysis.cpp:360-390) for a whole batch; errors name the file."""

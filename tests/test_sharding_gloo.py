@@ -19,12 +19,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, lengths, q):
+def _worker(rank, world, port, lengths, q, handicap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = [sh.frame_count(n, 16000, 5.0) for n in lengths]
-    shards = sh.lpt_shards(frames, world)
+    shards = sh.lpt_shards(frames, world, sh.rank0_handicap(world) if handicap else None)
     mine = shards[rank]
     counts = [frames[i] for i in mine]
     total = sum(counts)
@@ -62,3 +62,25 @@ def test_two_rank_gather_v():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+
+def test_eight_rank_gather_v_with_rank0_handicap():
+    """The node's full width on CPU: eight gloo ranks, the sweep's partition (rank 0 handicapped: it also moves
+    everybody's features), ragged shards including short ones, gather-v to rank 0 in rank order."""
+    rng = np.random.default_rng(3)
+    lengths = [int(n) for n in rng.integers(16000, 128000, 61)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, lengths, q, True)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
+    frames = [sh.frame_count(n, 16000, 5.0) for n in lengths]
+    shards = sh.lpt_shards(frames, 8, sh.rank0_handicap(8))
+    loads = [sum(frames[i] for i in s) for s in shards]
+    assert loads[0] < min(loads[1:])

@@ -41,7 +41,9 @@ def test_bench_gpus_flag_starts_the_ranks():
     got = sorted(i for ln in lines for i in ln["utterances"])
     assert got == list(range(30))
     assert sum(ln["frames"] for ln in lines) == lines[0]["corpus_frames"]
-    assert abs(lines[0]["frames"] - lines[1]["frames"]) < 1700          # LPT: within one (longest) utterance
+    # LPT with rank 0's handicap (it also moves both ranks' features): its frames x 1.107 within one (longest) utterance
+    by_rank = {ln["rank"]: ln["frames"] for ln in lines}
+    assert by_rank[0] < by_rank[1] and abs(by_rank[0] * sh.rank0_handicap(2)[0] - by_rank[1]) < 1700 * 1.2
     # weak-scaling workloads: rank r owns utterances [r * utts, (r + 1) * utts)
     lines = _bench("--gpus", 3, "--backend", "gloo", "--utts", 4, "--plan-only")
     assert sorted(tuple(ln["utterances"]) for ln in lines) == [(0, 1, 2, 3), (4, 5, 6, 7), (8, 9, 10, 11)]
@@ -192,18 +194,21 @@ def test_sharded_sweep_writes_the_files_of_one_rank(tmp_path, ranks, coded):
 @pytest.mark.gpu
 def test_headline_line_at_two_ranks_carries_the_gather():
     """`bench.py --gpus 2` on the headline workload (two gloo ranks sharing the box's GPU): one line from rank 0, weak
-    scaling over both ranks' frames, and `with_gather` -- the same step followed by the gather-v of the float32 slabs to
-    rank 0 -- under the same timing contract."""
+    scaling over both ranks' frames, and `with_gather` / `with_gather_raw` -- the same step followed by the gather-v of
+    the coded / raw float32 slabs to rank 0 -- under the same timing contract."""
     lines = _bench("--gpus", 2, "--backend", "gloo", "--utts", 6, "--dur", 0.5, 1.2, "--steps", 2, "--warmup", 1,
                    "--prewarm", 0, "--no-cpu-baseline", "--no-side", "--workers", 1)
     assert len(lines) == 1
     ln = lines[0]
     assert ln["n_gpus"] == 2 and ln["scaling"] == "weak" and ln["config"]["utterances_per_gpu"] == 6
-    wg = ln["with_gather"]
-    assert wg["value"] > 0 and wg["ms_per_step"] >= ln["ms_per_step"] * 0.5
     frames = ln["config"]["frames_per_gpu"]
-    assert wg["gathered_bytes_per_step"] == 4 * frames * (1 + 2 * 513)      # one peer's f0 + sp + ap, float32
-    assert wg["gather_alone_ms"] > 0 and wg["gather_alone_gbs_into_rank0"] > 0
+    # what the recipe's own call writes (coded lf0 / mgc[50] / bap[25], 304 B per frame) by default, raw float32 beside it
+    for key, per_frame in (("with_gather", 4 * (1 + 50 + 25)), ("with_gather_raw", 4 * (1 + 2 * 513))):
+        wg = ln[key]
+        assert wg["value"] > 0 and wg["ms_per_step"] >= ln["ms_per_step"] * 0.5
+        assert wg["gathered_bytes_per_step"] == frames * per_frame          # one peer's slabs
+        assert wg["gather_alone_ms"] > 0 and wg["gather_alone_gbs_into_rank0"] > 0
+    assert ln["summary"]["with_gather"] == ln["with_gather"]["value"]
     assert ln["rccl"]["world_size"] == 2 and len(ln["rccl"]["devices"]) == 2
     assert ln["roofline"]["kernel"] == "d4c_kernel" and ln["roofline"]["frac"] > 0
 
