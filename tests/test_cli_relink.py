@@ -146,6 +146,25 @@ def test_relinked_cli_on_the_reference_wavs(gpu, tmp_path, name):
     assert excess[i, j] <= 0, "frame %d bin %d: %r against %r, row sum %r, f0 %r" % (i, j, rows_g[i, j], rows_r[i, j],
                                                                                    rows_r[i].sum(), rf0[i])
     np.testing.assert_allclose(gap, rap, rtol=3e-7, atol=1e-12)
+    # The same in float32 ulps (the distance between the bit patterns of two positive floats), by the bin's level under
+    # its frame's strongest -- this is the largest deviation between the two link lines anywhere in the suite, so it
+    # gets numbers, not a sentence.
+    ulp = np.abs(rows_g.astype(np.float32).view(np.int32).astype(np.int64) - rows_r.astype(np.float32).view(np.int32).astype(np.int64))
+    level = rows_r / rows_r.max(axis=1, keepdims=True)
+    stats = {"differ": float((ulp > 0).mean()), "more_than_one_ulp": float((ulp > 1).mean())}
+    for lo, hi, key in ((1e-3, 2.0, "0..-30dB"), (1e-6, 1e-3, "-30..-60dB"), (1e-9, 1e-6, "-60..-90dB"), (0.0, 1e-9, "below-90dB")):
+        m = (level >= lo) & (level < hi)
+        stats[key] = (round(float(m.mean()), 4), int(ulp[m].max()) if m.any() else 0, round(float((ulp[m] > 0).mean()), 4) if m.any() else 0.0)
+    print("relinked CLI sp, float32 ulps (%s): %s" % (name, stats))
+    # measured (round 5, these two files): within 60 dB of the frame's peak at most ONE ulp apart and 0.1 % of the values
+    # differ at all; 60-90 dB down up to 47 ulps (a quarter of them differ); below 90 dB (0.7 % / 4.5 % of the bins) up
+    # to 270 / 1143 ulps = 7e-5 relative.  Bounds with room for other boxes' rounding, none for a regression:
+    assert stats["0..-30dB"][1] <= 1 and stats["-30..-60dB"][1] <= 1, stats
+    assert stats["0..-30dB"][2] < 5e-3 and stats["-30..-60dB"][2] < 5e-3, stats
+    assert stats["-60..-90dB"][1] <= 128 and stats["below-90dB"][1] <= 4096, stats
+    assert stats["differ"] < 0.15 and stats["more_than_one_ulp"] < 0.1, stats
+    ulp_ap = np.abs(gap.view(np.int32).astype(np.int64) - rap.view(np.int32).astype(np.int64))
+    assert int(ulp_ap.max()) <= 2 and float((ulp_ap > 0).mean()) < 1e-2, (int(ulp_ap.max()), float((ulp_ap > 0).mean()))
     rl, rm, rb = analysis_files(a_ref, wav, tmp_path, "refc", (5, F, 50, 25))
     gl, gm, gb = analysis_files(a_gpu, wav, tmp_path, "gpuc", (5, F, 50, 25))
     np.testing.assert_allclose(gl, rl, atol=1e-6, rtol=0)
