@@ -537,7 +537,9 @@ struct Workspace {
     return b;
   }
 };
-Workspace g_ws;
+// Never destroyed (a leaked singleton, like g_ctx): at process exit the HIP runtime may already be gone when static
+// destructors run, and a destroyed cache whose batches are then unreachable is what a leak checker reports.
+Workspace& g_ws = *new Workspace();
 
 void drop_in_failed(const DropInError& e) {
   (void)hipDeviceSynchronize();               // nothing of the failed call may still write into the staging buffers

@@ -54,3 +54,38 @@ def test_host_file_writer_under_asan_ubsan(tmp_path):
                                 UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
     assert r.returncode == 0 and "fileio ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_host_layer_of_the_c_abi_under_asan_ubsan(tmp_path):
+    """the host marshalling under sanitizers.  Every translation unit of the library is compiled
+    host-only (hipcc --cuda-host-only: no device code) with AddressSanitizer + UBSan and linked against
+    tests/hostsan/hip_stub.cpp -- "device" memory is host heap, kernels do not run -- and tests/hostsan/capi_harness.cpp
+    calls WORLD's C ABI like the reference CLIs: `double**` rows allocated one by one at their exact size, ten
+    utterance shapes (8 ... 48 kHz, 1 / 5 / 10 ms, non-default fft sizes, Harvest, 7 frames), the codec entry points,
+    refused arguments through the error handler, a box without a device, and device-allocation failures injected at a
+    dozen points of the run (every one must reach the handler; nothing may leak or touch freed memory)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    rt = [p for p in ("/opt/rocm/lib/llvm/lib/clang",) if os.path.isdir(p)]
+    if not os.path.exists(hipcc) or not rt:
+        pytest.skip("hipcc / clang sanitizer runtimes not installed")
+    out = tmp_path / "hs"
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "hostsan", "build_capi_harness.sh"), str(out)],
+                       capture_output=True, text=True, timeout=900)
+    exe = out / "capi_harness"
+    assert r.returncode == 0 and exe.exists(), (r.stdout[-2000:], r.stderr[-2000:],
+                                                  [open(p).read()[-600:] for p in map(str, out.glob("*.log")) if os.path.getsize(p)])
+    env = dict(os.environ, ASAN_OPTIONS="abort_on_error=0:halt_on_error=1:detect_leaks=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+
+    def run(**extra):
+        p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=dict(env, **extra))
+        text = p.stdout + p.stderr
+        assert p.returncode == 0, text[-4000:]
+        assert "AddressSanitizer" not in text and "LeakSanitizer" not in text and "runtime error" not in text, text[-4000:]
+        return text
+
+    text = run()
+    assert "capi ok" in text and "device allocations" in text
+    assert "capi no-device ok" in run(HIP_STUB_DEVICES="0")
+    for n in (0, 1, 3, 8, 21, 34, 55, 89, 120):
+        assert "handler:" in run(HIP_STUB_FAIL_MALLOC_AFTER=str(n))
