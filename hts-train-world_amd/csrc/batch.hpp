@@ -60,6 +60,22 @@ struct Context {
   hipEvent_t ev_f0 = nullptr, ev_prep = nullptr, ev_d4c = nullptr, ev_rare = nullptr;
   hipEvent_t ev_pulse[2] = {nullptr, nullptr}, ev_ola[2] = {nullptr, nullptr};   // synthesis_render's two response halves
   int ensure_side();                 // the second stream and its events, created on first use
+  // Dio's filters -- low-cut taps, Nuttall windows and their block spectra (fftconv.hpp) -- depend on the options and
+  // the sampling rate only, not on the utterances: built once per context and configuration and shared by every batch
+  // (the drop-in API makes a batch per utterance length: rebuilding them per batch was 0.1 ms of every Dio call)
+  struct DioFilters {
+    int fs, speed;
+    double f0_floor, f0_ceil, channels;
+    double* d_lowcut;
+    double* d_win;
+    void* d_H;
+  };
+  std::vector<DioFilters> dio_filters;
+  // likewise: D4C's Nuttall window by length (a function of the sampling rate) and StoneMask's DFT twiddle table
+  std::vector<std::pair<int, double*>> nuttall_windows;
+  std::vector<std::pair<int, double*>> dc_removers;   // Synthesis' GetDCRemover table by fft_size (a one-thread kernel:
+                                                      // 0.29 ms in front of every Synthesis() of a new utterance length)
+  void* d_sm_twid = nullptr;
   // optional per-kernel HIP-event timing on `stream` (bench.py's roofline leg)
   bool timing = false;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> timed;
@@ -151,9 +167,9 @@ struct Batch {
   int* d_perm_d4c = nullptr;         // [total_f]
   int* d_part_cnt_d4c = nullptr;     // [total_f / 1024 + 2]
   int* d_part_n_d4c = nullptr;       // [4]
-  void* d_sm_twid = nullptr;         // StoneMask's DFT twiddle table (stonemask.hip)
+  void* d_sm_twid = nullptr;         // StoneMask's DFT twiddle table (stonemask.hip): the context's, not owned
   // D4C tables
-  double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity
+  double* d_d4c_window = nullptr;    // Nuttall window of GetCoarseAperiodicity: the context's, not owned (non-null = D4C's tables are ready)
   int* d_utt_total = nullptr;        // [n_utt] LoveTrain randn totals
   double* d_d4c_big = nullptr;       // fft_size_d4c 4096: centroid quarters, centroid, group delay, coarse values per frame
   // DIO workspace
@@ -161,6 +177,7 @@ struct Batch {
   void* dio_host = nullptr;          // DioHost (dio.hip)
   double* d_dio_lowcut = nullptr;    // low-cut FIR taps by lag
   double* d_dio_win = nullptr;       // Nuttall low-pass windows, all bands
+  void* d_dio_desc = nullptr;        // ONE block holding the per-utterance tables below (fft, ylen, offsets): one upload
   int* d_dio_fft = nullptr;          // [n_utt] the reference's fft_size (circular indexing)
   double* d_dio_ws = nullptr;        // [3][total_f] contour work arrays
   void* d_dio_H = nullptr;           // filter spectra of the FFT-convolution path (fftconv.hpp)
@@ -202,10 +219,11 @@ struct Batch {
   int* d_pulse_first = nullptr;      // first pulse at or after every 128th sample of an utterance (the overlap-add's table)
   int* d_syn_order = nullptr;        // [2 n_utt] the identity, then the utterances by output length (shortest first)
   std::vector<int> syn_sorted;       // host copy of the second half
+  std::vector<int> syn_order_host;   // what d_syn_order was uploaded from: kept alive, so the upload needs no wait
   void* d_pulse_rec = nullptr;       // [pulse_rec_cap] PulseRec (synthesis.hip), grown on demand
   int64_t pulse_rec_cap = 0;
   int* d_pulse_perm = nullptr;       // [cap] voiced-first pulse order of a chunk, then n, then block counts
-  double* d_dc_remover = nullptr;    // [fft_size]
+  double* d_dc_remover = nullptr;    // [fft_size]: the context's, not owned
   int64_t syn_total_p = 0, syn_chunk = 0;   // pulses of the prepared synthesis, pulses per piece (half of the response scratch)
   bool syn_warm = false;                    // launch_analyze_synthesize has run once on this batch
 

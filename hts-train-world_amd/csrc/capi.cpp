@@ -128,6 +128,19 @@ void WorldMi355DestroyContext(WorldMi355Context* h) {
   c.timing_clear();
   if (c.d_rng) wm::dev_free(c.d_rng);
   if (c.d_scratch) wm::dev_free(c.d_scratch);
+  for (auto& f : c.dio_filters) {
+    if (f.d_lowcut) wm::dev_free(f.d_lowcut);
+    if (f.d_win) wm::dev_free(f.d_win);
+    if (f.d_H) wm::dev_free(f.d_H);
+  }
+  c.dio_filters.clear();
+  for (auto& w : c.nuttall_windows)
+    if (w.second) wm::dev_free(w.second);
+  c.nuttall_windows.clear();
+  for (auto& w : c.dc_removers)
+    if (w.second) wm::dev_free(w.second);
+  c.dc_removers.clear();
+  if (c.d_sm_twid) wm::dev_free(c.d_sm_twid);
   if (c.h_pulse_info) hipHostFree(c.h_pulse_info);
   if (c.own_stream) hipStreamDestroy(c.stream);
   if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }

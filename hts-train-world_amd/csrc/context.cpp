@@ -356,10 +356,10 @@ void codec_free(void* p);
 void vibrato_free(void* p);
 
 void free_batch_buffers(Batch& b) {
-  void* ptrs[] = {b.d_arena, b.d_perm2, b.d_sm_twid, b.d_d4c_window, b.d_utt_total, b.d_d4c_big,
-                  b.d_dio_lowcut, b.d_dio_win, b.d_dio_fft, b.d_dio_ws, b.d_dio_H, b.d_dio_edges, b.d_dio_ylen, b.d_dio_y, b.d_dio_tmp,
-                  b.d_dio_yoff, b.d_dio_toff, b.d_dio_mean, b.d_dio_mean_part, b.d_dio_z,
-                  b.d_dio_z_off, b.d_dio_events, b.d_dio_ev_off, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_slot_off, b.d_dio_cand,
+  void* ptrs[] = {b.d_arena, b.d_perm2, b.d_utt_total, b.d_d4c_big,
+                  // (Dio's filters are the context's, its per-utterance tables live in d_dio_desc)
+                  b.d_dio_desc, b.d_dio_ws, b.d_dio_edges, b.d_dio_y, b.d_dio_tmp, b.d_dio_mean, b.d_dio_mean_part, b.d_dio_z,
+                  b.d_dio_events, b.d_dio_ev_cnt, b.d_dio_tile_cnt, b.d_dio_slots, b.d_dio_cand,
                   b.d_dio_score, b.d_syn_arena, b.d_pulse_rec, b.d_pulse_perm};
   for (void* p : ptrs)
     if (p) dev_free(p);

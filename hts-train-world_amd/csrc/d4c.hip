@@ -664,21 +664,27 @@ int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_
   // Nuttall window table for GetCoarseAperiodicity (d4c.cpp:356-359, common.cpp:113-121)
   const int wl = (int)(kFreqInterval * FD / fs) * 2 + 1;
   if (!b.d_d4c_window) {
-    std::vector<double> w((size_t)wl);
-    for (int i = 0; i < wl; ++i) {
-      double tmp = i / (wl - 1.0);
-      w[(size_t)i] = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) + 0.144232 * cos(4.0 * kPi * tmp) -
-                     0.012604 * cos(6.0 * kPi * tmp);
-    }
     double* dw = nullptr;
-    rc = wm_check(dev_alloc(&dw, sizeof(double) * (size_t)wl));
-    if (rc) return rc;
-    rc = wm_check(hipMemcpyAsync(dw, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
-    if (!rc) rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
-    if (!rc) rc = wm_check(dev_alloc(&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
+    for (const auto& e : c.nuttall_windows)
+      if (e.first == wl) dw = e.second;
+    if (!dw) {                                           // once per context and sampling rate
+      std::vector<double> w((size_t)wl);
+      for (int i = 0; i < wl; ++i) {
+        double tmp = i / (wl - 1.0);
+        w[(size_t)i] = 0.355768 - 0.487396 * cos(2.0 * kPi * tmp) + 0.144232 * cos(4.0 * kPi * tmp) -
+                       0.012604 * cos(6.0 * kPi * tmp);
+      }
+      rc = wm_check(dev_alloc(&dw, sizeof(double) * (size_t)wl));
+      if (rc) return rc;
+      rc = wm_check(hipMemcpyAsync(dw, w.data(), sizeof(double) * (size_t)wl, hipMemcpyHostToDevice, st));
+      if (!rc) rc = wm_check(hipStreamSynchronize(st));   // w is a stack-lifetime buffer
+      if (rc) { dev_free(dw); return rc; }
+      c.nuttall_windows.push_back(std::make_pair(wl, dw));
+    }
+    if (!b.d_utt_total) rc = wm_check(dev_alloc(&b.d_utt_total, sizeof(int) * (size_t)b.n_utt));
     if (!rc && !b.d_perm2)                               // StoneMask may have taken it already
       rc = wm_check(dev_alloc(&b.d_perm2, sizeof(int) * (size_t)(b.total_f > 0 ? b.total_f : 1)));
-    if (rc) { dev_free(dw); return rc; }
+    if (rc) return rc;
     b.d_d4c_window = dw;
   }
   D4CTables tab;

@@ -16,6 +16,7 @@
 //   dio_candidate_kernel interp1 of the four interval tracks, mean/std score  dio.cpp:441-508, 562-567
 //   dio_fix_kernel       best band + FixStep1..4                    dio.cpp:112-289
 #include <math.h>
+#include <string.h>
 
 #include "batch.hpp"
 #include "common.hpp"
@@ -472,18 +473,20 @@ struct DioHost {
   std::vector<double> lowcut, win;
 };
 
-// frees every device buffer dio_setup() allocates and clears the pointers
+// frees every device buffer dio_setup() allocates and clears the pointers (the filters belong to the context)
 static void dio_release(Batch& b) {
-  void** ptrs[] = {(void**)&b.d_dio_lowcut, (void**)&b.d_dio_win, (void**)&b.d_dio_fft, (void**)&b.d_dio_ylen,
-                   (void**)&b.d_dio_yoff, (void**)&b.d_dio_toff, (void**)&b.d_dio_z_off, (void**)&b.d_dio_ev_off,
-                   (void**)&b.d_dio_mean, (void**)&b.d_dio_mean_part, (void**)&b.d_dio_y, (void**)&b.d_dio_tmp,
-                   (void**)&b.d_dio_z, (void**)&b.d_dio_events, (void**)&b.d_dio_ev_cnt, (void**)&b.d_dio_tile_cnt,
-                   (void**)&b.d_dio_slot_off, (void**)&b.d_dio_slots, (void**)&b.d_dio_cand, (void**)&b.d_dio_score,
-                   (void**)&b.d_dio_ws, (void**)&b.d_dio_H};
+  void** ptrs[] = {(void**)&b.d_dio_desc, (void**)&b.d_dio_mean, (void**)&b.d_dio_mean_part, (void**)&b.d_dio_y,
+                   (void**)&b.d_dio_tmp, (void**)&b.d_dio_z, (void**)&b.d_dio_events, (void**)&b.d_dio_ev_cnt,
+                   (void**)&b.d_dio_tile_cnt, (void**)&b.d_dio_slots, (void**)&b.d_dio_cand, (void**)&b.d_dio_score,
+                   (void**)&b.d_dio_ws};
   for (void** p : ptrs) {
     if (*p) dev_free(*p);
     *p = nullptr;
   }
+  b.d_dio_lowcut = b.d_dio_win = nullptr;
+  b.d_dio_H = nullptr;
+  b.d_dio_fft = b.d_dio_ylen = nullptr;
+  b.d_dio_yoff = b.d_dio_toff = b.d_dio_z_off = b.d_dio_ev_off = b.d_dio_slot_off = nullptr;
 }
 
 static int dio_setup(Batch& b) {
@@ -548,22 +551,39 @@ static int dio_setup(Batch& b) {
     b.dio_ev_off[(size_t)u + 1] = b.dio_ev_off[(size_t)u] + (int64_t)m.nb * 4 * (ylen / 2 + 2);
   }
   int rc = WM_OK;
-  auto up = [&](void** dst, const void* src, size_t bytes) {
-    if (rc) return;
-    rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
-    if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-  };
-  up((void**)&b.d_dio_lowcut, H->lowcut.data(), sizeof(double) * H->lowcut.size());
-  up((void**)&b.d_dio_win, H->win.data(), sizeof(double) * H->win.size());
-  up((void**)&b.d_dio_fft, fftn.data(), sizeof(int) * fftn.size());
-  up((void**)&b.d_dio_ylen, ylens.data(), sizeof(int) * ylens.size());
-  if (m.ratio > 1) {
-    up((void**)&b.d_dio_yoff, yoff.data(), sizeof(int64_t) * yoff.size());
-    up((void**)&b.d_dio_toff, toff.data(), sizeof(int64_t) * toff.size());
-    b.dio_tot_y = yoff[(size_t)b.n_utt];
+  // slot offsets of the staged events (needed below, part of the same upload)
+  std::vector<int64_t> soff((size_t)b.n_utt + 1, 0);
+  for (int u = 0; u < b.n_utt; ++u)
+    soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nb * 4 * dio_tiles(ylens[(size_t)u], m.step) * kZcSlot;
+  if (m.ratio > 1) b.dio_tot_y = yoff[(size_t)b.n_utt];
+  // The per-utterance tables in ONE block and one upload (a batch per utterance length is what the drop-in API makes:
+  // eight synchronous copies of a few bytes each were 0.1 ms of every Dio call).  Sections are 8-byte aligned.
+  {
+    const size_t n = (size_t)b.n_utt, n1 = n + 1;
+    const size_t ints = (2 * n + 1) & ~(size_t)1;                     // fft, ylen (padded to a multiple of two ints)
+    std::vector<int64_t> blob(ints / 2 + 5 * n1);
+    int* bi = (int*)blob.data();
+    for (size_t u = 0; u < n; ++u) { bi[u] = fftn[u]; bi[n + u] = ylens[u]; }
+    int64_t* bl = blob.data() + ints / 2;
+    memcpy(bl + 0 * n1, yoff.data(), 8 * n1);
+    memcpy(bl + 1 * n1, toff.data(), 8 * n1);
+    memcpy(bl + 2 * n1, b.dio_z_off.data(), 8 * n1);
+    memcpy(bl + 3 * n1, b.dio_ev_off.data(), 8 * n1);
+    memcpy(bl + 4 * n1, soff.data(), 8 * n1);
+    rc = wm_check(dev_alloc(&b.d_dio_desc, 8 * blob.size()));
+    if (!rc) rc = wm_check(hipMemcpy(b.d_dio_desc, blob.data(), 8 * blob.size(), hipMemcpyHostToDevice));
+    if (!rc) {
+      int* di = (int*)b.d_dio_desc;
+      int64_t* dl = (int64_t*)b.d_dio_desc + ints / 2;
+      b.d_dio_fft = di;
+      b.d_dio_ylen = di + n;
+      b.d_dio_yoff = m.ratio > 1 ? dl + 0 * n1 : nullptr;
+      b.d_dio_toff = m.ratio > 1 ? dl + 1 * n1 : nullptr;
+      b.d_dio_z_off = dl + 2 * n1;
+      b.d_dio_ev_off = dl + 3 * n1;
+      b.d_dio_slot_off = dl + 4 * n1;
+    }
   }
-  up((void**)&b.d_dio_z_off, b.dio_z_off.data(), sizeof(int64_t) * b.dio_z_off.size());
-  up((void**)&b.d_dio_ev_off, b.dio_ev_off.data(), sizeof(int64_t) * b.dio_ev_off.size());
   auto al = [&](void** dst, size_t bytes) {
     if (rc) return;
     rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
@@ -579,53 +599,76 @@ static int dio_setup(Batch& b) {
   al((void**)&b.d_dio_ev_cnt, sizeof(int) * (size_t)b.n_utt * m.nb * 4);
   al((void**)&b.d_dio_tile_cnt,
      sizeof(int) * (size_t)b.n_utt * m.nb * 4 * ((size_t)dio_tiles(b.max_x_len / m.ratio + 1, m.step) + 1));
-  {
-    std::vector<int64_t> soff((size_t)b.n_utt + 1, 0);
-    for (int u = 0; u < b.n_utt; ++u)
-      soff[(size_t)u + 1] = soff[(size_t)u] + (int64_t)m.nb * 4 * dio_tiles(ylens[(size_t)u], m.step) * kZcSlot;
-    up((void**)&b.d_dio_slot_off, soff.data(), sizeof(int64_t) * soff.size());
-    al((void**)&b.d_dio_slots, sizeof(double) * (size_t)soff[(size_t)b.n_utt]);
-  }
+  al((void**)&b.d_dio_slots, sizeof(double) * (size_t)soff[(size_t)b.n_utt]);
   al((void**)&b.d_dio_cand, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_score, sizeof(double) * (size_t)m.nb * (size_t)b.total_f);
   al((void**)&b.d_dio_ws, sizeof(double) * 3 * (size_t)b.total_f);
-  // filter spectra of the FFT-convolution path: [0] low-cut (block lc_conv), [1 .. nb] bands (block band_conv)
-  if (!rc && (m.band_conv || m.lc_conv)) {
-    const size_t n_lc = m.lc_conv ? (size_t)m.lc_conv / 2 + 1 : 0, n_bd = m.band_conv ? (size_t)m.band_conv / 2 + 1 : 0;
-    al((void**)&b.d_dio_H, sizeof(cpx) * (n_lc + (size_t)m.nb * n_bd));
-    std::vector<int> off((size_t)m.nb + 1), nt((size_t)m.nb + 1), dl((size_t)m.nb + 1);
-    off[0] = 0; nt[0] = 2 * m.cut + 1; dl[0] = 0;
-    for (int i = 0; i < m.nb; ++i) {
-      off[(size_t)i + 1] = m.win_off[i];
-      nt[(size_t)i + 1] = 4 * m.hal[i];
-      dl[(size_t)i + 1] = 2 * (m.hal[0] - m.hal[i]);
+  // The filters: the context's, by configuration.  Taps and windows as the reference designs them (above); the filter
+  // spectra of the FFT-convolution path: [0] low-cut (block lc_conv), [1 .. nb] bands (block band_conv).
+  if (!rc) {
+    Context& c = *b.ctx;
+    const Context::DioFilters* hit = nullptr;
+    for (const auto& f : c.dio_filters)
+      if (f.fs == p.fs && f.speed == m.ratio && f.f0_floor == p.f0_floor && f.f0_ceil == p.f0_ceil &&
+          f.channels == p.channels_in_octave)
+        hit = &f;
+    if (!hit) {
+      Context::DioFilters f{p.fs, m.ratio, p.f0_floor, p.f0_ceil, p.channels_in_octave, nullptr, nullptr, nullptr};
+      auto up = [&](void** dst, const void* src, size_t bytes) {
+        if (rc) return;
+        rc = wm_check(dev_alloc(dst, bytes ? bytes : 8));
+        if (!rc && bytes) rc = wm_check(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+      };
+      up((void**)&f.d_lowcut, H->lowcut.data(), sizeof(double) * H->lowcut.size());
+      up((void**)&f.d_win, H->win.data(), sizeof(double) * H->win.size());
+      if (!rc && (m.band_conv || m.lc_conv)) {
+        const size_t n_lc = m.lc_conv ? (size_t)m.lc_conv / 2 + 1 : 0, n_bd = m.band_conv ? (size_t)m.band_conv / 2 + 1 : 0;
+        rc = wm_check(dev_alloc(&f.d_H, sizeof(cpx) * (n_lc + (size_t)m.nb * n_bd)));
+        std::vector<int> desc(3 * ((size_t)m.nb + 1));
+        const int n1 = m.nb + 1;
+        desc[0] = 0; desc[(size_t)n1] = 2 * m.cut + 1; desc[2 * (size_t)n1] = 0;
+        for (int i = 0; i < m.nb; ++i) {
+          desc[(size_t)i + 1] = m.win_off[i];
+          desc[(size_t)n1 + i + 1] = 4 * m.hal[i];
+          desc[2 * (size_t)n1 + i + 1] = 2 * (m.hal[0] - m.hal[i]);
+        }
+        int* d_desc = nullptr;
+        up((void**)&d_desc, desc.data(), sizeof(int) * desc.size());
+        if (!rc) {
+          cpx* Hs = (cpx*)f.d_H;
+          hipStream_t st = c.stream;
+          if (m.lc_conv == 2048)
+            hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(1), dim3(64), 0, st, f.d_lowcut, d_desc, d_desc + n1,
+                               d_desc + 2 * n1, Hs);
+          else if (m.lc_conv == 4096)
+            hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(1), dim3(64), 0, st, f.d_lowcut, d_desc, d_desc + n1,
+                               d_desc + 2 * n1, Hs);
+          if (m.band_conv == 4096)
+            hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(m.nb), dim3(64), 0, st, f.d_win, d_desc + 1,
+                               d_desc + n1 + 1, d_desc + 2 * n1 + 1, Hs + n_lc);
+          else if (m.band_conv)
+            hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(m.nb), dim3(64), 0, st, f.d_win, d_desc + 1,
+                               d_desc + n1 + 1, d_desc + 2 * n1 + 1, Hs + n_lc);
+          rc = wm_check(hipGetLastError());
+          if (!rc) rc = wm_check(hipStreamSynchronize(st));
+        }
+        if (d_desc) dev_free(d_desc);
+      }
+      if (rc) {
+        if (f.d_lowcut) dev_free(f.d_lowcut);
+        if (f.d_win) dev_free(f.d_win);
+        if (f.d_H) dev_free(f.d_H);
+      } else {
+        // kept for the life of the context (about 150 KB per configuration; batches hold the pointers)
+        c.dio_filters.push_back(f);
+        hit = &c.dio_filters.back();
+      }
     }
-    int* d_desc = nullptr;
-    std::vector<int> desc;
-    desc.insert(desc.end(), off.begin(), off.end());
-    desc.insert(desc.end(), nt.begin(), nt.end());
-    desc.insert(desc.end(), dl.begin(), dl.end());
-    up((void**)&d_desc, desc.data(), sizeof(int) * desc.size());
     if (!rc) {
-      const int n1 = m.nb + 1;
-      cpx* H = (cpx*)b.d_dio_H;
-      hipStream_t st = b.ctx->stream;
-      if (m.lc_conv == 2048)
-        hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(1), dim3(64), 0, st, b.d_dio_lowcut, d_desc, d_desc + n1,
-                           d_desc + 2 * n1, H);
-      else if (m.lc_conv == 4096)
-        hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(1), dim3(64), 0, st, b.d_dio_lowcut, d_desc, d_desc + n1,
-                           d_desc + 2 * n1, H);
-      if (m.band_conv == 4096)
-        hipLaunchKernelGGL(conv_spectrum_kernel<4096>, dim3(m.nb), dim3(64), 0, st, b.d_dio_win, d_desc + 1,
-                           d_desc + n1 + 1, d_desc + 2 * n1 + 1, (cpx*)b.d_dio_H + n_lc);
-      else if (m.band_conv)
-        hipLaunchKernelGGL(conv_spectrum_kernel<2048>, dim3(m.nb), dim3(64), 0, st, b.d_dio_win, d_desc + 1,
-                           d_desc + n1 + 1, d_desc + 2 * n1 + 1, H + n_lc);
-      rc = wm_check(hipGetLastError());
-      if (!rc) rc = wm_check(hipStreamSynchronize(st));
+      b.d_dio_lowcut = hit->d_lowcut;
+      b.d_dio_win = hit->d_win;
+      b.d_dio_H = hit->d_H;
     }
-    if (d_desc) dev_free(d_desc);
   }
   if (rc) {
     // nothing half-built stays behind: a retry starts from scratch instead of leaking H and the buffers above

@@ -253,11 +253,14 @@ int launch_stonemask(Batch& b, const double* d_x, const double* d_t, const doubl
   const int fs = b.p.fs;
   const int64_t tf = b.total_f;
   if (tf <= 0) return WM_OK;
-  if (!b.d_sm_twid) {
-    int rc = wm_check(dev_alloc(&b.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
+  if (!c.d_sm_twid) {                       // once per context (the table depends on nothing)
+    int rc = wm_check(dev_alloc(&c.d_sm_twid, sizeof(cpx) * (size_t)kSmTwid));
     if (rc) return rc;
-    hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)b.d_sm_twid);
+    hipLaunchKernelGGL(sm_twiddle_kernel, dim3(kSmTwid / 256), dim3(256), 0, c.stream, (cpx*)c.d_sm_twid);
+    rc = wm_check(hipStreamSynchronize(c.stream));          // later calls may come on other streams
+    if (rc) return rc;
   }
+  b.d_sm_twid = c.d_sm_twid;
   // The output is cleared before the list is made from d_f0: the two must not be the same array (the reference's
   // StoneMask takes them as separate arrays too, stonemask.h:27-29); refused rather than answered with zeros.
   if (d_out == d_f0) {

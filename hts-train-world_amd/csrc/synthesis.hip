@@ -957,9 +957,21 @@ static int synthesis_arena(Batch& b) {
   size_t at = 0;
   auto take = [&](size_t bytes) { const size_t o = at; at = (at + (bytes ? bytes : 8) + 255) & ~(size_t)255; return o; };
   const size_t o_idx = take(4 * ny), o_shift = take(8 * ny), o_vuv = take(8 * ny), o_phase = take(8 * ny);
-  const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1)), o_dcr = take(8 * (size_t)F);
+  const size_t o_cnt = take(4 * nu), o_tile = take(4 * nu * tiles), o_off = take(8 * (nu + 1));
   const size_t o_first = take(4 * (ny / kOlaStep + 2 * nu + 4));
   const size_t o_order = take(4 * 2 * nu);
+  // the DC remover (GetDCRemover, synthesis.cpp:322-334) depends on fft_size only: once per context
+  double* dcr = nullptr;
+  for (const auto& e : c.dc_removers)
+    if (e.first == F) dcr = e.second;
+  if (!dcr) {
+    int rc0 = wm_check(dev_alloc(&dcr, sizeof(double) * (size_t)F));
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, c.stream, F, dcr);
+    rc0 = wm_check(hipStreamSynchronize(c.stream));                // later calls may come on other streams
+    if (rc0) { dev_free(dcr); return rc0; }
+    c.dc_removers.push_back(std::make_pair(F, dcr));
+  }
   unsigned char* base = nullptr;
   int rc = wm_check(dev_alloc(&base, at));
   if (rc) return rc;
@@ -972,17 +984,18 @@ static int synthesis_arena(Batch& b) {
   b.d_pulse_idx = (int*)(base + o_idx); b.d_pulse_shift = (double*)(base + o_shift);
   b.d_vuv = (double*)(base + o_vuv); b.d_phase = (double*)(base + o_phase);
   b.d_pulse_cnt = (int*)(base + o_cnt); b.d_pulse_tile_cnt = (int*)(base + o_tile);
-  b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = (double*)(base + o_dcr);
+  b.d_pulse_off = (int64_t*)(base + o_off); b.d_dc_remover = dcr;
   b.d_pulse_first = (int*)(base + o_first);
   b.d_syn_order = (int*)(base + o_order);
   // [0, n): the identity; [n, 2 n): the utterances by output length, shortest first (stable)
-  std::vector<int> order(2 * nu);
+  std::vector<int>& order = b.syn_order_host;                    // the batch's: alive until the copy has been made
+  order.resize(2 * nu);
   for (size_t u = 0; u < nu; ++u) order[u] = order[nu + u] = (int)u;
   std::stable_sort(order.begin() + (long)nu, order.end(), [&](int x, int y) { return b.y_len[(size_t)x] < b.y_len[(size_t)y]; });
   b.syn_sorted.assign(order.begin() + (long)nu, order.end());
+  // (a copy from pageable memory returns once the source has been read or staged: no wait here -- it was 20 us of
+  // every Synthesis() of a new utterance length)
   rc = wm_check(hipMemcpyAsync(b.d_syn_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, c.stream));
-  rc = rc ? rc : wm_check(hipStreamSynchronize(c.stream));      // `order` is pageable and goes out of scope
-  hipLaunchKernelGGL(synth_dc_remover_kernel, dim3(1), dim3(64), 0, c.stream, F, b.d_dc_remover);
   return rc;
 }
 
