@@ -574,6 +574,7 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
 }  // namespace wm
 #include "d4c_big.hpp"
 #include "d4c_q.hpp"
+#include "d4c_wide.hpp"
 namespace wm {
 
 // fft_size_d4c = 4096 / 8192: the four-kernel form of d4c_big.hpp for the usual frames
@@ -629,7 +630,7 @@ static int launch_d4c_big(Batch& b, const double* d_x, const double* d_t, const 
   const int64_t blocks = (tf + 3) / 4;
   hipLaunchKernelGGL(d4cb_output_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, fs, tab,
                      b.p.fft_size, tf, perm, nl,
-                     D4cRunRarePred{d_f0, (const double*)b.d_ap0, b.p.d4c_threshold, FD <= 4096 ? FD : 0, fs},
+                     D4cRunRarePred{d_f0, (const double*)b.d_ap0, b.p.d4c_threshold, FD, fs},
                      (const double*)COARSE, d_ap);
   return wm_check(hipGetLastError());
 }
@@ -748,9 +749,9 @@ int d4c_rare(Batch& b, const double* d_x, const double* d_t, const double* d_f0,
   // The RARE launch on its own: its rows are its own (the other kernels leave them alone), so it needs nothing of
   // d4c_run() but the lists -- and behind the usual kernel it cost 62 us of every pass with its list empty (the default
   // f0 range), for a kernel whose every wave leaves at its fourth instruction.  Its waves need a SIMD to themselves:
-  // beside another kernel the launch sits until that one drains, so the one-call forms give it a stream of its own.  At 8192 there is no one-kernel form (its
-  // transform would be 4096 complex points on one wavefront): frames with f0 >= fs / 16 (6 kHz at 96 kHz) keep the
-  // default row there.
+  // beside another kernel the launch sits until that one drains, so the one-call forms give it a stream of its own.  At 8192 there is no one-wavefront form (its
+  // transform would be 4096 complex points on one wavefront): frames with f0 >= fs / 16 (6 kHz at 96 kHz) go to
+  // d4c_wide_kernel, a workgroup per frame with direct DFTs (their windows are at most 65 samples).
 #define WM_D4C_RARE(FF)                                                                                   \
   case FF: {                                                                                              \
     const int per2_ = persistent_grid(c, d4c_kernel<FF, 1, true>, 64, (int64_t)1 << 40);           \
@@ -763,6 +764,13 @@ int d4c_rare(Batch& b, const double* d_x, const double* d_t, const double* d_f0,
     WM_D4C_RARE(1024)
     WM_D4C_RARE(2048)
     WM_D4C_RARE(4096)
+    case 8192: {               // one workgroup per frame, everything in LDS, direct DFTs (d4c_wide.hpp)
+      const int lds = (int)(sizeof(double) * D4cWideLds::doubles(8192));
+      allow_dynamic_lds(c, d4c_wide_kernel<8192>, lds);
+      hipLaunchKernelGGL(d4c_wide_kernel<8192>, dim3(imin(grid, c.num_cu)), dim3(kWideThreads), lds, st, d_x, b.d_x_off,
+                         b.d_x_len, b.d_frame_utt, d_t, d_f0, b.d_rng_off_d4c, c.d_rng, fs, tab, b.p.fft_size,
+                         (const int*)b.d_perm2, (const int*)(b.d_part_n_d4c + 1), d_ap);
+    } break;
   }
 #undef WM_D4C_RARE
   return wm_check(hipGetLastError());

@@ -9,9 +9,8 @@
 //   WM_UTT_TOO_SHORT         f0_length <= voice_range_minimum: Dio has no contour to fix (the reference returns
 //                            with f0 unwritten, dio.cpp:266; here f0 is all zero)
 //   WM_UTT_OUTPUT_NONFINITE  a NaN / Inf in the utterance's f0 / sp / ap rows (arrays given as NULL are skipped)
-//   WM_UTT_D4C_DEFAULT_ROWS  only where D4C's own transform has 8192 points (fs above 48.1 kHz): a frame with
-//                            f0 >= fs / 16 (6 kHz at 96 kHz), which the reference analyses and WorldMi355D4C leaves
-//                            at the default row 1 - 1e-12 (d4c.hip: no one-kernel form at that size)
+//   WM_UTT_D4C_DEFAULT_ROWS  kept for ABI compatibility, never set since round 5 (it marked frames with f0 >= fs / 16 at
+//                            fs above 48.1 kHz, which kept D4C's default row until d4c_wide.hpp analysed them)
 #include "batch.hpp"
 #include "common.hpp"
 
@@ -66,7 +65,10 @@ int launch_utterance_status(Batch& b, const double* d_x, const double* d_f0, con
   const int vrm = (int)(0.5 + 1000.0 / b.p.frame_period / b.p.f0_floor) * 2 + 1;   // dio.cpp:263-264
   // fft_size_d4c (d4c.cpp:344-346); the rare-frame kernel exists up to 4096 points
   const int fd = (int)pow(2.0, 1.0 + (int)(log(4.0 * b.p.fs / 47.0 + 1) / log(2.0)));
-  const int bin_limit = fd > 4096 ? fd / 16 : 0;
+  // (until round 5 frames with f0 >= fs / 16 kept D4C's default row where its transform has 8192 points, and were
+  // flagged here; d4c_wide_kernel analyses them now, so WM_UTT_D4C_DEFAULT_ROWS is never set any more)
+  const int bin_limit = 0;
+  (void)fd;
   hipLaunchKernelGGL(utterance_status_kernel, dim3(b.n_utt), dim3(256), 0, b.ctx->stream, b.total_x > 0 ? d_x : nullptr,
                      b.d_x_off, b.d_x_len, b.d_f_off, d_f0, d_sp, d_ap, b.p.fft_size / 2 + 1, vrm, (double)fd / b.p.fs,
                      bin_limit, d_status);

@@ -38,10 +38,7 @@ extern "C" {
 #define WM_OK 0
 #define WM_ERR_HIP 1              /* a HIP runtime call failed; see WorldMi355LastError() */
 #define WM_ERR_BAD_ARG 2
-#define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048,4096}; D4C's own size outside {1024,2048,4096,8192}.
-                                   * At D4C's own size 8192 (fs above 48.1 kHz: 88.2 / 96 kHz) frames with f0 >= fs / 16
-                                   * keep the default row 1 - 1e-12 where the reference analyses them: WM_OK is returned
-                                   * and WorldMi355UtteranceStatus reports WM_UTT_D4C_DEFAULT_ROWS for the utterance. */
+#define WM_ERR_UNSUPPORTED_FFT 3  /* fft_size outside {512,1024,2048,4096}; D4C's own size outside {1024,2048,4096,8192} */
 #define WM_ERR_NO_DEVICE 4        /* no HIP device: the product path never falls back to CPU */
 #define WM_ERR_UNSUPPORTED 5
 #define WM_ERR_IO 6                /* a file could not be written (WorldMi355WriteFiles); see WorldMi355LastError() */
@@ -140,7 +137,8 @@ int WorldMi355AnalyzeSynthesize(WorldMi355Batch* b, const double* x, double* t, 
 #define WM_UTT_INPUT_NONFINITE 1   /* NaN / Inf among the samples of x */
 #define WM_UTT_TOO_SHORT 2         /* f0_length <= Dio's voice_range_minimum: f0 is all zero (dio.cpp:263-266) */
 #define WM_UTT_OUTPUT_NONFINITE 4  /* NaN / Inf among the utterance's f0 / sp / ap */
-#define WM_UTT_D4C_DEFAULT_ROWS 8  /* fs above 48.1 kHz only: a frame with f0 >= fs / 16 kept D4C's default row */
+#define WM_UTT_D4C_DEFAULT_ROWS 8  /* never set since round 5 (kept for ABI compatibility): it marked frames with f0 >= fs / 16
+                                    * at fs above 48.1 kHz, which kept D4C's default row; they are analysed now */
 int WorldMi355UtteranceStatus(WorldMi355Batch* b, const double* x, const double* f0, const double* sp,
                               const double* ap, int* status);
 

@@ -338,33 +338,43 @@ def test_fft_size_4096_above_51khz(gpu, oracle, fs):
     b.close()
 
 
-def test_d4c_default_rows_above_fs_over_16_at_96khz(gpu, oracle):
-    """The one documented gap of D4C (include/world_mi355.h, WM_ERR_UNSUPPORTED_FFT): where its own transform has 8192
-    points, frames with f0 >= fs / 16 keep the default row (the reference analyses them).  Pinned: those frames read
-    1 - 1e-12, every other frame is the oracle's, and the utterance is reported through WM_UTT_D4C_DEFAULT_ROWS;
-    the same f0 values at 48 kHz (transform of 4096 points) are analysed and not flagged."""
+@pytest.mark.parametrize("fs", [96000, 88200, 48000])
+def test_d4c_above_fs_over_16_where_its_transform_has_8192_points(gpu, oracle, fs):
+    """Frames with f0 >= fs / 16 (the smoothing mirrors reach past an eighth of the spectrum).  Up to 48 kHz the
+    one-wavefront RARE kernel has taken them since round 2; where D4C's own transform has 8192 points (88.2 / 96 kHz)
+    they kept the default row until round 5 -- the one place the library differed from the reference on valid input.
+    d4c_wide_kernel (a workgroup per frame, direct DFTs) analyses them now: every frame is the oracle's, nothing is
+    flagged, and the frames around them are untouched by the extra launch."""
     torch, W, ctx = gpu
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
-    for fs, flagged in ((96000, True), (48000, False)):
-        x = sd.make_utterance(113, fs, duration=0.25)
-        t = np.arange(int(1000.0 * len(x) / fs / 5.0) + 1) * 0.005
-        f0 = np.full(len(t), 180.0)
-        f0[5] = fs / 16.0 + 50.0
-        f0[11] = fs / 16.0 - 50.0
-        b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x), len(x)])
-        xx, tt = dev(np.concatenate([x, x])), dev(np.concatenate([t, t]))
-        f2 = np.concatenate([f0, np.full(len(t), 180.0)])           # the second utterance has no such frame
-        ap = b.d4c(xx, tt, dev(f2))
-        st = b.utterance_status(xx, dev(f2), None, ap).cpu().numpy()
-        assert list(st) == ([8, 0] if flagged else [0, 0])
-        got = b.split_frames(ap)[0].cpu().numpy()
-        want = oracle.d4c(x, fs, t, f0, b.fft_size, 0.0)
-        keep = np.ones(len(t), dtype=bool)
-        if flagged:
-            keep[5] = False
-            assert np.all(got[5] == 1.0 - 1e-12) and not np.all(want[5] == 1.0 - 1e-12)
-        np.testing.assert_allclose(got[keep], want[keep], atol=AP_TOL, rtol=0)
-        b.close()
+    x = sd.make_utterance(113, fs, duration=0.25)
+    t = np.arange(int(1000.0 * len(x) / fs / 5.0) + 1) * 0.005
+    f0 = np.full(len(t), 180.0)
+    f0[5] = fs / 16.0 + 50.0
+    f0[11] = fs / 16.0 - 50.0
+    f0[17] = fs / 16.0                                   # the boundary itself
+    f0[23] = fs / 5.0                                    # mirrors of 40 % of the spectrum
+    f0[29] = fs / 2.0 - 3.0 * fs / 8192.0                # the widest the reference defines
+    f0[31] = 0.0
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x), len(x)])
+    xx, tt = dev(np.concatenate([x, x])), dev(np.concatenate([t, t]))
+    f2 = np.concatenate([f0, np.full(len(t), 180.0)])           # the second utterance has no such frame
+    ap = b.d4c(xx, tt, dev(f2))
+    st = b.utterance_status(xx, dev(f2), None, ap).cpu().numpy()
+    assert list(st) == [0, 0]
+    got = b.split_frames(ap)
+    want = oracle.d4c(x, fs, t, f0, b.fft_size, 0.0)
+    for k in (5, 17, 23, 29):
+        assert not np.all(want[k] == 1.0 - 1e-12)              # the reference does analyse them
+    np.testing.assert_allclose(got[0].cpu().numpy(), want, atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(got[1].cpu().numpy(), oracle.d4c(x, fs, t, np.full(len(t), 180.0), b.fft_size, 0.0),
+                               atol=AP_TOL, rtol=0)
+    # with LoveTrain deciding (threshold 0.85): the same frames, those it lets through
+    b85 = W.WorldBatch(ctx, W.default_params(fs, 5.0, d4c_threshold=0.85), x_lengths=[len(x)])
+    np.testing.assert_allclose(b85.d4c(dev(x), dev(t), dev(f0)).cpu().numpy(), oracle.d4c(x, fs, t, f0, b.fft_size, 0.85),
+                               atol=AP_TOL, rtol=0)
+    b85.close()
+    b.close()
 
 
 @pytest.mark.parametrize("fs,fp", [(16000, 1.0), (16000, 10.0), (16000, 2.5), (22050, 3.0), (48000, 4.0)])
