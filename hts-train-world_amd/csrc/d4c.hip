@@ -657,9 +657,11 @@ int d4c_prepare(Batch& b, const double* d_x, const double* d_t, const double* d_
   hipStream_t st = c.stream;
   const int fs = b.p.fs;
   const int FD = d4c_fft_size(fs), FL = lovetrain_fft_size(fs);
-  if (FD != FL || (FD != 1024 && FD != 2048 && FD != 4096 && FD != 8192)) {
-    return WM_ERR_UNSUPPORTED_FFT;
-  }
+  // D4C's own transform and LoveTrain's are sized independently (d4c.cpp:344-346, :261-263): they differ for fs in
+  // [12.0, 13.6), [24.1, 27.3) and [48.1, 54.6) kHz (2048 / 1024, 4096 / 2048, 8192 / 4096).  LoveTrain's transform is
+  // only run for a threshold above zero.
+  if (FD != 1024 && FD != 2048 && FD != 4096 && FD != 8192) return WM_ERR_UNSUPPORTED_FFT;
+  if (b.p.d4c_threshold > 0.0 && FL != 1024 && FL != 2048 && FL != 4096 && FL != 8192) return WM_ERR_UNSUPPORTED_FFT;
   int rc = c.ensure_rng(b.rng_bound_d4c());
   if (rc) return rc;
   // Nuttall window table for GetCoarseAperiodicity (d4c.cpp:356-359, common.cpp:113-121)

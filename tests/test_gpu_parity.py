@@ -377,6 +377,33 @@ def test_d4c_above_fs_over_16_where_its_transform_has_8192_points(gpu, oracle, f
     b.close()
 
 
+@pytest.mark.parametrize("fs", [12500, 25000, 50000])
+def test_rates_where_d4c_and_lovetrain_transforms_differ(gpu, oracle, fs):
+    """fs in [12.0, 13.6), [24.1, 27.3), [48.1, 54.6) kHz: D4C's own transform is twice LoveTrain's (d4c.cpp:344-346 against
+    :261-263).  Refused until round 5 (the two were required to be equal); the two kernels are sized independently."""
+    torch, W, ctx = gpu
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    x = sd.make_utterance(70 + fs // 1000, fs, duration=0.6)
+    r = oracle_chain(oracle, x, fs)
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x)])
+    t, f0, sp, ap = b.analyze(dev(x))
+    y = b.synthesize(f0, sp, ap)
+    assert ((f0.cpu().numpy() > 0) == (r["f0"] > 0)).all() and (r["f0"] > 0).sum() > 20
+    np.testing.assert_allclose(f0.cpu().numpy(), r["f0"], atol=F0_TOL, rtol=0)
+    sp_close(sp.cpu().numpy(), r["sp"])
+    np.testing.assert_allclose(ap.cpu().numpy(), r["ap"], atol=AP_TOL, rtol=0)
+    np.testing.assert_allclose(y.cpu().numpy(), r["y"], atol=Y_TOL, rtol=0)
+    b.close()
+    if fs < 15800:
+        # below 15.8 kHz D4CLoveTrainSub accumulates its power spectrum up to ceil(7900 fft / fs), past the Nyquist bin,
+        # i.e. over memory it never wrote (d4c.cpp:243-247): with a threshold above zero the reference is undefined there
+        return
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0, d4c_threshold=0.85), x_lengths=[len(x)])     # LoveTrain decides
+    ap85 = b.d4c(dev(x), dev(r["t"]), dev(r["f0"])).cpu().numpy()
+    np.testing.assert_allclose(ap85, oracle.d4c(x, fs, r["t"], r["f0"], r["F"], 0.85), atol=AP_TOL, rtol=0)
+    b.close()
+
+
 @pytest.mark.parametrize("fs,fp", [(16000, 1.0), (16000, 10.0), (16000, 2.5), (22050, 3.0), (48000, 4.0)])
 def test_other_frame_periods(gpu, oracle, fs, fp):
     """Frame periods other than 5 ms, including ones that are not a whole number of samples (rounding ties)."""
