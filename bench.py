@@ -968,6 +968,15 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
             longest = max(c8, host_side, w)
             return longest + (c8 + host_side + w - longest) / R
         pred8 = pass8(ncpu)
+
+        def pass8_all(cores):
+            # --writers all: no funnel -- every rank copies and writes its own eighth (the ranks share the node's cores)
+            ca = comp_max / k / 8.0
+            ha = phases["to_host"] / k / 8.0
+            w = wr * float(ncpu) / float(cores)
+            longest = max(ca, ha, w)
+            return longest + (ca + ha + w - longest) / R
+        by_cores_all = {str(c): round(pass8_all(c) * 1e3, 3) for c in (16, 64, 128)}
         by_cores = {str(c): round(pass8(c) * 1e3, 3) for c in (16, 64, 128)}
         speed_by_cores = {c: round(elapsed_max / steps / (v * 1e-3), 2) for c, v in by_cores.items()} if world == 1 else None
         line = {
@@ -1001,6 +1010,7 @@ def sweep_bench(env, ctx, counts, by_id, fs, fp, steps, warmup, cpu=True):
                           "speedup_over_this_run": round(elapsed_max / steps / pred8, 2) if world == 1 and pred8 > 0 else None,
                           "host_cores_assumed": ncpu, "writer_threads_assumed": io_threads,
                           "ms_per_step_by_host_cores": by_cores, "speedup_by_host_cores": speed_by_cores,
+                          "writers_all_ms_by_host_cores": by_cores_all,
                           "rank0_handicap": round(h8, 3),
                           "model": "max(compute/(7 + 1/handicap), gather + to_host, write) + (the other two stages) / "
                                    "rounds, from this run's phases; the writes are page-cache fills by two native threads "
