@@ -196,7 +196,12 @@ __global__ __launch_bounds__(kWideThreads) void d4c_wide_kernel(
     const int roff = rng_off[frame];
     const int Lw = 2 * matlab_round(2.0 * fs / cf0) + 1;
     double* row = ap + frame * (int64_t)out_bins;
-    if (Lw > kWideMaxTaps || wl > kWideMaxTaps) continue;             // cannot happen for this kernel's frames (f0 >= fs / 16)
+    if (Lw > kWideMaxTaps || wl > kWideMaxTaps) {
+      // cannot happen for this kernel's frames (f0 >= fs / 16: windows of at most 65 samples, slices of 513 / 557 taps);
+      // if a caller ever lists such a frame it gets the default row rather than an unwritten one
+      for (int i = threadIdx.x; i < out_bins; i += kWideThreads) row[i] = 1.0 - kSafe;
+      continue;
+    }
     // ---- GetStaticCentroid (d4c.cpp:125-142) ----
     for (int k = threadIdx.x; k <= H; k += kWideThreads) cen[k] = 0.0;
     __syncthreads();
