@@ -113,14 +113,30 @@ def wav_header(path):
         return w.getnframes(), w.getframerate()
 
 
+def outputs_complete(job, n_frames, fs, spec_dim=0, ap_dim=24):
+    """True when the three feature files of `job` = (wav, f0_out, sp_out, ap_out) exist with exactly the sizes the
+    analysis of this wav writes (float32: n_frames, n_frames x width, n_frames x width; width = CheapTrick's bins, or
+    spec_dim / ap_dim in the recipe's coded form, analysis.cpp:292-390).  The test behind `resume`: a run that was cut
+    short left its last files missing or short (the native writer creates, fills and closes file after file)."""
+    bins = capi.cheaptrick_fft_size(fs) // 2 + 1
+    want = (4 * n_frames, 4 * n_frames * (spec_dim if spec_dim else bins), 4 * n_frames * (ap_dim if spec_dim else bins))
+    try:
+        return all(os.path.getsize(str(p)) == w for p, w in zip(job[1:4], want))
+    except OSError:
+        return False
+
+
 def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ctx=None,
-                   max_batch_frames=MAX_BATCH_FRAMES, io_threads=8, gather=False):
+                   max_batch_frames=MAX_BATCH_FRAMES, io_threads=8, gather=False, resume=False):
     """jobs: [(wav, f0_out, sp_out, ap_out)].  Writes what `analysis wav f0 sp ap frame_period fft_size
     [spec_dim [ap_dim]]` writes for every job; returns the number of frames analysed by this rank.
 
     Every rank reads the wav HEADERS of the whole list (the partition needs the frame counts), but decodes only the
     utterances of its own shard, one batch at a time.  gather=False: every rank writes the files of its shard.
-    gather=True (BASELINE.json configs[3]): the float32 slabs go to rank 0 (sweep.ShardedSweep), which writes all files."""
+    gather=True (BASELINE.json configs[3]): the float32 slabs go to rank 0 (sweep.ShardedSweep), which writes all files.
+    resume=True (every rank writes its shard only): a rank skips the jobs of ITS shard whose outputs are complete
+    (outputs_complete) -- the partition is made on the whole list first, so ranks that start at different times agree on
+    it whatever is on disk; the reference's recipe re-runs every utterance (data/Makefile.in:206-216)."""
     import torch
     jobs = list(jobs)
     with ThreadPoolExecutor(io_threads) as pool:
@@ -134,12 +150,16 @@ def analysis_files(jobs, frame_period=5.0, fft_size=0, spec_dim=0, ap_dim=24, ct
                 raise ValueError("fft_size %d is not CheapTrick's size for %d Hz (%d)" % (fft_size, fs, own_size))
         own_ctx = ctx is None
         ctx = ctx or _own_context()
+        if gather and resume:
+            raise ValueError("resume goes with every rank writing its own shard (gather=False)")
         if gather:
             done = _analysis_gathered(jobs, heads, frame_period, spec_dim, ap_dim, ctx, max_batch_frames, io_threads)
             if own_ctx:
                 ctx.close()
             return done
         mine = _my_share(frames)
+        if resume:
+            mine = [i for i in mine if not outputs_complete(jobs[i], frames[i], heads[i][1], spec_dim, ap_dim)]
         done = 0
         writes = []
         for fs in sorted({heads[i][1] for i in mine}):
@@ -401,6 +421,8 @@ def main(argv=None):
         if name == "analysis":
             p.add_argument("--gather", action="store_true",
                            help="several ranks (torchrun): gather the features to rank 0, which writes every file")
+            p.add_argument("--resume", action="store_true",
+                           help="skip utterances whose three output files are already complete (a run that was cut short)")
         if name == "synth":
             p.add_argument("--fs", type=int, required=True)
     a = ap.parse_args(argv)
@@ -411,7 +433,7 @@ def main(argv=None):
             import torch.distributed as dist
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
             dist.init_process_group(os.environ.get("WM_BACKEND", "nccl"))
-        n = analysis_files(jobs, a.frame_period, a.fft_size, a.spec_dim, a.ap_dim, gather=a.gather)
+        n = analysis_files(jobs, a.frame_period, a.fft_size, a.spec_dim, a.ap_dim, gather=a.gather, resume=a.resume)
     else:
         n = synth_files(jobs, a.frame_period, a.fft_size, a.fs, a.spec_dim, a.ap_dim)
     print("complete. %d frames" % n)

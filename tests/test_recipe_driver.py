@@ -48,6 +48,51 @@ def test_sharing_of_jobs(monkeypatch):
     assert [i for g in groups for i in g] == [5, 0, 2, 3, 4, 1] and all(sum(costs[i] for i in g) <= 100 for g in groups)
 
 
+def test_outputs_complete_is_a_size_check(tmp_path):
+    """`resume` skips an utterance only when its three files have exactly the sizes its analysis writes."""
+    n, fs = 137, 16000                                        # frames, CheapTrick's fft 1024 -> 513 bins
+    job = ("x.wav", tmp_path / "a.f0", tmp_path / "a.sp", tmp_path / "a.ap")
+    assert not recipe.outputs_complete(job, n, fs)            # nothing there
+    (tmp_path / "a.f0").write_bytes(b"\0" * (4 * n))
+    (tmp_path / "a.sp").write_bytes(b"\0" * (4 * n * 513))
+    (tmp_path / "a.ap").write_bytes(b"\0" * (4 * n * 513 - 4))         # cut short
+    assert not recipe.outputs_complete(job, n, fs)
+    (tmp_path / "a.ap").write_bytes(b"\0" * (4 * n * 513))
+    assert recipe.outputs_complete(job, n, fs)
+    assert not recipe.outputs_complete(job, n, fs, spec_dim=50, ap_dim=25)     # raw files are not the coded ones
+    (tmp_path / "a.sp").write_bytes(b"\0" * (4 * n * 50))
+    (tmp_path / "a.ap").write_bytes(b"\0" * (4 * n * 25))
+    assert recipe.outputs_complete(job, n, fs, spec_dim=50, ap_dim=25)
+    assert not recipe.outputs_complete(job, n + 1, fs, spec_dim=50, ap_dim=25)
+
+
+@pytest.mark.gpu
+def test_driver_resumes_a_run_that_was_cut_short(gpu, tmp_path):
+    """analysis_files(resume=True): utterances whose files are complete are left alone (same bytes, same mtime), a
+    missing and a truncated one are analysed again -- and come out as in the uninterrupted run."""
+    specs = [(16000, 45, 0.6), (16000, 46, 0.9), (16000, 47, 0.4), (48000, 48, 0.5)]
+    jobs = []
+    for k, (fs, idx, dur) in enumerate(specs):
+        wav = tmp_path / f"r{k}.wav"
+        write_wav_py(wav, sd.make_utterance(idx, fs, duration=dur), fs)
+        jobs.append((wav, tmp_path / f"r{k}.lf0", tmp_path / f"r{k}.mgc", tmp_path / f"r{k}.bap"))
+    n_all = recipe.analysis_files(jobs, 5.0, 0, 50, 25)
+    want = {p: open(p, "rb").read() for j in jobs for p in j[1:]}
+    os.remove(jobs[1][2])                                     # one file of utterance 1 missing
+    with open(jobs[3][3], "r+b") as f:                        # utterance 3's last file cut short
+        f.truncate(os.path.getsize(jobs[3][3]) - 100)
+    before = {p: os.stat(p).st_mtime_ns for j in (jobs[0], jobs[2]) for p in j[1:]}
+    n_again = recipe.analysis_files(jobs, 5.0, 0, 50, 25, resume=True)
+    assert 0 < n_again < n_all
+    for p, data in want.items():
+        assert open(p, "rb").read() == data, p
+    for p, t in before.items():
+        assert os.stat(p).st_mtime_ns == t, p                 # untouched
+    assert recipe.analysis_files(jobs, 5.0, 0, 50, 25, resume=True) == 0
+    with pytest.raises(ValueError):
+        recipe.analysis_files(jobs, 5.0, 0, 50, 25, resume=True, gather=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("coded", [False, True])
 def test_driver_writes_the_clis_files(gpu, tmp_path, coded):
