@@ -66,7 +66,7 @@ struct HarvestWs {
   double* d_bf = nullptr; int* d_half = nullptr; int* d_tapoff = nullptr; double* d_taps = nullptr;
   double* d_y = nullptr; double* d_tmp = nullptr;
   double* d_mean_part = nullptr;               // [n_utt][kHvMeanTiles]
-  double* d_events = nullptr; int* d_evcnt = nullptr;
+  int* d_evcnt = nullptr;
   int* d_tile_cnt = nullptr; int tiles_max = 0;
   void* d_H = nullptr;                         // channel spectra of the FFT filter bank
   double* d_slots = nullptr; int64_t* d_slot_off = nullptr;
@@ -212,21 +212,6 @@ __global__ __launch_bounds__(64) void hv_band_scan_kernel(const int* __restrict_
                 evcnt + ((int64_t)u * nch + ch) * 4, threadIdx.x);
 }
 
-__global__ __launch_bounds__(256) void hv_band_compact_kernel(
-    const int* __restrict__ ylen_a, int nch, int step, int tiles_max, const int* __restrict__ tile_cnt,
-    const int64_t* __restrict__ slot_off, const double* __restrict__ slots, const int64_t* __restrict__ evoff,
-    double* __restrict__ events) {
-  __shared__ int lds_off[4 * (kZcCompactTiles + 1)];
-  const int u = blockIdx.y, ch = blockIdx.x;
-  const int ylen = ylen_a[u];
-  const int nt = hv_tiles(ylen, step);
-  const int cap = ylen / 2 + 2;
-  const int64_t slot_cap = (int64_t)nt * kZcSlot;
-  zc_compact_signal(slots + slot_off[u] + (int64_t)ch * 4 * slot_cap, slot_cap, nt,
-                    tile_cnt + ((int64_t)u * nch + ch) * (tiles_max + 1) * 4, events + evoff[u] + (int64_t)ch * 4 * cap, cap,
-                    lds_off);
-}
-
 // raw_f0_candidates[channel][frame] (harvest.cpp:240-293), stored [frame][channel]
 // GetF0CandidateContour(+Sub) (harvest.cpp:240-293): per channel the four zero-crossing tracks are interpolated
 // (interp1, matlabfunctions.cpp:136-182) at every basic frame time and averaged.  The frame times of an utterance
@@ -240,8 +225,9 @@ __global__ __launch_bounds__(256) void hv_band_compact_kernel(
 // Lanes of a wavefront are consecutive channels of the same run, so the stores are rows of raw[frame][channel].
 constexpr int kRawRun = 128;
 
+// (SlotList: zcfilter.hpp -- the edge lists are read where the filter bank staged them, no compaction pass)
 struct RawTrack {                 // one zero-crossing track of a channel, positioned on a knot interval
-  const double* e;                // fine edges, n + 1 of them
+  SlotList e;                     // fine edges, n + 1 of them
   int n;                          // knots (locations) 0 .. n-1
   int lo;                         // number of knots at or before the current time (histc's count)
   int k;                          // lo clamped to [1, n-1]: the interval [knot k-1, knot k]
@@ -257,7 +243,7 @@ __device__ __forceinline__ void raw_init(RawTrack& tr, double fs) {
   const int k = tr.lo < 1 ? 1 : (tr.lo > tr.n - 1 ? tr.n - 1 : tr.lo);
   tr.k = k;
 #pragma unroll
-  for (int j = 0; j < 5; ++j) tr.w[j] = tr.e[imin(tr.n, k - 1 + j)];
+  for (int j = 0; j < 5; ++j) tr.w[j] = tr.e.at(imin(tr.n, k - 1 + j));
   tr.x0 = (tr.w[0] + tr.w[1]) / 2.0 / fs;
   tr.x1 = (tr.w[1] + tr.w[2]) / 2.0 / fs;
   tr.y0 = fs / (tr.w[1] - tr.w[0]);
@@ -273,7 +259,7 @@ __device__ __forceinline__ void raw_advance(RawTrack& tr, double fs) {
   if (k != tr.k) {                                              // the next interval: its left knot is the old right one
     tr.k = k;
     tr.w[0] = tr.w[1]; tr.w[1] = tr.w[2]; tr.w[2] = tr.w[3]; tr.w[3] = tr.w[4];
-    tr.w[4] = tr.e[imin(tr.n, k + 3)];
+    tr.w[4] = tr.e.at(imin(tr.n, k + 3));
     tr.x0 = tr.x1;
     tr.y0 = tr.y1;
     tr.x1 = (tr.w[1] + tr.w[2]) / 2.0 / fs;
@@ -283,7 +269,6 @@ __device__ __forceinline__ void raw_advance(RawTrack& tr, double fs) {
   }
   raw_next_knot(tr);
 }
-
 // quad_perm DPP: the value of lane (4 * (lane / 4) + Q) of the same quad
 template <int Q>
 __device__ __forceinline__ double quad_lane(double v) {
@@ -297,8 +282,9 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ run
                                                      int64_t n_items, const int64_t* __restrict__ boff,
                                                      const int* __restrict__ nb1_a, const int* __restrict__ ylen_a,
                                                      HvMeta m, const double* __restrict__ bf, double f0_floor,
-                                                     double f0_ceil, const int64_t* __restrict__ evoff,
-                                                     const double* __restrict__ events, const int* __restrict__ evcnt,
+                                                     double f0_ceil, int tiles_max, const int* __restrict__ tile_off,
+                                                     const int64_t* __restrict__ slot_off,
+                                                     const double* __restrict__ slots, const int* __restrict__ evcnt,
                                                      double* __restrict__ raw) {
   // item = ((run, channel), track), track fastest; threads past the end shadow the last item and store nothing
   const int64_t tid_all = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -308,12 +294,11 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ run
   const int run = (int)(item / m.nch), ch = (int)(item - (int64_t)run * m.nch);
   const int u = run_utt[run], k0 = run_first[run];
   const int k1 = imin(nb1_a[u], k0 + kRawRun);
-  const int cap = ylen_a[u] / 2 + 2;
+  const int nt = hv_tiles(ylen_a[u], m.step);
   const int c = evcnt[((int64_t)u * m.nch + ch) * 4 + ty];
   const double fs = m.afs;
   double* out = raw + (boff[u] + k0) * m.nch + ch;
   RawTrack tr;
-  tr.e = events + evoff[u] + ((int64_t)ch * 4 + ty) * cap;
   tr.n = c < 2 ? 0 : c - 1;
   // CheckEvent(n - 2) on all four tracks (:263-266): the quad's lanes agree on the outcome
   const bool mine_ok = tr.n > 2;
@@ -325,7 +310,14 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const int* __restrict__ run
       for (int k = k0; k < k1; ++k) out[(int64_t)(k - k0) * m.nch] = 0.0;
     return;
   }
-  tr.lo = zc_upper(tr.e, tr.n, fs, k0 * 1 / 1000.0);             // basic frame period 1 ms (:1174-1175)
+  {
+    const double t_first = k0 * 1 / 1000.0;                       // basic frame period 1 ms (:1174-1175)
+    const int64_t slot_cap = (int64_t)nt * kZcSlot;
+    tr.e.open(slots + slot_off[u] + ((int64_t)ch * 4 + ty) * slot_cap,
+              tile_off + ((int64_t)u * m.nch + ch) * (tiles_max + 1) * 4, ty, nt, (int)(t_first * fs) / m.step - 1);
+    tr.lo = slot_upper(tr.e, tr.n, fs, t_first, m.step,
+                       [&](double a, double b) { return (a + b) / 2.0 / fs <= t_first; });     // zc_upper's literal form
+  }
   raw_init(tr, fs);
   const double b = bf[ch];
   const double b_hi = b * 1.1, b_lo = b * 0.9;
@@ -1438,7 +1430,7 @@ static int hv_setup(Batch& b) {
   al((void**)&W->d_y, sizeof(double) * (size_t)W->tot_y);
   al((void**)&W->d_mean_part, sizeof(double) * (size_t)n_utt * kHvMeanTiles);
   if (m.r > 1) al((void**)&W->d_tmp, sizeof(double) * (size_t)W->tot_t);
-  al((void**)&W->d_events, sizeof(double) * (size_t)W->tot_ev);
+  // (W->d_events, the compacted lists, is gone: 0.58 GB at configs[2] that nobody reads any more)
   al((void**)&W->d_evcnt, sizeof(int) * (size_t)n_utt * m.nch * 4);
   {
     int ymax = 1;
@@ -1549,15 +1541,15 @@ int launch_harvest(Batch& b, const double* d_x, double* d_t, double* d_f0) {
     }
     hipLaunchKernelGGL(hv_band_scan_kernel, dim3(m.nch, n_utt), dim3(64), 0, st, W.d_ylen, m.nch, m.step, W.tiles_max,
                        W.d_tile_cnt, W.d_evcnt);
-    hipLaunchKernelGGL(hv_band_compact_kernel, dim3(m.nch, n_utt), dim3(256), 0, st, W.d_ylen, m.nch,
-                       m.step, W.tiles_max, W.d_tile_cnt, W.d_slot_off, W.d_slots, W.d_evoff, W.d_events);
+    // (no compaction of the staged events into contiguous lists any more: hv_raw_kernel reads the slots, SlotList)
   }
   {
     TimedScope ts_(b.ctx, "hv_raw_kernel");
     const int64_t items = W.n_runs * m.nch;                      // four threads (the four tracks) each
     hipLaunchKernelGGL(hv_raw_kernel, dim3((unsigned)((items * 4 + 255) / 256)), dim3(256), 0, st, W.d_run_utt, W.d_run_first,
-                       items, W.d_boff, W.d_nb1, W.d_ylen, m, W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.d_evoff, W.d_events,
-                       W.d_evcnt, W.d_raw);
+                       items, W.d_boff, W.d_nb1, W.d_ylen, m, W.d_bf, b.p.f0_floor, b.p.f0_ceil, W.tiles_max,
+                       (const int*)W.d_tile_cnt, (const int64_t*)W.d_slot_off, (const double*)W.d_slots,
+                       (const int*)W.d_evcnt, W.d_raw);
   }
   (void)hipMemsetAsync(W.d_ncand1, 0, sizeof(int) * (size_t)n_utt, st);
   if (m.nch > 192) return WM_ERR_UNSUPPORTED;                    // hv_detect_kernel: channel mask of 3 words

@@ -300,4 +300,69 @@ __device__ __forceinline__ int zc_upper(const double* __restrict__ e, int n, dou
   }
   return lo;
 }
+
+// ---- the ordered lists read where they were staged (round 5) ----------------------------------------------------
+// The ordered list of fine edges of one (signal, kind), read WHERE THE FILTER KERNEL STAGED IT: tile t of the signal left
+// its events of this kind at slot + t * kZcSlot, and the scanned counts (zc_scan_tiles) say which list indices a tile
+// holds -- off[4 t + kind] <= g < off[4 (t + 1) + kind].  Until round 5 a compaction kernel (zc_compact_signal) copied the
+// staged events into one contiguous list per (signal, kind) first -- 0.58 GB written and read again per pass of Harvest's
+// configs[2] (0.31 ms) -- for the sake of `e[g]`.  Harvest's consumer is a walk (consecutive indices), so a cursor on the
+// current tile serves it with a compare per access: 5.63 -> 5.36 ms per pass.  DIO's consumer brackets every frame on its
+// own (a thread per frame): the same lists through slots made dio_candidate_kernel 0.13 -> 0.24 ms for the 0.07 ms of
+// compaction saved (profiles/r05_v_dio_slots_ab.txt), so DIO keeps its compaction.
+struct SlotList {
+  const double* slot;             // the kind's slot rows of the signal
+  const int* off;                 // scanned tile offsets of the signal, layout [tile][kind], entry nt = the total
+  int kind, nt;
+  int tile, tb, te;               // cursor: list indices [tb, te) live in `tile`
+  __device__ __forceinline__ void open(const double* slot_, const int* off_, int kind_, int nt_, int tile_) {
+    slot = slot_; off = off_; kind = kind_; nt = nt_;
+    tile = tile_ < 0 ? 0 : (tile_ > nt_ - 1 ? nt_ - 1 : tile_);
+    tb = off[4 * tile + kind];
+    te = off[4 * (tile + 1) + kind];
+  }
+  __device__ __forceinline__ double at(int g) {              // 0 <= g < the list's length
+    while (g >= te && tile + 1 < nt) {                        // empty tiles are stepped over
+      ++tile;
+      tb = te;
+      te = off[4 * (tile + 1) + kind];
+    }
+    while (g < tb && tile > 0) {
+      --tile;
+      te = tb;
+      tb = off[4 * tile + kind];
+    }
+    return slot[(int64_t)tile * kZcSlot + (g - tb)];
+  }
+};
+// histc's count of knots at or before t -- knot j = (e[j] + e[j+1]) / 2 / fs, j < n -- over a SlotList, with `le(a, b)`
+// the caller's form of "knot of edges a, b <= t" (zc_upper's literal division, or zc_track's half-sum against hmax).
+// A knot lies between its two edges and an edge lies in its tile's sample range, so the count falls inside the tiles
+// around sample t fs: the bisection runs over those (a handful of probes near the cursor) and its two ends are CHECKED
+// against their neighbours; only a signal with empty tiles there takes the bisection over the whole list.
+template <class LE>
+__device__ __forceinline__ int slot_upper(SlotList& e, int n, double fs, double t, int step, LE le) {
+  const int t0 = (int)(t * fs) / step;
+  const int ta = imax(0, imin(e.nt - 1, t0 - 1)), tz = imax(0, imin(e.nt, t0 + 2));
+  int lo = imin(n, e.off[4 * ta + e.kind]), hi = imin(n, e.off[4 * tz + e.kind]);
+  const int lo0 = lo, hi0 = hi;
+  auto knot_le = [&](int j) {
+    const double a = e.at(j), b = e.at(j + 1);
+    return le(a, b);
+  };
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (knot_le(mid)) lo = mid + 1; else hi = mid;
+  }
+  const bool ok_lo = lo > lo0 || lo0 == 0 || knot_le(lo0 - 1);
+  const bool ok_hi = lo < hi0 || hi0 == n || !knot_le(hi0);
+  if (ok_lo && ok_hi) return lo;
+  lo = 0;
+  hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (knot_le(mid)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 }  // namespace wm
