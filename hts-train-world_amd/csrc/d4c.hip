@@ -797,11 +797,10 @@ int d4c_run(Batch& b, const double* d_x, const double* d_t, const double* d_f0, 
                        (const int*)b.d_perm_d4c, (const int*)b.d_part_n_d4c, d_ap);                               \
   } break;
   // fft_size_d4c 2048 (the headline's 16 kHz): WORLD_MI355_D4C_Q=1 selects the three-waves-per-SIMD form on the
-  // 512-point engine (d4c_q.hpp).  Built in round 5 because two waves looked latency-starved (SQ_ACTIVE_INST_VALU 36 %
-  // per wave); measured (profiles/r05_b_*): the same number of shader cycles per launch -- every wave64 vector
-  // instruction holds the SIMD for four cycles, and 2.52 M instructions per SIMD x 4.45 cycles already ARE the 11.4 M
-  // cycles of the two-wave launch -- 5 % more instructions, and a clock 12 % lower (2.26 -> 1.98 GHz: the denser issue
-  // costs power, and the kernels that follow inherit the lower clock).  5.05 -> 5.8 ms: off by default.
+  // 512-point engine (d4c_q.hpp).  Built in round 5 because two waves issue a vector instruction every 6.0 cycles where
+  // the SIMD could take one every 4; measured (profiles/r05_b_*): a third wave brings that to 5.8 -- whatever the waves
+  // wait for, another wave does not hide it -- for 5 % more instructions, at a clock 12 % lower (2.26 -> 1.98 GHz: the
+  // denser issue costs power, and the kernels that follow inherit the lower clock).  5.05 -> 5.8 ms: off by default.
   static const bool use_q = getenv("WORLD_MI355_D4C_Q") && atoi(getenv("WORLD_MI355_D4C_Q")) != 0;
 #define WM_D4CQ_LAUNCH(OB)                                                                                \
   {                                                                                                       \
