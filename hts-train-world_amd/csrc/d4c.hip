@@ -421,18 +421,14 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       const FrameGeom fg = frame_geom(fs, cf0, pos, 4.0);
       frame_packed<kHann, false, M>(xu, xl, fg, rtab, roff + 2 * Lw, lane, v);
       WM_PHASE_MARK(3)                                                                // Hann frame
-      rfft_forward_nz<N>(v, img, img, tw, lane, RARE ? M : (fg.L + 127) >> 7);
       double p[MB];
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        cpx s = img[lane + 64 * m];
-        p[m] = s.x * s.x + s.y * s.y;
-      }
       {
-        cpx s = img[N];
-        p[M] = s.x * s.x + s.y * s.y;
+        cpx xk[M], xn;                                   // the half spectrum stays in registers (rfft_split_regs)
+        rfft_forward_nz_regs<N>(v, img, tw, lane, RARE ? M : (fg.L + 127) >> 7, xk, xn);
+#pragma unroll
+        for (int m = 0; m < M; ++m) p[m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
+        p[M] = xn.x * xn.x + xn.y * xn.y;
       }
-      wave_sync();
 #pragma unroll
       for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
       if (lane == 0) arr[H] = p[M];
@@ -502,21 +498,22 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
         }
       }
       WM_PHASE_MARK(7)                                                                // band window
-      rfft_forward_nz<N>(v, img, img, tw, lane, (wl + 127) >> 7);
-      WM_PHASE_MARK(8)                                                                // band transform
       double p[MB];
       double tot = 0.0;
+      {
+        cpx xk[M], xn;
+        rfft_forward_nz_regs<N>(v, img, tw, lane, (wl + 127) >> 7, xk, xn);
+        WM_PHASE_MARK(8)                                                              // band transform
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        cpx s = img[lane + 64 * m];
-        p[m] = s.x * s.x + s.y * s.y;
-        tot += p[m];
-      }
-      p[M] = -1.0;
-      if (lane == 0) {
-        cpx s = img[N];
-        p[M] = s.x * s.x + s.y * s.y;
-        tot += p[M];
+        for (int m = 0; m < M; ++m) {
+          p[m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
+          tot += p[m];
+        }
+        p[M] = -1.0;
+        if (lane == 0) {
+          p[M] = xn.x * xn.x + xn.y * xn.y;
+          tot += p[M];
+        }
       }
       tot = wave_sum(tot);
       // Sum of all but the (bnd + 1) largest bins: cum[h - bnd - 1] keeps the h - bnd smallest
