@@ -248,7 +248,14 @@ __device__ __forceinline__ void fft_sync() {
 
 template <int N> struct FftCfg;
 template <> struct FftCfg<512>  { static constexpr int R1 = 8,  R2 = 8,  R3 = 8; };
+#ifndef WM_FFT_1024_SWAP
+#define WM_FFT_1024_SWAP 1
+#endif
+#if WM_FFT_1024_SWAP
+template <> struct FftCfg<1024> { static constexpr int R1 = 16, R2 = 16, R3 = 4; };   // second exchange by permlane swaps
+#else
 template <> struct FftCfg<1024> { static constexpr int R1 = 16, R2 = 8,  R3 = 8; };
+#endif
 template <> struct FftCfg<2048> { static constexpr int R1 = 16, R2 = 16, R3 = 8; };
 
 // LDS doubles2 needed by one transform of N points (padded image)
@@ -346,6 +353,77 @@ __device__ __forceinline__ void fft_pass1(const cpx (&v)[N / 64], cpx* lds, int 
   }
 }
 
+// Two registers trade halves (v_permlane32_swap: a' = [a(0:31), b(0:31)], b' = [a(32:63), b(32:63)]) or odd / even
+// rows of sixteen lanes (v_permlane16_swap: a' = rows [a0, b0, a2, b2], b' = rows [a1, b1, a3, b3]): a transposition of
+// one LANE bit (5 resp. 4) with the bit that tells the two registers apart, one instruction per pair of dwords.
+__device__ __forceinline__ void lane_swap32(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void lane_swap16(double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// passes 2 and 3 of the 16 x 16 x 4 plan (N = 1024): LDS image -> registers with ONE trip through LDS.
+// Pass 2 is one radix-16 butterfly per lane whose output r belongs at image position
+//   (lane / 16) 256 + lane % 16 + 16 r,
+// and butterfly b of pass 3 in lane L reads the positions L + 64 b + 256 r3, r3 < 4: the value comes from lane
+// L % 16 + 16 r3, register r = L / 16 + 4 b.  That second exchange moves nothing between the sixteen-lane rows'
+// COLUMNS: it is the transposition of lane bits (4, 5) with register bits (0, 1), i.e. two rounds of permlane swaps
+// (64 VALU instructions) instead of sixteen ds_write_b128 (13 LDS cycles each on gfx950, MI355X_MICROARCH.md) and
+// sixteen ds_read_b128 on a CU whose LDS pipe the transforms keep busy -- and one
+// wait for LDS less on the transform's critical path.  After the swaps register slot r3 + 4 b holds input r3 of
+// butterfly b.
+template <int N>
+__device__ __forceinline__ void fft_finish_swap4(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  constexpr int M = N / 64;
+  static_assert(M == 16 && FftCfg<N>::R1 == 16 && FftCfg<N>::R2 == 16 && FftCfg<N>::R3 == 4, "16 x 16 x 4");
+  fft_sync();
+  cpx a[16];
+#pragma unroll
+  for (int m = 0; m < M; ++m) a[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
+  fft_sync();
+  {
+    cpx pw[4];
+    pw[0] = tw.w2;
+    pw[1] = csqr(pw[0]);
+    pw[2] = csqr(pw[1]);
+    pw[3] = csqr(pw[2]);
+    TwDft<16>::run(a, pw);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r & 2) == 0) {
+      lane_swap32(a[r].x, a[r + 2].x);
+      lane_swap32(a[r].y, a[r + 2].y);
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r & 1) == 0) {
+      lane_swap16(a[r].x, a[r + 1].x);
+      lane_swap16(a[r].y, a[r + 1].y);
+    }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    cpx c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = a[r + 4 * b];
+    cpx pw[4];
+    pw[0] = tw.w3(b);
+    pw[1] = csqr(pw[0]);
+    pw[2] = pw[1];
+    pw[3] = pw[1];
+    TwDft<4>::run(c, pw);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[b + 4 * r] = c[r];
+  }
+}
+
 // passes 2 and 3: LDS image -> registers
 template <int N>
 __device__ __forceinline__ void fft_finish(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
@@ -354,6 +432,10 @@ __device__ __forceinline__ void fft_finish(cpx (&v)[N / 64], cpx* lds, const Fft
   constexpr int S2 = M / R2, S3 = M / R3;
   static_assert(S2 >= 1 && S3 >= 1, "radix plan does not fit 64 lanes");
   static_assert(R1 * R2 * R3 == N, "radix plan");
+  if constexpr (R3 == 4 && M == 16) {
+    fft_finish_swap4<N>(v, lds, tw, lane);
+    return;
+  }
   fft_sync();
 #pragma unroll
   for (int m = 0; m < M; ++m) v[m] = lds[fft_pad<N>((unsigned)lane + 64u * m)];
