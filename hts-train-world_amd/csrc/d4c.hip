@@ -408,10 +408,13 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     }
     wave_sync();
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);  // d4c.cpp:139
-    double sc[MB];
+    // The centroid waits in the smoothing's own layout (BI consecutive bins per lane; bins past H: whatever the margin
+    // holds, they only ever meet other bins past H), so that the elementwise steps between the smoothings below ride on
+    // the smoothings' stores.
+    constexpr int BI = SmoothCfg<H, kBM>::kBi;
+    double sc[BI];
 #pragma unroll
-    for (int m = 0; m < M; ++m) sc[m] = arr[lane + 64 * m];
-    sc[M] = arr[H];
+    for (int q = 0; q < BI; ++q) sc[q] = arr[lane * BI + q];
     wave_sync();
     WM_PHASE_MARK(2)                                                                  // DC correction of the centroid
 
@@ -421,39 +424,26 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       const FrameGeom fg = frame_geom(fs, cf0, pos, 4.0);
       frame_packed<kHann, false, M>(xu, xl, fg, rtab, roff + 2 * Lw, lane, v);
       WM_PHASE_MARK(3)                                                                // Hann frame
-      double p[MB];
       {
-        cpx xk[M], xn;                                   // the half spectrum stays in registers (rfft_split_regs)
-        rfft_forward_nz_regs<N>(v, img, tw, lane, RARE ? M : (fg.L + 127) >> 7, xk, xn);
+        cpx xk[M / 2], xr[M / 2], xh;                    // the half spectrum stays in registers (rfft_split_pairs)
+        rfft_forward_nz_pairs<N>(v, img, tw, lane, RARE ? M : (fg.L + 127) >> 7, xk, xr, xh);
 #pragma unroll
-        for (int m = 0; m < M; ++m) p[m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
-        p[M] = xn.x * xn.x + xn.y * xn.y;
+        for (int m = 0; m < M / 2; ++m) {
+          arr[lane + 64 * m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
+          arr[N - (lane + 64 * m)] = xr[m].x * xr[m].x + xr[m].y * xr[m].y;
+        }
+        if (lane == 0) arr[N / 2] = xh.x * xh.x + xh.y * xh.y;
       }
-#pragma unroll
-      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = p[m];
-      if (lane == 0) arr[H] = p[M];
       wave_sync();
     }
     WM_PHASE_MARK(4)                                                                  // its transform and power
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186): centroid / smoothed power, smoothed by f0 / 2, minus that smoothed by f0 ----
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane, [&](int q, double s) { return sc[q] / s; });
     WM_PHASE_MARK(5)                                                                  // DC correction + smoothing
-    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
-#pragma unroll
-    for (int m = 0; m < M; ++m) arr[lane + 64 * m] = sc[m] / arr[lane + 64 * m];
-    if (lane == 0) arr[H] = sc[M] / arr[H];
-    wave_sync();
-    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
-    double gd[MB];
-#pragma unroll
-    for (int m = 0; m < M; ++m) gd[m] = arr[lane + 64 * m];
-    gd[M] = arr[H];
-    wave_sync();
-    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
-#pragma unroll
-    for (int m = 0; m < M; ++m) gd[m] -= arr[lane + 64 * m];
-    gd[M] -= arr[H];
-    wave_sync();
+    double gd[BI];
+    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane, [&](int q, double s) { return gd[q] = s; });
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane, [&](int q, double s) { return gd[q] -= s; });
     WM_PHASE_MARK(6)                                                                  // group delay: two smoothings
 
     // ---- GetCoarseAperiodicity (d4c.cpp:192-223) ----
@@ -463,10 +453,11 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
     double coarse[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int band = 0; band < tab.nap; ++band) {
+      if (band > 0) {                 // the first band finds the group delay where the last smoothing stored it
 #pragma unroll
-      for (int m = 0; m < M; ++m) arr[lane + 64 * m] = gd[m];
-      if (lane == 0) arr[H] = gd[M];
-      wave_sync();
+        for (int q = 0; q < BI; ++q) arr[lane * BI + q] = gd[q];
+        wave_sync();
+      }
       const int center = (int)(kFreqInterval * (band + 1) * FD / fs);
       cpx v[M];
       // Window values in groups of four register pairs: the loads of a group are issued together with clamped
@@ -501,17 +492,18 @@ __global__ __launch_bounds__(64, WAVES) void d4c_kernel(
       double p[MB];
       double tot = 0.0;
       {
-        cpx xk[M], xn;
-        rfft_forward_nz_regs<N>(v, img, tw, lane, (wl + 127) >> 7, xk, xn);
+        cpx xk[M / 2], xr[M / 2], xh;                    // which lane holds which bin is all the same to what follows
+        rfft_forward_nz_pairs<N>(v, img, tw, lane, (wl + 127) >> 7, xk, xr, xh);
         WM_PHASE_MARK(8)                                                              // band transform
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-          p[m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
-          tot += p[m];
+        for (int m = 0; m < M / 2; ++m) {
+          p[2 * m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
+          p[2 * m + 1] = xr[m].x * xr[m].x + xr[m].y * xr[m].y;
+          tot += p[2 * m] + p[2 * m + 1];
         }
         p[M] = -1.0;
         if (lane == 0) {
-          p[M] = xn.x * xn.x + xn.y * xn.y;
+          p[M] = xh.x * xh.x + xh.y * xh.y;
           tot += p[M];
         }
       }

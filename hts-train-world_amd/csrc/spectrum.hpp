@@ -62,8 +62,12 @@ __device__ __forceinline__ void dc_correction_margin(double* arr, double f0, int
 }
 
 // LinearSmoothing in place on arr[0..HALF]; b = int(width * fft_size / fs) + 1 <= BM.
-template <int HALF, int BM>
-__device__ __forceinline__ void linear_smoothing_margin(double* arr, double width, int fs, int fft_size, int lane) {
+// `fin(q, s)` is what is stored for the lane's q-th bin (bin lane * kBi + q) whose smoothed value is s: a caller whose
+// next step is elementwise passes it here, with its other operand held in the SAME blocked layout (kBi consecutive bins
+// per lane), instead of reading the smoothed spectrum back in another layout and storing the result again.
+template <int HALF, int BM, class Fin>
+__device__ __forceinline__ void linear_smoothing_margin(double* arr, double width, int fs, int fft_size, int lane,
+                                                        Fin fin) {
   constexpr int CH = SmoothCfg<HALF, BM>::kCh, BI = SmoothCfg<HALF, BM>::kBi;
   const double inv_fft = 1.0 / fft_size;               // power of two: x * inv_fft == x / fft_size exactly
   const double wq = width * fft_size / fs;             // width in bins
@@ -118,8 +122,12 @@ __device__ __forceinline__ void linear_smoothing_margin(double* arr, double widt
   wave_sync();                                          // all knots read: the spectrum may be overwritten
   // unconditional: bins beyond HALF land in the right margin (rewritten by the next mirror fill)
 #pragma unroll
-  for (int q = 0; q < BI; ++q) arr[i0 + q] = out[q];
+  for (int q = 0; q < BI; ++q) arr[i0 + q] = fin(q, out[q]);
   wave_sync();
+}
+template <int HALF, int BM>
+__device__ __forceinline__ void linear_smoothing_margin(double* arr, double width, int fs, int fft_size, int lane) {
+  linear_smoothing_margin<HALF, BM>(arr, width, fs, fft_size, lane, [](int, double s) { return s; });
 }
 
 }  // namespace wm
