@@ -118,22 +118,16 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     WM_PHASE_MARK(1)
 
     // ---- GetPowerSpectrum (cheaptrick.cpp:64-82) ----
-    rfft_forward_nz<N>(v, img, img, tw, lane, (fg.L + 127) >> 7);     // the window reaches that many packed registers
+    // The half spectrum never goes to LDS: every bin's power is stored from the lane that computed it (rfft_split_pairs).
     {
-      double p[M + 1];
+      cpx xk[M / 2], xr[M / 2], xh;
+      rfft_forward_nz_pairs<N>(v, img, tw, lane, (fg.L + 127) >> 7, xk, xr, xh);   // the window reaches that many packed registers
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const cpx s = img[lane + 64 * m];
-        p[m] = s.x * s.x + s.y * s.y;
+      for (int m = 0; m < M / 2; ++m) {
+        pw[lane + 64 * m] = xk[m].x * xk[m].x + xk[m].y * xk[m].y;
+        pw[N - (lane + 64 * m)] = xr[m].x * xr[m].x + xr[m].y * xr[m].y;
       }
-      {
-        const cpx s = img[N];
-        p[M] = s.x * s.x + s.y * s.y;
-      }
-      wave_sync();
-#pragma unroll
-      for (int m = 0; m < M; ++m) pw[lane + 64 * m] = p[m];
-      if (lane == 0) pw[H] = p[M];
+      if (lane == 0) pw[N / 2] = xh.x * xh.x + xh.y * xh.y;
       wave_sync();
     }
     WM_PHASE_MARK(2)
@@ -141,25 +135,17 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
     WM_PHASE_MARK(3)
 
     // ---- LinearSmoothing (cheaptrick.cpp:176) + AddInfinitesimalNoise (:147-151) + log (:39-40) ----
-    linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane);
-    WM_PHASE_MARK(4)
+    // The noise and the logarithm ride on the smoothing's store, in the smoothing's layout (BI consecutive bins per lane;
+    // what lands past bin H is margin).  The draws of a lane's bins are requested before the smoothing starts.
     {
-      // the draws of all bins first (one trip to memory; a rolled loop made each bin wait for its own)
-      uint32_t rv[M + 1];
-      double pv[M + 1];
+      constexpr int BI = SmoothCfg<H, kBM>::kBi;
+      uint32_t rv[BI];
 #pragma unroll
-      for (int m = 0; m <= M; ++m) rv[m] = rtab[roff + fg.L + imin(lane + 64 * m, H)];
-#pragma unroll
-      for (int m = 0; m <= M; ++m) pv[m] = pw[imin(lane + 64 * m, H)];        // and the smoothed bins in one round trip
-#pragma unroll
-      for (int m = 0; m <= M; ++m) {
-        const int i = lane + 64 * m;
-        const double val = wm_log(pv[m] + fabs((double)rv[m] / 268435456.0 - 6.0) * kEps);
-        if (m < M || lane == 0) pw[i] = val;
-        __builtin_amdgcn_sched_barrier(0);                        // one bin at a time: keeps the register peak low
-      }
+      for (int q = 0; q < BI; ++q) rv[q] = rtab[roff + fg.L + imin(lane * BI + q, H)];
+      linear_smoothing_margin<H, kBM>(pw, cf0 * 2.0 / 3.0, fs, F, lane, [&](int q, double s) {
+        return wm_log(s + fabs((double)rv[q] / 268435456.0 - 6.0) * kEps);
+      });
     }
-    wave_sync();
     WM_PHASE_MARK(5)
 
     // ---- SmoothingWithRecovery (cheaptrick.cpp:22-57) ----
@@ -168,31 +154,41 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F >= 2048 ? 2 : 3)) void cheap
       const int i0 = 2 * (lane + 64 * m), i1 = i0 + 1;
       v[m] = make_double2(pw[i0 <= H ? i0 : F - i0], pw[i1 <= H ? i1 : F - i1]);
     }
-    rfft_forward<N>(v, img, img, tw, lane);
-    WM_PHASE_MARK(6)
     {
-      // lifters at quefrency i/fs: sin(pi f0 q)/(pi f0 q) and (1-2q1) + 2 q1 cos(2 pi f0 q);
-      // angle pi*f0*i/fs advances by a rotation per 64 bins; cos(2a) = 1 - 2 sin^2(a)
+      // The cepstrum stays in registers by pairs (quefrencies i and N - i in one lane), is liftered there, and goes
+      // straight into the inverse transform's operand.
+      cpx xk[M / 2], xr[M / 2], xh;
+      rfft_forward_pairs<N>(v, img, tw, lane, xk, xr, xh);
+      WM_PHASE_MARK(6)
+      // lifters at quefrency i / fs: sin(pi f0 q) / (pi f0 q) and (1 - 2 q1) + 2 q1 cos(2 pi f0 q), cos(2 a) = 1 - 2 sin^2(a).
+      // The angle pi f0 i / fs advances by a rotation per 64 bins; that of N - i follows from it and the (wave-uniform)
+      // angle of N, itself the double of N / 2's, which lane 0 needs for the middle bin.
+      const double a = cf0 / fs;
       CosGen g;
-      g.init(cf0 / fs, lane, 64);
-      double cx[M + 1];
+      g.init(a, lane, 64);
+      double sh, ch;
+      wm_sincospi(uniform_d(a * (N / 2)), &sh, &ch);
+      const double sn = 2.0 * sh * ch, cn = 1.0 - 2.0 * sh * sh;
+      auto lifter = [&](int i, double si) {
+        const double quef = (double)i / fs;
+        const double sl = si / (kPi * cf0 * quef);
+        const double cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * si * si);
+        return sl * cl;
+      };
 #pragma unroll
-      for (int m = 0; m <= M; ++m) cx[m] = img[imin(lane + 64 * m, H)].x;      // the cepstrum in one round trip
-#pragma unroll
-      for (int m = 0; m <= M; ++m) {
+      for (int m = 0; m < M / 2; ++m) {
         const int i = lane + 64 * m;
-        double sl = 1.0, cl = (1.0 - 2.0 * q1) + 2.0 * q1;
-        if (i > 0) {
-          const double quef = (double)i / fs;
-          sl = g.s / (kPi * cf0 * quef);
-          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * g.s * g.s);
-        }
-        if (m < M || lane == 0) img[i] = make_double2(cx[m] * sl * cl / F, 0.0);
+        double lk = (1.0 - 2.0 * q1) + 2.0 * q1;                                  // i = 0
+        if (i > 0) lk = lifter(i, g.s);
+        const double lr = lifter(N - i, sn * g.c - cn * g.s);
+        xk[m] = make_double2(xk[m].x * lk / F, 0.0);
+        xr[m] = make_double2(xr[m].x * lr / F, 0.0);
         g.next();
       }
+      xh = make_double2(xh.x * lifter(N / 2, sh) / F, 0.0);
+      WM_PHASE_MARK(7)
+      rfft_backward_pairs<N>(xk, xr, xh, v, img, tw, lane);
     }
-    WM_PHASE_MARK(7)
-    rfft_backward<N>(img, v, img, tw, lane);
     WM_PHASE_MARK(8)
     // x[2n], x[2n+1] for n = lane + 64 m: the first H + 1 samples are the envelope's logarithm
     double* row = sp + frame * (int64_t)(H + 1);

@@ -658,6 +658,48 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
   fft_backward<N>(v, lds, tw, lane);
 }
 
+// The inverse real transform from a half spectrum held by PAIRS as rfft_split_pairs leaves it (xk[m] = X[k],
+// xr[m] = X[N - k], k = lane + 64 m < N / 2; lane 0, m = 0: X[0] and X[N], imaginary parts ignored; xh = X[N / 2] in
+// lane 0): Z[k] and Z[N - k] are again the same sums and differences under twiddles that differ in sign, so one lane
+// computes both and only Z[N - k] travels (through LDS) to the lane and register it belongs to -- half a store and half
+// a read per element where rfft_backward reads a stored spectrum twice.
+template <int N>
+__device__ __forceinline__ void rfft_backward_pairs(const cpx (&xk)[N / 128], const cpx (&xr)[N / 128], cpx xh,
+                                                    cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  constexpr int M = N / 64;
+  asm volatile("" : "+v"(lane));
+  const_cast<FftTw<N>&>(tw).fence();
+  const cpx wc = cconj(tw.wsplit);                           // conj(W_2N^lane) = e^{+j pi lane / N}
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < M / 2; ++m) {
+    const int k = lane + 64 * m;
+    cpx a = xk[m], bz = xr[m];
+    if (m == 0) {                                            // Im(DC), Im(Nyquist) ignored
+      a.y = lane == 0 ? 0.0 : a.y;
+      bz.y = lane == 0 ? 0.0 : bz.y;
+    }
+    const cpx w = m == 0 ? wc : cmul(wc, cconj(cis64(m * (2048 / N))));
+    const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
+    const double pr = __builtin_fma(dy, w.x, dx * w.y), pi = __builtin_fma(dx, w.x, -(dy * w.y));
+    v[m] = make_double2(sx - pr, sy + pi);
+    const cpx zr = make_double2(sx + pr, pi - sy);           // Z[N - k]
+    if (m > 0 || lane > 0) lds[N - k] = zr;
+  }
+  if (lane == 0) lds[N / 2] = make_double2(2.0 * xh.x, -2.0 * xh.y);
+  wave_sync();
+#pragma unroll
+  for (int m = M / 2; m < M; ++m) v[m] = lds[lane + 64 * m];
+  fft_backward<N>(v, lds, tw, lane);
+}
+
+template <int N>
+__device__ __forceinline__ void rfft_forward_pairs(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane,
+                                                   cpx (&xk)[N / 128], cpx (&xr)[N / 128], cpx& xh) {
+  fft_forward<N>(v, lds, tw, lane);
+  rfft_split_pairs<N>(v, lds, tw, lane, xk, xr, xh);
+}
+
 // ---- N = 256 (fft_size 512: CheapTrick / Synthesis / codec at fs <= 12.8 kHz, cheaptrick.cpp:191-194) ----------
 // Four elements per lane leave no room for a three-pass radix plan, and the case is rare (8 kHz speech), so the
 // 256-point transform rides on the 512-point one: interleaving the input with zeros, z'[2 n] = z[n], z'[2 n + 1] = 0,

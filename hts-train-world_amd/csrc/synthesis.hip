@@ -47,6 +47,13 @@ __device__ __forceinline__ double coarse_vuv(const double* __restrict__ f0, int 
 
 // Part 1 of GetTimeBase (synthesis.cpp:287-307): per-sample interpolation of the coarse f0 / vuv
 // contours and the phase increment 2 pi f0 / fs.  Fully parallel over samples.
+// The f0-only kernels are latency chains of a few waves that run BESIDE the frame kernels of the analysis (CheapTrick,
+// D4C) or of an earlier part's render stage, whose waves fill every SIMD: at equal priority a chain wave gets the
+// issue slots the older waves leave.  Raised priority hands a chain its slot whenever it is ready -- it needs few.
+#ifndef WM_CHAIN_PRIO_LEVEL
+#define WM_CHAIN_PRIO_LEVEL 3
+#endif
+#define WM_CHAIN_PRIO __builtin_amdgcn_s_setprio(WM_CHAIN_PRIO_LEVEL);
 // (All f0-only kernels take their utterances through a list: Synthesis prepares the batch in two parts, the
 // shortest utterances first -- synthesis_prepare_part.)
 __global__ __launch_bounds__(256) void synth_inc_kernel(
@@ -55,6 +62,7 @@ __global__ __launch_bounds__(256) void synth_inc_kernel(
     double* __restrict__ inc_out) {
   // bit-exact increments are required (see synth_timebase_kernel): no FMA contraction
 #pragma clang fp contract(off)
+  WM_CHAIN_PRIO
   const int u = utts[blockIdx.y];
   const double* f0u = f0 + f_off[u];
   const int nf = (int)(f_off[u + 1] - f_off[u]);
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(256) void synth_inc_kernel(
 __global__ __launch_bounds__(64) void synth_timebase_kernel(const int* __restrict__ utts,
                                                             const int64_t* __restrict__ y_off, double* phase) {
 #pragma clang fp contract(off)
+  WM_CHAIN_PRIO
   const int u = utts[blockIdx.x], lane = threadIdx.x;
   const int64_t yb = y_off[u];
   const int ylen = (int)(y_off[u + 1] - yb);
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(256) void synth_pulse_search_kernel(
     int tiles_max, int* __restrict__ tile_cnt, int* __restrict__ pulse_idx, double* __restrict__ pulse_shift,
     int* __restrict__ pulse_cnt) {
 #pragma clang fp contract(off)
+  WM_CHAIN_PRIO
   __shared__ int wave_cnt[kSearchSub][4];
   __shared__ int red[4];
   const int u = utts[blockIdx.y], tile = blockIdx.x;
