@@ -594,9 +594,11 @@ __device__ __forceinline__ void rfft_split(cpx (&v)[N / 64], cpx* lds, cpx* spec
 // Only the upper half of Z goes through LDS (half the stores, reads and twiddles of rfft_split); the bins
 // above N / 2 come out in the lanes of their partners, which is all the same to a consumer that stores them by index or
 // sums / sorts them.
-template <int N>
-__device__ __forceinline__ void rfft_split_pairs(const cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane,
-                                                 cpx (&xk)[N / 128], cpx (&xr)[N / 128], cpx& xh) {
+// The functor forms hand each pair on as it is computed -- f(m, X[k], X[N - k]) for m < M / 2, then f(M / 2, X[N / 2],
+// X[N / 2]) (lane 0's is the bin) -- so that a consumer which stores or transforms the values at once keeps neither
+// array alive; the array forms below are wrappers.
+template <int N, class F>
+__device__ __forceinline__ void rfft_split_pairs_f(const cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane, F f) {
   constexpr int M = N / 64;
   asm volatile("" : "+v"(lane));
   wave_sync();
@@ -616,11 +618,24 @@ __device__ __forceinline__ void rfft_split_pairs(const cpx (&v)[N / 64], cpx* ld
     const cpx w = m == 0 ? wh : cmul(wh, cis64(m * (2048 / N)));
     const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
     const double pr = __builtin_fma(w.x, dy, w.y * dx), pi = __builtin_fma(w.y, dy, -(w.x * dx));
-    xk[m] = make_double2(__builtin_fma(0.5, sx, pr), __builtin_fma(0.5, sy, pi));
-    xr[m] = make_double2(__builtin_fma(0.5, sx, -pr), __builtin_fma(-0.5, sy, pi));
+    f(m, make_double2(__builtin_fma(0.5, sx, pr), __builtin_fma(0.5, sy, pi)),
+      make_double2(__builtin_fma(0.5, sx, -pr), __builtin_fma(-0.5, sy, pi)));
   }
-  xh = make_double2(v[M / 2].x, -v[M / 2].y);                           // lane 0: X[N / 2] = conj Z[N / 2]
+  const cpx xh = make_double2(v[M / 2].x, -v[M / 2].y);                 // lane 0: X[N / 2] = conj Z[N / 2]
+  f(M / 2, xh, xh);
   wave_sync();
+}
+template <int N>
+__device__ __forceinline__ void rfft_split_pairs(const cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane,
+                                                 cpx (&xk)[N / 128], cpx (&xr)[N / 128], cpx& xh) {
+  rfft_split_pairs_f<N>(v, lds, tw, lane, [&](int m, cpx a, cpx b) {
+    if (m < N / 128) {
+      xk[m < N / 128 ? m : 0] = a;
+      xr[m < N / 128 ? m : 0] = b;
+    } else {
+      xh = a;
+    }
+  });
 }
 template <int N>
 __device__ __forceinline__ void rfft_forward_nz_pairs(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane, int nz,
@@ -663,9 +678,16 @@ __device__ __forceinline__ void rfft_backward(const cpx* spec, cpx (&v)[N / 64],
 // lane 0): Z[k] and Z[N - k] are again the same sums and differences under twiddles that differ in sign, so one lane
 // computes both and only Z[N - k] travels (through LDS) to the lane and register it belongs to -- half a store and half
 // a read per element where rfft_backward reads a stored spectrum twice.
-template <int N>
-__device__ __forceinline__ void rfft_backward_pairs(const cpx (&xk)[N / 128], const cpx (&xr)[N / 128], cpx xh,
-                                                    cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+// The un-split of one pair: Z[k] (returned) and Z[N - k] from X[k] = a and X[N - k] = bz under w = conj(W_2N^k).
+__device__ __forceinline__ cpx rfft_unsplit_pair(cpx a, cpx bz, cpx w, cpx& zr) {
+  const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
+  const double pr = __builtin_fma(dy, w.x, dx * w.y), pi = __builtin_fma(dx, w.x, -(dy * w.y));
+  zr = make_double2(sx + pr, pi - sy);
+  return make_double2(sx - pr, sy + pi);
+}
+// g(m, xk, xr) fills the pair m < M / 2; g(M / 2, xh, .) the middle bin.  Leaves v = Z, the operand of fft_backward.
+template <int N, class G>
+__device__ __forceinline__ void rfft_unsplit_pairs_f(G g, cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
   constexpr int M = N / 64;
   asm volatile("" : "+v"(lane));
   const_cast<FftTw<N>&>(tw).fence();
@@ -674,29 +696,44 @@ __device__ __forceinline__ void rfft_backward_pairs(const cpx (&xk)[N / 128], co
 #pragma unroll
   for (int m = 0; m < M / 2; ++m) {
     const int k = lane + 64 * m;
-    cpx a = xk[m], bz = xr[m];
+    cpx a, bz;
+    g(m, a, bz);
     if (m == 0) {                                            // Im(DC), Im(Nyquist) ignored
       a.y = lane == 0 ? 0.0 : a.y;
       bz.y = lane == 0 ? 0.0 : bz.y;
     }
     const cpx w = m == 0 ? wc : cmul(wc, cconj(cis64(m * (2048 / N))));
-    const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
-    const double pr = __builtin_fma(dy, w.x, dx * w.y), pi = __builtin_fma(dx, w.x, -(dy * w.y));
-    v[m] = make_double2(sx - pr, sy + pi);
-    const cpx zr = make_double2(sx + pr, pi - sy);           // Z[N - k]
+    cpx zr;
+    v[m] = rfft_unsplit_pair(a, bz, w, zr);
     if (m > 0 || lane > 0) lds[N - k] = zr;
   }
-  if (lane == 0) lds[N / 2] = make_double2(2.0 * xh.x, -2.0 * xh.y);
+  {
+    cpx xh, unused;
+    g(M / 2, xh, unused);
+    if (lane == 0) lds[N / 2] = make_double2(2.0 * xh.x, -2.0 * xh.y);
+  }
   wave_sync();
 #pragma unroll
   for (int m = M / 2; m < M; ++m) v[m] = lds[lane + 64 * m];
+}
+template <int N>
+__device__ __forceinline__ void rfft_backward_pairs(const cpx (&xk)[N / 128], const cpx (&xr)[N / 128], cpx xh,
+                                                    cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  rfft_unsplit_pairs_f<N>([&](int m, cpx& a, cpx& b) {
+    if (m < N / 128) {
+      a = xk[m < N / 128 ? m : 0];
+      b = xr[m < N / 128 ? m : 0];
+    } else {
+      a = xh;
+    }
+  }, v, lds, tw, lane);
   fft_backward<N>(v, lds, tw, lane);
 }
-
-template <int N>
+template <int N, int NZM = N / 64>
 __device__ __forceinline__ void rfft_forward_pairs(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane,
                                                    cpx (&xk)[N / 128], cpx (&xr)[N / 128], cpx& xh) {
-  fft_forward<N>(v, lds, tw, lane);
+  if constexpr (N < 512) fft_forward<N>(v, lds, tw, lane);          // 256 points ride on the 512-point plan, unpruned
+  else fft_forward<N, NZM>(v, lds, tw, lane);
   rfft_split_pairs<N>(v, lds, tw, lane, xk, xr, xh);
 }
 
