@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void dio_lowcut_fft_kernel(
     const int i0 = base + 2 * (lane + 64 * m);
     v[m] = make_double2(dio_y(xu, n, ylen, fftn, mu, i0), dio_y(xu, n, ylen, fftn, mu, i0 + 1));
   }
-  cpx zr[M + 1];
+  ConvSpec<B> zr;
   conv_forward<B>(v, img, tw, lane, zr);
   conv_apply<B>(zr, H, img, tw, lane, v);
   double* zu = z + z_off[u];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64, B > 2048 ? 1 : 2) void dio_band_fft_kernel(
     const double a = zu[imin(hi - 1, imax(lo, i0))], c = zu[imin(hi - 1, imax(lo, i1))];
     v[m] = make_double2(i0 >= lo && i0 < hi ? a : 0.0, i1 >= lo && i1 < hi ? c : 0.0);
   }
-  cpx zr[M + 1];
+  ConvSpec<B> zr;
   conv_forward<B>(v, img, tw, lane, zr);
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
 #pragma unroll 1

@@ -72,34 +72,42 @@ __global__ __launch_bounds__(64) void conv_spectrum_kernel(const double* __restr
   for (int k = lane; k <= N; k += 64) Hf[k] = make_double2(img[k].x * inv, img[k].y * inv);
 }
 
-// Forward transform of a block given as packed pairs v[m] = (blk[2q], blk[2q + 1]), q = lane + 64 m; on exit
-// z[m] = Z[lane + 64 m], m < M, and z[M] = Z[B / 2] (every lane).
+// The spectrum of a block, held by PAIRS in registers (fft.hpp, rfft_split_pairs): k[m] = Z[j], r[m] = Z[N - j] for
+// j = lane + 64 m < N / 2 (lane 0, m = 0: Z[0] and Z[N]), h = Z[N / 2] (lane 0's counts).
+template <int B> struct ConvSpec {
+  cpx k[ConvCfg<B>::M / 2], r[ConvCfg<B>::M / 2], h;
+};
+
+// Forward transform of a block given as packed pairs v[m] = (blk[2q], blk[2q + 1]), q = lane + 64 m.
 template <int B>
 __device__ __forceinline__ void conv_forward(cpx (&v)[ConvCfg<B>::M], cpx* img, const FftTw<ConvCfg<B>::N>& tw, int lane,
-                                             cpx (&z)[ConvCfg<B>::M + 1]) {
-  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M;
-  rfft_forward<N>(v, img, img, tw, lane);
-#pragma unroll
-  for (int m = 0; m < M; ++m) z[m] = img[lane + 64 * m];
-  z[M] = img[N];
-  wave_sync();
+                                             ConvSpec<B>& z) {
+  constexpr int N = ConvCfg<B>::N;
+  rfft_forward_pairs<N>(v, img, tw, lane, z.k, z.r, z.h);
 }
 
-// out = IFFT(Z . H): v[m] = (out[2q], out[2q + 1]).
+// out = IFFT(Z . H): v[m] = (out[2q], out[2q + 1]).  The product is taken pair by pair as the inverse transform's
+// un-split consumes it: no spectrum goes through LDS on either side of it.
 template <int B>
-__device__ __forceinline__ void conv_apply(const cpx (&z)[ConvCfg<B>::M + 1], const cpx* __restrict__ Hf, cpx* img,
+__device__ __forceinline__ void conv_apply(const ConvSpec<B>& z, const cpx* __restrict__ Hf, cpx* img,
                                            const FftTw<ConvCfg<B>::N>& tw, int lane, cpx (&v)[ConvCfg<B>::M]) {
-  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M;
-  cpx h[M];
+  constexpr int N = ConvCfg<B>::N, M = ConvCfg<B>::M, MH = M / 2;
+  cpx hk[MH], hr[MH];
 #pragma unroll
-  for (int m = 0; m < M; ++m) h[m] = Hf[lane + 64 * m];
-  const cpx hN = Hf[N];
-  wave_sync();
-#pragma unroll
-  for (int m = 0; m < M; ++m) img[lane + 64 * m] = cmul(z[m], h[m]);
-  if (lane == 0) img[N] = cmul(z[M], hN);
-  wave_sync();
-  rfft_backward<N>(img, v, img, tw, lane);
+  for (int m = 0; m < MH; ++m) {
+    hk[m] = Hf[lane + 64 * m];
+    hr[m] = Hf[N - (lane + 64 * m)];
+  }
+  const cpx hh = Hf[N / 2];
+  rfft_unsplit_pairs_f<N>([&](int m, cpx& a, cpx& b) {
+    if (m < MH) {
+      a = cmul(z.k[m < MH ? m : 0], hk[m < MH ? m : 0]);
+      b = cmul(z.r[m < MH ? m : 0], hr[m < MH ? m : 0]);
+    } else {
+      a = cmul(z.h, hh);
+    }
+  }, v, img, tw, lane);
+  fft_backward<N>(v, img, tw, lane);
 }
 
 // The four zero-crossing passes (zcfilter.hpp: ZeroCrossingEngine, dio.cpp:357-393; kinds :402-435) of one block

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64, 2) void hv_band_fft_kernel(const int64_t* __res
     const double a = yu[imin(ylen - 1, imax(0, i0))], c = yu[imin(ylen - 1, imax(0, i1))];
     v[m] = make_double2(i0 >= 0 && i0 < ylen ? a : 0.0, i1 >= 0 && i1 < ylen ? c : 0.0);
   }
-  cpx zr[M + 1];
+  ConvSpec<B> zr;
   conv_forward<B>(v, img, tw, lane, zr);
   const int64_t slot_cap = (int64_t)nt * kZcSlot;
   const int ch_end = imin(nch, (grp + 1) * kHvChGroup);
