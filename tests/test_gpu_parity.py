@@ -67,6 +67,37 @@ def test_wavefront_fft_vs_numpy(gpu, n):
     assert np.abs(xb.cpu().numpy() / n - x.cpu().numpy()).max() < 1e-13
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_real_transforms_by_pairs(gpu, n):
+    """rfft_split_pairs / rfft_backward_pairs (csrc/fft.hpp): the lane that holds Z[k] computes X[k] AND X[N - k], only the
+    upper half of Z travels through LDS, and the inverse takes the pairs back.  Every bin against numpy, the round
+    trip against the input, the pruned first pass (rows zero from some register on) against the plain one; 512 points
+    ride on the 512-point complex plan (CheapTrick at fs <= 12.8 kHz)."""
+    import ctypes as C
+    torch, W, ctx = gpu
+    lib = C.CDLL(os.environ.get("WORLD_MI355_FFT_HOOK") or os.path.join(os.path.dirname(__file__), "hooks", "libfft_hook.so"))
+    vp = C.c_void_p
+    lib.FftHookRfftPairs.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    g = torch.Generator(device="cuda").manual_seed(7 * n)
+    M = n // 128
+    for reach in (M, max(1, M // 4), max(1, M // 2)):
+        x = torch.randn(64, n, dtype=torch.float64, device="cuda", generator=g)
+        x[:, 128 * reach:] = 0.0
+        ref = np.fft.rfft(x.cpu().numpy(), axis=1)
+        scale = np.abs(ref).max()
+        for nz in (-1, reach):
+            re = torch.full((64, n // 2 + 1), np.nan, dtype=torch.float64, device="cuda")
+            im, xb = torch.full_like(re, np.nan), torch.empty_like(x)
+            torch.cuda.synchronize()
+            assert lib.FftHookRfftPairs(vp(torch.cuda.current_stream().cuda_stream), n, 64, nz, vp(x.data_ptr()),
+                                        vp(re.data_ptr()), vp(im.data_ptr()), vp(xb.data_ptr())) == 0
+            got = re.cpu().numpy() + 1j * im.cpu().numpy()
+            assert np.isfinite(got).all(), "a bin no lane wrote"
+            assert np.abs(got - ref).max() < 1e-14 * n * scale, (reach, nz)
+            assert np.abs(got[:, [0, -1]].imag).max() == 0.0          # DC and Nyquist: real, exactly
+            assert np.abs(xb.cpu().numpy() / n - x.cpu().numpy()).max() < 1e-13, (reach, nz)
+
+
 @pytest.mark.parametrize("n", [1024, 2048, 4096])
 def test_pruned_first_pass_of_the_fft(gpu, n):
     """rfft_forward_nz (csrc/fft.hpp): the first pass of a transform whose operand is zero from some register on skips
