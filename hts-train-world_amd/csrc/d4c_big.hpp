@@ -358,6 +358,71 @@ __device__ __forceinline__ void real_power_halves(cpx (&va)[D4cBig<FD>::MS], cpx
   wave_sync();
 }
 
+// The same power spectrum with every transform's output taken BY PAIRS (fft.hpp, rfft_split_pairs): the lane that holds
+// element j of a transform also receives its partner (NS - j for the even bins' split, NS - 1 - j for the odd bins'), and
+// both bins of a pair are the same sums and differences -- for the odd bins X[2 j + 1] = e + w o and
+// X[2 (NS - 1 - j) + 1] = conj(e - w o) -- so only the upper half of each transform's output goes through LDS, half the
+// twiddles are built, and no spectrum is parked in LDS to be read back.  put(bin, value) is called for every bin
+// 0 .. FD / 2 exactly once, from whichever lane holds it, AFTER the last read of the image (it may store into it).
+template <int FD, class Put>
+__device__ __forceinline__ void real_power_pairs(cpx (&va)[D4cBig<FD>::MS], cpx (&vb)[D4cBig<FD>::MS], bool folded,
+                                                 int nz, cpx* img, const FftTw<D4cBig<FD>::NS>& tw, int lane, Put put) {
+  constexpr int NS = D4cBig<FD>::NS, MS = D4cBig<FD>::MS, MH = MS / 2;
+  cpx odd[MS];
+  {
+    cpx w = tw.wsplit;                                            // W_{2 NS}^lane
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      const cpx d = folded ? csub(va[m], vb[m]) : va[m];
+      odd[m] = cmul(d, w);
+      if (folded) va[m] = cadd(va[m], vb[m]);
+      w = cmul(w, tw.wstep());
+    }
+  }
+  // even bins 2 j: the real transform of 2 NS points as it is; j = lane + 64 m and NS - j, and NS / 2 in lane 0
+  double ek[MH], er[MH], eh = 0.0;
+  fft_forward_nz<NS>(va, img, tw, lane, nz);
+  rfft_split_pairs_f<NS>(va, img, tw, lane, [&](int m, cpx a, cpx b) {
+    if (m < MH) {
+      ek[m < MH ? m : 0] = a.x * a.x + a.y * a.y;
+      er[m < MH ? m : 0] = b.x * b.x + b.y * b.y;
+    } else {
+      eh = a.x * a.x + a.y * a.y;
+    }
+  });
+  // odd bins: X[2 j + 1] from O[j] and O[NS - 1 - j] with the twiddle W_FD^(2 j + 1)
+  double ok[MH], orr[MH];
+  fft_forward_nz<NS>(odd, img, tw, lane, nz);
+  store_upper<NS>(odd, img, lane);
+  {
+    const cpx w1 = cis_neg2pi(1.0 / (double)FD);                  // W_FD
+    cpx w = cmul(tw.wsplit, w1);                                  // W_FD^(2 lane + 1)
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      const cpx a = odd[m];
+      const cpx b = cconj(img[NS - 1 - (lane + 64 * m)]);
+      const cpx e = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+      const cpx d = csub(a, b);
+      const cpx o = make_double2(0.5 * d.y, -0.5 * d.x);          // (a - b) / (2 i)
+      const cpx wo = cmul(w, o);
+      const cpx xp = cadd(e, wo), xm = csub(e, wo);
+      ok[m] = xp.x * xp.x + xp.y * xp.y;
+      orr[m] = xm.x * xm.x + xm.y * xm.y;
+      w = cmul(w, tw.wstep());                                    // W_FD^128 = W_{2 NS}^64
+    }
+  }
+  wave_sync();                                                    // every partner is read: the image may be written
+#pragma unroll
+  for (int m = 0; m < MH; ++m) {
+    const int j = lane + 64 * m;
+    put(2 * j, ek[m]);
+    put(2 * j + 1, ok[m]);
+    put(2 * NS - 2 * j - 1, orr[m]);
+    put(2 * NS - 2 * j, er[m]);
+  }
+  if (lane == 0) put(NS, eh);
+}
+
 template <int FD>
 __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int* __restrict__ x_len,
@@ -370,7 +435,7 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
   constexpr int kImg = 2 * FftLds<NS>::kElems;
   constexpr int kRegion = SmoothCfg<H, kBM>::kRegion;
   constexpr int kTot = kImg > kRegion ? kImg : kRegion;
-  constexpr int T = (H + 1 + 63) / 64;                           // strided elements per lane of a spectrum
+  constexpr int T = SmoothCfg<H, kBM>::kBi;                       // consecutive bins per lane of the smoothing's layout
   __shared__ __attribute__((aligned(16))) double smem[kTot];
   double* arr = smem + kBM;
   cpx* img = reinterpret_cast<cpx*>(smem);
@@ -402,19 +467,13 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
 #pragma unroll
         for (int m = 0; m < MS; ++m) { va[m] = vp[m]; vb[m] = vp[m + MS]; }
       }
-      double pe[MS + 1], po[MS];
-      real_power_halves<FD>(va, vb, fg.L > 2 * NS, fg.L > 2 * NS ? MS : (fg.L + 127) >> 7, img, tw, lane, pe, po);
-      cpx* arr2 = reinterpret_cast<cpx*>(arr);
-#pragma unroll
-      for (int m = 0; m < MS; ++m) arr2[lane + 64 * m] = make_double2(pe[m], po[m]);   // bins 2 j, 2 j + 1
-      if (lane == 0) arr[H] = pe[MS];
+      real_power_pairs<FD>(va, vb, fg.L > 2 * NS, fg.L > 2 * NS ? MS : (fg.L + 127) >> 7, img, tw, lane,
+                           [&](int bin, double v) { arr[bin] = v; });
       wave_sync();
     }
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
-#pragma unroll
-    for (int t = 0; t < T; ++t) ps[t] = arr[imin(lane + 64 * t, H)];
-    wave_sync();
+    // the smoothed power waits in the smoothing's own layout (BI consecutive bins per lane) for the division below
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane, [&](int q, double s) { return ps[q] = s; });
     // ---- static centroid: gather the four quarters, DCCorrection (d4c.cpp:139) ----
     {
       double cq[4][MS / 2];                                      // all 32 loads in flight, then the LDS stores
@@ -433,20 +492,23 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_spectrum_kernel(
     }
     wave_sync();
     dc_correction_margin<H, kBM>(arr, cf0, fs, FD, lane);
-    // ---- GetStaticGroupDelay (d4c.cpp:170-186) ----
+    // ---- GetStaticGroupDelay (d4c.cpp:170-186): centroid / smoothed power, smoothed by f0 / 2 minus that by f0; the
+    //      elementwise steps ride on the smoothings' stores, the last one straight to the frame's row in HBM ----
+    {
+      double cb[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (lane + 64 * t <= H) arr[lane + 64 * t] = arr[lane + 64 * t] / ps[t];
-    wave_sync();
-    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane);
+      for (int q = 0; q < T; ++q) cb[q] = arr[lane * T + q];
+      wave_sync();
 #pragma unroll
-    for (int t = 0; t < T; ++t) ps[t] = arr[imin(lane + 64 * t, H)];      // the first smoothing, in the same registers
-    wave_sync();
-    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane);
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (lane + 64 * t <= H) GDf[lane + 64 * t] = ps[t] - arr[lane + 64 * t];
-    wave_sync();
+      for (int q = 0; q < T; ++q) arr[lane * T + q] = cb[q] / ps[q];
+      wave_sync();
+    }
+    linear_smoothing_margin<H, kBM>(arr, cf0 / 2.0, fs, FD, lane, [&](int q, double s) { return ps[q] = s; });
+    linear_smoothing_margin<H, kBM>(arr, cf0, fs, FD, lane, [&](int q, double s) {
+      const int i = lane * T + q;
+      if (i <= H) GDf[i] = ps[q] - s;
+      return s;
+    });
   }
 }
 
@@ -500,30 +562,26 @@ __global__ __launch_bounds__(64, FD > 4096 ? 1 : 2) void d4cb_band_kernel(const 
 #pragma unroll
       for (int m = MS / 2; m < MS; ++m) vp[m] = make_double2(0.0, 0.0);
     }
-    double pe[MS + 1], po[MS];
     cpx none[MS];
 #pragma unroll
     for (int m = 0; m < MS; ++m) none[m] = make_double2(0.0, 0.0);
-    real_power_halves<FD>(vp, none, false, (wl + 127) >> 7, img, tw, lane, pe, po);   // the window never folds
-    // through LDS into strided order (p[t] = bin lane + 64 t): the main lobe the peel removes is a run of
-    // neighbouring bins, which then sit in different lanes and go in one or two steps of peel_largest()
+    // every bin's power by index into LDS, then in strided order (p[t] = bin lane + 64 t): the main lobe the peel
+    // removes is a run of neighbouring bins, which then sit in different lanes and go in one or two steps of
+    // peel_largest()
+    real_power_pairs<FD>(vp, none, false, (wl + 127) >> 7, img, tw, lane,          // the window never folds
+                         [&](int bin, double v) { smem[bin] = v; });
+    wave_sync();
     double p[NP];
     double tot = 0.0;
-    {
-      cpx* flat2 = reinterpret_cast<cpx*>(smem);
 #pragma unroll
-      for (int m = 0; m < MS; ++m) flat2[lane + 64 * m] = make_double2(pe[m], po[m]);     // bins 2 j, 2 j + 1
-      wave_sync();
-#pragma unroll
-      for (int t = 0; t < 2 * MS; ++t) {
-        p[t] = smem[lane + 64 * t];
-        tot += p[t];
-      }
+    for (int t = 0; t < 2 * MS; ++t) {
+      p[t] = smem[lane + 64 * t];
+      tot += p[t];
     }
     p[2 * MS] = -1.0;
     if (lane == 0) {
-      p[2 * MS] = pe[MS];
-      tot += pe[MS];
+      p[2 * MS] = smem[2 * MS * 64];                                                 // bin FD / 2
+      tot += p[2 * MS];
     }
     tot = wave_sum(tot);
     // the (bnd + 1) largest of the FD / 2 + 1 values are left out (d4c.cpp:215-220): see d4c_kernel
