@@ -306,12 +306,12 @@ __device__ __forceinline__ double dio_select_wave(double cur, double past, doubl
                                                   double allowed) {
   const double ref = (cur * 3.0 - past) / 2.0;
   const double err = lane < nb ? fabs(ref - cv) : HUGE_VAL;
-  double m = err;
-#pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) m = fmin(m, __shfl_xor(m, sh, 64));
+  // exact minimum by DPP steps on the bit patterns (a chain of twelve ds_bpermute round trips before: this function is
+  // the body of a loop that runs once per frame of a voiced section, on one wavefront per utterance)
+  const double m = wave_min_nonneg(err);
   const unsigned long long at = __ballot(err == m);
   const int who = at ? __ffsll((long long)at) - 1 : 0;
-  const double best = __shfl(cv, who, 64);
+  const double best = readlane_d(cv, __builtin_amdgcn_readfirstlane(who));
   if (fabs(1.0 - best / ref) > allowed) return 0.0;
   return best;
 }

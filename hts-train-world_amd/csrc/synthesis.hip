@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void synth_timebase_kernel(const int* __restric
     // the running phase replaces the increment it came from (the ring read it long ago); wrapping
     // and the pulse search are per-sample work and live in synth_pulse_search_kernel
     if (i < ylen) phase[yb + i] = t;
-    carry = __shfl(t, 63, 64);
+    carry = lane63(t);                            // v_readlane (a ds_bpermute round trip per 64 samples before)
   }
 }
 
