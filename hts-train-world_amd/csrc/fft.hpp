@@ -729,6 +729,67 @@ __device__ __forceinline__ void rfft_backward_pairs(const cpx (&xk)[N / 128], co
   }, v, lds, tw, lane);
   fft_backward<N>(v, lds, tw, lane);
 }
+template <int N, class G>
+__device__ __forceinline__ void rfft_backward_pairs_f(G g, cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane) {
+  rfft_unsplit_pairs_f<N>(g, v, lds, tw, lane);
+  fft_backward<N>(v, lds, tw, lane);
+}
+
+// x -> irfft(mul . rfft(x)) in one go: forward transform (only v[0 .. nz) may be non-zero), then every pair is split,
+// handed to mul(m, X[k], X[N - k]) (m = M / 2: the middle bin, lane 0's counts) to be changed in place, and un-split
+// again at once: the spectrum never exists outside the pair in flight.  A lane reads its partner Z[N - k] from LDS and
+// later writes the new Z[N - k] to the same address, which no other lane reads: no barrier in between.
+template <int N, class Mul>
+__device__ __forceinline__ void rfft_filter_pairs(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane, int nz,
+                                                  Mul mul) {
+  constexpr int M = N / 64;
+  fft_forward_nz<N>(v, lds, tw, lane, nz);
+  asm volatile("" : "+v"(lane));
+  wave_sync();
+#pragma unroll
+  for (int m = M / 2; m < M; ++m) lds[lane + 64 * m] = v[m];
+  wave_sync();
+  const cpx wh = make_double2(0.5 * tw.wsplit.x, 0.5 * tw.wsplit.y);    // W_2N^k / 2
+#pragma unroll
+  for (int m = 0; m < M / 2; ++m) {
+    const int k = lane + 64 * m;
+    const cpx a = v[m];
+    cpx bz = lds[(N - k) & (N - 1)];
+    if (m == 0) {
+      bz.x = lane == 0 ? a.x : bz.x;
+      bz.y = lane == 0 ? a.y : bz.y;
+    }
+    const cpx w = m == 0 ? wh : cmul(wh, cis64(m * (2048 / N)));
+    const double sx = a.x + bz.x, sy = a.y - bz.y, dx = a.x - bz.x, dy = a.y + bz.y;
+    const double pr = __builtin_fma(w.x, dy, w.y * dx), pi = __builtin_fma(w.y, dy, -(w.x * dx));
+    cpx xk = make_double2(__builtin_fma(0.5, sx, pr), __builtin_fma(0.5, sy, pi));
+    cpx xr = make_double2(__builtin_fma(0.5, sx, -pr), __builtin_fma(-0.5, sy, pi));
+    mul(m, xk, xr);
+    if (m == 0) {                                            // Im(DC), Im(Nyquist) ignored
+      xk.y = lane == 0 ? 0.0 : xk.y;
+      xr.y = lane == 0 ? 0.0 : xr.y;
+    }
+    cpx zr;
+    v[m] = rfft_unsplit_pair(xk, xr, make_double2(2.0 * w.x, -2.0 * w.y), zr);      // conj(W_2N^k)
+    if (m > 0 || lane > 0) lds[N - k] = zr;
+  }
+  {
+    cpx xh = make_double2(v[M / 2].x, -v[M / 2].y), unused = xh;
+    mul(M / 2, xh, unused);
+    if (lane == 0) lds[N / 2] = make_double2(2.0 * xh.x, -2.0 * xh.y);
+  }
+  wave_sync();
+#pragma unroll
+  for (int m = M / 2; m < M; ++m) v[m] = lds[lane + 64 * m];
+  fft_backward<N>(v, lds, tw, lane);
+}
+
+template <int N, int NZM = N / 64, class F>
+__device__ __forceinline__ void rfft_forward_pairs_f(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane, F f) {
+  if constexpr (N < 512) fft_forward<N>(v, lds, tw, lane);          // 256 points ride on the 512-point plan, unpruned
+  else fft_forward<N, NZM>(v, lds, tw, lane);
+  rfft_split_pairs_f<N>(v, lds, tw, lane, f);
+}
 template <int N, int NZM = N / 64>
 __device__ __forceinline__ void rfft_forward_pairs(cpx (&v)[N / 64], cpx* lds, const FftTw<N>& tw, int lane,
                                                    cpx (&xk)[N / 128], cpx (&xr)[N / 128], cpx& xh) {

@@ -851,6 +851,10 @@ __global__ __launch_bounds__(64, F >= 4096 ? 1 : (F == 1024 ? 4 : (F < 1024 ? 3 
   }
 }
 
+}  // namespace wm
+#include "synth_pulse_bp.hpp"
+namespace wm {
+
 // y[n] += sum over pulses p (of this utterance, within [p_begin, p_end)) covering n, in pulse order:
 // index = j + idx - F/2 + 1  (synthesis.cpp:378-383)  ->  j = n - idx + F/2 - 1.
 // ONE WAVEFRONT owns a stretch of kOlaSeg consecutive output samples (lane l the pairs 2 l + 128 q, q < kOlaQ) and
@@ -1144,20 +1148,35 @@ static int synthesis_render_part(Batch& b, const SynPart& part, const double* d_
     const int grid = (int)(np < (int64_t)c.frame_grid ? np : (int64_t)c.frame_grid);
     if (piece >= 2) rc = wm_check(hipStreamWaitEvent(st, c.ev_ola[h], 0));
     if (rc) break;
-#define WM_SY_CASE(FF)                                                                                          \
+#define WM_SY_CASE(FF, KERNEL)                                                                                  \
   case FF: {                                                                                                    \
-    const int per_ = persistent_grid(c, synth_pulse_kernel<FF>, 64, (int64_t)1 << 40);                   \
-    hipLaunchKernelGGL(synth_pulse_kernel<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,             \
+    const int per_ = persistent_grid(c, KERNEL<FF>, 64, (int64_t)1 << 40);                               \
+    hipLaunchKernelGGL(KERNEL<FF>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,                         \
                        (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,                 \
                        (const int*)b.d_pulse_perm + p0, resp);                                                  \
   } break;
     {
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
+      // fft 2048 (two waves per SIMD): spectra by pairs in registers (synth_pulse_bp.hpp); WORLD_MI355_PULSE_BP=0: the
+      // strided form
+      static const bool bp = !(getenv("WORLD_MI355_PULSE_BP") && atoi(getenv("WORLD_MI355_PULSE_BP")) == 0);
       switch (F) {
-        WM_SY_CASE(512)
-        WM_SY_CASE(1024)
-        WM_SY_CASE(2048)
-        WM_SY_CASE(4096)
+        WM_SY_CASE(512, synth_pulse_kernel)
+        WM_SY_CASE(1024, synth_pulse_kernel)
+        case 2048:
+          if (bp) {
+            const int per_ = persistent_grid(c, synth_pulse_bp_kernel<2048>, 64, (int64_t)1 << 40);
+            hipLaunchKernelGGL(synth_pulse_bp_kernel<2048>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,
+                               (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,
+                               (const int*)b.d_pulse_perm + p0, resp);
+          } else {
+            const int per_ = persistent_grid(c, synth_pulse_kernel<2048>, 64, (int64_t)1 << 40);
+            hipLaunchKernelGGL(synth_pulse_kernel<2048>, dim3(imin(grid, per_)), dim3(64), 0, st, d_sp, d_ap,
+                               (const PulseRec*)b.d_pulse_rec, b.d_dc_remover, c.d_rng, fs, fp, p0, p1,
+                               (const int*)b.d_pulse_perm + p0, resp);
+          }
+          break;
+        WM_SY_CASE(4096, synth_pulse_kernel)
       }
     }
 #undef WM_SY_CASE
