@@ -1159,7 +1159,8 @@ static int synthesis_render_part(Batch& b, const SynPart& part, const double* d_
       TimedScope ts_(b.ctx, "synth_pulse_kernel");
       // fft 2048 (two waves per SIMD): spectra by pairs in registers (synth_pulse_bp.hpp); WORLD_MI355_PULSE_BP=0: the
       // strided form
-      static const bool bp = !(getenv("WORLD_MI355_PULSE_BP") && atoi(getenv("WORLD_MI355_PULSE_BP")) == 0);
+      const char* bp_env = getenv("WORLD_MI355_PULSE_BP");          // read per launch: a test switches it within a process
+      const bool bp = !(bp_env && atoi(bp_env) == 0);
       switch (F) {
         WM_SY_CASE(512, synth_pulse_kernel)
         WM_SY_CASE(1024, synth_pulse_kernel)

@@ -253,6 +253,35 @@ def test_other_sampling_rates(gpu, oracle, fs, fft):
     b.close()
 
 
+def test_pulse_kernel_forms_at_fft_2048(gpu, oracle):
+    """Synthesis at fft 2048 renders its pulses with the spectra held by pairs in registers (csrc/synth_pulse_bp.hpp);
+    WORLD_MI355_PULSE_BP=0 (read per launch) selects the strided form the other sizes use.  Same arithmetic per bin:
+    both against the oracle at the tolerance of y, and against each other far below it."""
+    torch, W, ctx = gpu
+    fs = 48000
+    xs = [sd.make_utterance(70 + i, fs, duration=0.5 + 0.1 * i) for i in range(3)]
+    b = W.WorldBatch(ctx, W.default_params(fs, 5.0), x_lengths=[len(x) for x in xs])
+    assert b.fft_size == 2048
+    t, f0, sp, ap = b.analyze(torch.from_numpy(np.concatenate(xs)).cuda())
+    old = os.environ.get("WORLD_MI355_PULSE_BP")
+    try:
+        os.environ["WORLD_MI355_PULSE_BP"] = "1"
+        y_pairs = b.synthesize(f0, sp, ap).cpu().numpy()
+        os.environ["WORLD_MI355_PULSE_BP"] = "0"
+        y_strided = b.synthesize(f0, sp, ap).cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop("WORLD_MI355_PULSE_BP", None)
+        else:
+            os.environ["WORLD_MI355_PULSE_BP"] = old
+    assert np.abs(y_pairs - y_strided).max() < 1e-11
+    r = oracle_chain(oracle, xs[0], fs)
+    n = len(r["y"])
+    np.testing.assert_allclose(y_pairs[:n], r["y"], atol=Y_TOL, rtol=0)
+    np.testing.assert_allclose(y_strided[:n], r["y"], atol=Y_TOL, rtol=0)
+    b.close()
+
+
 _D4C_Q_CHILD = r"""
 import importlib, sys
 import numpy as np, torch
